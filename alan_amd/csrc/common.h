@@ -1,0 +1,95 @@
+// Shared host/device helpers for libalan_mi355 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "alan_mi355.h"
+
+namespace alan {
+
+constexpr int MAXD = ALAN_MAX_DIMS;
+constexpr int MAXF = ALAN_MAX_FACTORS;
+constexpr int WAVE = 64;  // CDNA4 wavefront
+
+// n / d for n < 2^31, d >= 1, by multiply-high (no hardware integer divide on CDNA).
+struct FastDiv {
+    uint32_t d, m, l;
+};
+
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.l = l;
+    f.m = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+    return f;
+}
+
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv &f) {
+    return (__umulhi(n, f.m) + n) >> f.l;
+}
+
+template <typename T>
+struct Num;
+template <>
+struct Num<float> {
+    static constexpr float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+    __device__ static __forceinline__ float exp(float x) { return __expf(x); }
+    __device__ static __forceinline__ float log(float x) { return logf(x); }
+    __device__ static __forceinline__ float ninf() { return -__builtin_huge_valf(); }
+    __device__ static __forceinline__ float nan() { return __builtin_nanf(""); }
+};
+template <>
+struct Num<double> {
+    static constexpr double eps = 2.220446049250313e-16;  // torch.finfo(float64).eps
+    __device__ static __forceinline__ double exp(double x) { return ::exp(x); }
+    __device__ static __forceinline__ double log(double x) { return ::log(x); }
+    __device__ static __forceinline__ double ninf() { return -__builtin_huge_val(); }
+    __device__ static __forceinline__ double nan() { return __builtin_nan(""); }
+};
+
+template <typename T>
+__device__ __forceinline__ T load_as(const void *p, int dtype, int64_t off) {
+    return dtype == ALAN_F32 ? (T)((const float *)p)[off] : (T)((const double *)p)[off];
+}
+
+template <typename T>
+__device__ __forceinline__ void store_as(void *p, int dtype, int64_t off, T v) {
+    if (dtype == ALAN_F32)
+        ((float *)p)[off] = (float)v;
+    else
+        ((double *)p)[off] = (double)v;
+}
+
+// One-exp online log-sum-exp update of the running (max m, scaled sum s) with a new value x.
+// -inf contributes nothing; NaN poisons s (as torch's amax/exp/sum would).
+template <typename T>
+__device__ __forceinline__ void lse_push(T &m, T &s, T x) {
+    if (!(x == Num<T>::ninf())) {
+        T d = x - m;                         // +inf on the first finite value (m = -inf)
+        T e = Num<T>::exp(d > 0 ? -d : d);   // exp(-|d|)
+        s = d > 0 ? s * e + T(1) : s + e;
+        m = d > 0 ? x : m;
+    }
+}
+
+// Merge another lane's (m, s) into ours.
+template <typename T>
+__device__ __forceinline__ void lse_merge(T &m, T &s, T m2, T s2) {
+    T mm = m > m2 ? m : m2;
+    // (a NaN sum survives the multiply by 0, as it must)
+    T a = s * ((m == Num<T>::ninf()) ? T(0) : Num<T>::exp(m - mm));
+    T b = s2 * ((m2 == Num<T>::ninf()) ? T(0) : Num<T>::exp(m2 - mm));
+    s = a + b;
+    m = mm;
+}
+
+// log(s + eps) + m with the reference's corner cases: an all -inf slice gives NaN (x - max = NaN in
+// utils.py:219), and so does a +inf max.
+template <typename T>
+__device__ __forceinline__ T lse_finish(T m, T s) {
+    if (m == Num<T>::ninf() || m == -Num<T>::ninf()) return Num<T>::nan();
+    return Num<T>::log(s + Num<T>::eps) + m;
+}
+
+}  // namespace alan

@@ -1,0 +1,62 @@
+// Host-side planning: canonicalise an alan_reduce_desc_t (drop unit dims, order dims for
+// coalescing, merge contiguous dims) and pick a kernel + launch geometry.
+#pragma once
+#include "common.h"
+
+namespace alan {
+
+struct KTensor {
+    const void *p;
+    int32_t dtype;
+    float scale;
+    int64_t ks[MAXD];  // element stride per canonical keep dim
+    int64_t rs[MAXD];  // element stride per canonical reduce dim
+};
+
+// Kernel argument of the group kernel (passed by value; lives in the kernarg segment).
+struct GroupDesc {
+    int32_t nf, nk, nr, out_dtype;
+    uint32_t n_out, n_red;
+    FastDiv kdiv[MAXD], rdiv[MAXD];  // sizes, outermost first; index decomposition walks backwards
+    KTensor f[MAXF];
+    KTensor w;
+    void *out;
+    int64_t oks[MAXD];
+    double add_const;
+};
+
+struct GroupLaunch {
+    int logG;
+    bool block;
+    uint32_t grid;
+};
+
+// Canonical problem: keep dims and reduce dims, each ordered outermost -> innermost.
+struct Canon {
+    int nk = 0, nr = 0;
+    int64_t ksize[MAXD], rsize[MAXD];
+    int nf = 0;
+    KTensor f[MAXF];
+    KTensor w;       // w.p == nullptr when absent
+    KTensor o;       // output: ks only
+    int dominant = 0;      // index of the largest factor
+    int64_t n_out = 1, n_red = 1;
+    bool red_contig = false;   // dominant factor's unit-stride dim is the innermost reduce dim
+    bool keep_contig = false;  // ... is the innermost keep dim
+};
+
+// keep_mask / red_mask: bit d set => dim d of the descriptor is a keep / reduce dim.  Dims in
+// neither mask must have size 1 for every tensor that is read (they are ignored).
+int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask,
+                 const alan_tensor_t &out, Canon &c);
+
+int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl);
+
+int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream);
+
+// rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
+// fit it (caller then falls back to the group kernel).
+int try_launch_rows(const Canon &c, int mode, int compute_dtype, int out_dtype, double add_const,
+                    hipStream_t stream);
+
+}  // namespace alan

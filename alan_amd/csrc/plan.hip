@@ -1,0 +1,284 @@
+// Host side of alan_reduce: validation, canonicalisation, kernel choice, the PLATE two-stage plan.
+#include <algorithm>
+#include <cstring>
+
+#include "plan.h"
+
+namespace alan {
+
+static int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
+
+static bool valid_dtype(int32_t dt) { return dt == ALAN_F32 || dt == ALAN_F64; }
+static size_t dtype_bytes(int32_t dt) { return dt == ALAN_F64 ? 8 : 4; }
+
+int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask,
+                 const alan_tensor_t &out, Canon &c) {
+    if (d.ndim < 0 || d.ndim > MAXD) return ALAN_ERR_BAD_DESC;
+    if (d.n_factors < 1 || d.n_factors > MAXF) return ALAN_ERR_BAD_DESC;
+    for (int i = 0; i < d.ndim; ++i)
+        if (d.size[i] < 1) return ALAN_ERR_BAD_DESC;
+    for (int f = 0; f < d.n_factors; ++f)
+        if (!d.factor[f].data || !valid_dtype(d.factor[f].dtype)) return ALAN_ERR_BAD_DESC;
+    if (!out.data || !valid_dtype(out.dtype)) return ALAN_ERR_BAD_DESC;
+    const bool has_w = d.mode == ALAN_MODE_WEXPSUM;
+    if (has_w && (!d.weight.data || !valid_dtype(d.weight.dtype))) return ALAN_ERR_BAD_DESC;
+
+    // dominant factor: the one that spans the most elements of the space
+    int dom = 0;
+    double best = -1;
+    for (int f = 0; f < d.n_factors; ++f) {
+        double ext = 1;
+        for (int i = 0; i < d.ndim; ++i)
+            if (((keep_mask | red_mask) >> i) & 1)
+                if (d.factor[f].stride[i] != 0) ext *= (double)d.size[i];
+        if (ext > best) {
+            best = ext;
+            dom = f;
+        }
+    }
+    c.dominant = dom;
+
+    // order dims by the dominant factor's stride (outermost first); dims the dominant factor lacks
+    // are ordered by the largest stride any other tensor gives them and go outermost.
+    auto sort_key = [&](int i) -> int64_t {
+        int64_t s = iabs64(d.factor[dom].stride[i]);
+        if (s != 0) return s;
+        int64_t alt = 0;
+        for (int f = 0; f < d.n_factors; ++f) alt = std::max(alt, iabs64(d.factor[f].stride[i]));
+        return (int64_t)1 << 62 | alt;
+    };
+    auto gather = [&](uint32_t mask, int *idx) {
+        int n = 0;
+        for (int i = 0; i < d.ndim; ++i)
+            if (((mask >> i) & 1) && d.size[i] > 1) idx[n++] = i;
+        std::stable_sort(idx, idx + n, [&](int a, int b) { return sort_key(a) > sort_key(b); });
+        return n;
+    };
+    int kidx[MAXD], ridx[MAXD];
+    int nk = gather(keep_mask, kidx);
+    int nr = gather(red_mask, ridx);
+
+    c.nf = d.n_factors;
+    for (int f = 0; f < c.nf; ++f) {
+        c.f[f].p = d.factor[f].data;
+        c.f[f].dtype = d.factor[f].dtype;
+        c.f[f].scale = d.factor[f].scale;
+    }
+    c.w.p = has_w ? d.weight.data : nullptr;
+    c.w.dtype = d.weight.dtype;
+    c.w.scale = 1.f;
+    c.o.p = out.data;
+    c.o.dtype = out.dtype;
+    c.o.scale = 1.f;
+
+    // merge adjacent dims that every tensor strides through contiguously
+    auto build = [&](const int *idx, int n, bool keep, int64_t *size_out) -> int {
+        int m = 0;
+        int64_t fs[MAXF][MAXD], ws[MAXD], os[MAXD];
+        for (int j = 0; j < n; ++j) {
+            const int i = idx[j];
+            bool merged = false;
+            if (m > 0) {
+                const int64_t sz = d.size[i];
+                bool ok = true;
+                for (int f = 0; f < c.nf && ok; ++f) ok = fs[f][m - 1] == d.factor[f].stride[i] * sz;
+                if (ok && has_w) ok = ws[m - 1] == d.weight.stride[i] * sz;
+                if (ok && keep) ok = os[m - 1] == out.stride[i] * sz;
+                if (ok) {
+                    size_out[m - 1] *= sz;
+                    for (int f = 0; f < c.nf; ++f) fs[f][m - 1] = d.factor[f].stride[i];
+                    ws[m - 1] = d.weight.stride[i];
+                    os[m - 1] = out.stride[i];
+                    merged = true;
+                }
+            }
+            if (!merged) {
+                size_out[m] = d.size[i];
+                for (int f = 0; f < c.nf; ++f) fs[f][m] = d.factor[f].stride[i];
+                ws[m] = has_w ? d.weight.stride[i] : 0;
+                os[m] = keep ? out.stride[i] : 0;
+                ++m;
+            }
+        }
+        for (int j = 0; j < m; ++j) {
+            for (int f = 0; f < c.nf; ++f) (keep ? c.f[f].ks : c.f[f].rs)[j] = fs[f][j];
+            (keep ? c.w.ks : c.w.rs)[j] = ws[j];
+            if (keep) c.o.ks[j] = os[j];
+        }
+        return m;
+    };
+    c.nk = build(kidx, nk, true, c.ksize);
+    c.nr = build(ridx, nr, false, c.rsize);
+
+    c.n_out = 1;
+    c.n_red = 1;
+    for (int j = 0; j < c.nk; ++j) c.n_out *= c.ksize[j];
+    for (int j = 0; j < c.nr; ++j) c.n_red *= c.rsize[j];
+    if (c.n_out >= (1ll << 31) || c.n_red >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+    c.red_contig = c.nr > 0 && c.f[dom].rs[c.nr - 1] == 1;
+    c.keep_contig = c.nk > 0 && c.f[dom].ks[c.nk - 1] == 1;
+    return ALAN_OK;
+}
+
+int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl) {
+    std::memset(&gd, 0, sizeof(gd));
+    gd.nf = c.nf;
+    gd.nk = c.nk;
+    gd.nr = c.nr;
+    gd.out_dtype = out_dtype;
+    gd.n_out = (uint32_t)c.n_out;
+    gd.n_red = (uint32_t)c.n_red;
+    for (int j = 0; j < c.nk; ++j) gd.kdiv[j] = make_fastdiv((uint32_t)c.ksize[j]);
+    for (int j = 0; j < c.nr; ++j) gd.rdiv[j] = make_fastdiv((uint32_t)c.rsize[j]);
+    for (int f = 0; f < c.nf; ++f) gd.f[f] = c.f[f];
+    gd.w = c.w;
+    gd.out = const_cast<void *>(c.o.p);
+    for (int j = 0; j < c.nk; ++j) gd.oks[j] = c.o.ks[j];
+    gd.add_const = add_const;
+    if (gd.nr == 0) {  // the kernel's single-dim fast path reads rs[0]
+        gd.nr = 1;
+        gd.rdiv[0] = make_fastdiv(1);
+    }
+
+    // ---- lanes per output element
+    const int64_t want_threads = 256ll * 256 * 4;  // >= 4 workgroups per CU
+    int logG = 0;
+    if (c.n_red > 1) {
+        if (c.red_contig) {
+            while (logG < 6 && (c.n_red >> logG) > 4) ++logG;  // ~4 elements per lane
+        }
+        while (logG < 6 && (c.n_out << logG) < want_threads && (c.n_red >> logG) >= 2) ++logG;
+    }
+    gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 2048);
+    gl.logG = logG;
+    if (gl.block) {
+        gl.grid = (uint32_t)c.n_out;
+    } else {
+        const int64_t threads = c.n_out << logG;
+        if (threads >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+        gl.grid = (uint32_t)((threads + 255) / 256);
+    }
+    return ALAN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout of the per-(KEEP,PLATE) log-sum-exp values when the caller does not provide lse_out:
+// contiguous, dims ordered like the largest factor stores them (so stage 1 writes coalesced).
+static void plate_workspace_layout(const alan_reduce_desc_t &d, alan_tensor_t &v, int64_t &numel) {
+    int dom = 0;
+    double best = -1;
+    for (int f = 0; f < d.n_factors; ++f) {
+        double ext = 1;
+        for (int i = 0; i < d.ndim; ++i)
+            if (d.factor[f].stride[i] != 0) ext *= (double)d.size[i];
+        if (ext > best) best = ext, dom = f;
+    }
+    int idx[MAXD], n = 0;
+    for (int i = 0; i < d.ndim; ++i)
+        if (d.role[i] != ALAN_REDUCE) idx[n++] = i;
+    std::stable_sort(idx, idx + n, [&](int a, int b) {
+        const int64_t sa = iabs64(d.factor[dom].stride[a]), sb = iabs64(d.factor[dom].stride[b]);
+        return (sa == 0 ? (int64_t)1 << 62 : sa) > (sb == 0 ? (int64_t)1 << 62 : sb);
+    });
+    std::memset(&v, 0, sizeof(v));
+    int64_t st = 1;
+    for (int j = n - 1; j >= 0; --j) {
+        v.stride[idx[j]] = d.size[idx[j]] > 1 ? st : 0;
+        st *= d.size[idx[j]];
+    }
+    numel = st;
+}
+
+static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask, int mode,
+                      const alan_tensor_t &out, double add_const, hipStream_t stream) {
+    Canon c;
+    int rc = canonicalise(d, keep_mask, red_mask, out, c);
+    if (rc != ALAN_OK) return rc;
+    const int compute = out.dtype;
+    rc = try_launch_rows(c, mode, compute, out.dtype, add_const, stream);
+    if (rc != ALAN_ERR_UNSUPPORTED) return rc;
+    GroupDesc gd;
+    GroupLaunch gl;
+    rc = plan_group(c, out.dtype, add_const, gd, gl);
+    if (rc != ALAN_OK) return rc;
+    return launch_group(gd, gl, mode, compute, stream);
+}
+
+static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, uint32_t &plate) {
+    keep = red = plate = 0;
+    if (d.ndim < 0 || d.ndim > MAXD) return ALAN_ERR_BAD_DESC;
+    for (int i = 0; i < d.ndim; ++i) {
+        switch (d.role[i]) {
+            case ALAN_KEEP: keep |= 1u << i; break;
+            case ALAN_REDUCE: red |= 1u << i; break;
+            case ALAN_PLATE: plate |= 1u << i; break;
+            default: return ALAN_ERR_BAD_DESC;
+        }
+    }
+    if (plate && d.mode != ALAN_MODE_LSE) return ALAN_ERR_BAD_DESC;
+    if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM && d.mode != ALAN_MODE_WEXPSUM)
+        return ALAN_ERR_BAD_DESC;
+    return ALAN_OK;
+}
+
+}  // namespace alan
+
+using namespace alan;
+
+extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
+    if (!d) return 0;
+    uint32_t keep, red, plate;
+    if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
+    if (!plate || !red || d->lse_out.data) return 0;
+    int64_t numel = 1;
+    for (int i = 0; i < d->ndim; ++i)
+        if (d->role[i] != ALAN_REDUCE) numel *= d->size[i];
+    return ((size_t)numel * dtype_bytes(d->out.dtype) + 255) & ~(size_t)255;
+}
+
+extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!d) return ALAN_ERR_BAD_DESC;
+    hipStream_t stream = (hipStream_t)stream_;
+    uint32_t keep, red, plate;
+    int rc = classify(*d, keep, red, plate);
+    if (rc != ALAN_OK) return rc;
+
+    if (d->mode == ALAN_MODE_LSE && red == 0) {
+        // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,
+        // followed by the plate sum if any.
+        return run_single(*d, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
+    }
+    if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream);
+
+    // ---- log-sum-exp over REDUCE, then sum over PLATE (logpq.py:128,149)
+    alan_tensor_t v;
+    if (d->lse_out.data) {
+        v = d->lse_out;
+        if (!valid_dtype(v.dtype)) return ALAN_ERR_BAD_DESC;
+    } else {
+        int64_t numel;
+        plate_workspace_layout(*d, v, numel);
+        v.dtype = d->out.dtype;
+        if (!workspace || workspace_bytes < (size_t)numel * dtype_bytes(v.dtype)) return ALAN_ERR_WORKSPACE;
+        v.data = workspace;
+    }
+    v.scale = 1.f;
+    rc = run_single(*d, keep | plate, red, ALAN_MODE_LSE, v, 0.0, stream);
+    if (rc != ALAN_OK) return rc;
+
+    alan_reduce_desc_t s2;
+    std::memset(&s2, 0, sizeof(s2));
+    s2.mode = ALAN_MODE_SUM;
+    s2.ndim = d->ndim;
+    for (int i = 0; i < d->ndim; ++i) {
+        s2.size[i] = d->role[i] == ALAN_REDUCE ? 1 : d->size[i];
+        s2.role[i] = d->role[i] == ALAN_PLATE ? ALAN_REDUCE : ALAN_KEEP;
+    }
+    s2.n_factors = 1;
+    s2.factor[0] = v;
+    s2.out = d->out;
+    return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
+}
+
+extern "C" int alan_abi_version(void) { return 1; }
+extern "C" const char *alan_build_target(void) { return "gfx950"; }

@@ -1,0 +1,154 @@
+// alan_reduce: fused multi-factor broadcast-add + reduction (log-sum-exp / sum / weighted exp-sum)
+// over arbitrary strided factors.  Replaces reduce_Ks.py:249-251 (logsumexp_sum),
+// utils.py:207-225 (logsumexp_dims / logmeanexp_dims), logpq.py:149-153 (plate sum) and the
+// autograd backward of those.  gfx950 (CDNA4, wave64) only.
+//
+// Kernel families
+//   group kernel   G = 2^g lanes (1..64) or a whole 256-thread block cooperate on ONE output
+//                  element, striding over the flattened reduce index; any strides, any dtypes.
+//                  Lanes of a group read consecutive reduce elements, consecutive groups read
+//                  consecutive outputs, so whichever of the two is the dominant factor's contiguous
+//                  dim gives coalesced loads.
+//   rows kernel    (rows.hip) LDS-staged fast path for the dominant shape: reduce dim contiguous in
+//                  the largest factor (movielens F[M,Ka,Kb,Kz] over Kz), optional fused plate sum.
+#include "common.h"
+#include "plan.h"
+
+namespace alan {
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool BLOCK>
+__global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, const int logG) {
+    const uint32_t G = BLOCK ? 256u : (1u << logG);
+    uint32_t grp, gl;
+    if (BLOCK) {
+        grp = blockIdx.x;
+        gl = threadIdx.x;
+    } else {
+        const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+        grp = gid >> logG;
+        gl = gid & (G - 1u);
+    }
+    const bool active = grp < d.n_out;
+    uint32_t o = active ? grp : d.n_out - 1u;
+
+    // ---- decompose the output index over the keep dims (innermost last), once per thread
+    int64_t base[MAXF];
+    int64_t wbase = 0, obase = 0;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) base[f] = 0;
+    for (int k = d.nk - 1; k >= 0; --k) {
+        const uint32_t q = fd_div(o, d.kdiv[k]);
+        const int64_t idx = (int64_t)(o - q * d.kdiv[k].d);
+        o = q;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (f < d.nf) base[f] += idx * d.f[f].ks[k];
+        if (MODE == ALAN_MODE_WEXPSUM) wbase += idx * d.w.ks[k];
+        obase += idx * d.oks[k];
+    }
+
+    // ---- stream over the reduce index
+    T m = Num<T>::ninf(), s = T(0);
+    for (uint32_t r = gl; r < d.n_red; r += G) {
+        T x = T(0);
+        T w = T(1);
+        if (d.nr == 1) {
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < d.nf)
+                    x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, base[f] + (int64_t)r * d.f[f].rs[0]);
+            if (MODE == ALAN_MODE_WEXPSUM) w = load_as<T>(d.w.p, d.w.dtype, wbase + (int64_t)r * d.w.rs[0]);
+        } else {
+            int64_t off[MAXF];
+            int64_t woff = wbase;
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) off[f] = base[f];
+            uint32_t rr = r;
+            for (int k = d.nr - 1; k >= 0; --k) {
+                const uint32_t q = fd_div(rr, d.rdiv[k]);
+                const int64_t idx = (int64_t)(rr - q * d.rdiv[k].d);
+                rr = q;
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f)
+                    if (f < d.nf) off[f] += idx * d.f[f].rs[k];
+                if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.w.rs[k];
+            }
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < d.nf) x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
+            if (MODE == ALAN_MODE_WEXPSUM) w = load_as<T>(d.w.p, d.w.dtype, woff);
+        }
+        if (MODE == ALAN_MODE_LSE)
+            lse_push(m, s, x);
+        else if (MODE == ALAN_MODE_SUM)
+            s += x;
+        else
+            s += w * Num<T>::exp(x);
+    }
+
+    // ---- combine the G lanes of the group
+    const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
+    if (MODE == ALAN_MODE_LSE) {
+        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) {
+            const T m2 = __shfl_xor(m, (int)ofs);
+            const T s2 = __shfl_xor(s, (int)ofs);
+            lse_merge(m, s, m2, s2);
+        }
+    } else {
+        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
+    }
+    if (BLOCK) {
+        __shared__ T sm[4], ss[4];
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            sm[wv] = m;
+            ss[wv] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = sm[0];
+            s = ss[0];
+            for (int i = 1; i < 4; ++i) {
+                if (MODE == ALAN_MODE_LSE)
+                    lse_merge(m, s, sm[i], ss[i]);
+                else
+                    s += ss[i];
+            }
+        }
+    }
+    if (active && gl == 0) {
+        T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
+        v += (T)d.add_const;
+        store_as<T>(d.out, d.out_dtype, obase, v);
+    }
+}
+
+template <typename T, int MODE>
+static int launch_group_T(const GroupDesc &gd, const GroupLaunch &gl, hipStream_t stream) {
+    if (gl.block) {
+        hipLaunchKernelGGL((reduce_group_kernel<T, MODE, true>), dim3(gl.grid), dim3(256), 0, stream, gd, 8);
+    } else {
+        hipLaunchKernelGGL((reduce_group_kernel<T, MODE, false>), dim3(gl.grid), dim3(256), 0, stream, gd, gl.logG);
+    }
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+}
+
+int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream) {
+    if (gd.n_out == 0) return ALAN_OK;
+#define ALAN_DISPATCH(T)                                                              \
+    switch (mode) {                                                                   \
+        case ALAN_MODE_LSE: return launch_group_T<T, ALAN_MODE_LSE>(gd, gl, stream);  \
+        case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream);  \
+        case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream); \
+    }
+    if (compute_dtype == ALAN_F32) {
+        ALAN_DISPATCH(float)
+    } else {
+        ALAN_DISPATCH(double)
+    }
+#undef ALAN_DISPATCH
+    return ALAN_ERR_BAD_DESC;
+}
+
+}  // namespace alan

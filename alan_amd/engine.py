@@ -1,0 +1,247 @@
+"""
+Positional-tensor front end of the HIP contraction engine.
+
+A *factor* here is ``(tensor, dims)``: a plain (positional) device tensor plus one hashable key
+per positional dim (functorch ``Dim`` objects in production, strings in tests).  This layer
+  * builds ``alan_reduce`` descriptors (include/alan_mi355.h) from factors,
+  * wraps each launch in a ``torch.autograd.Function`` whose backward is again ``alan_reduce``
+    (mode WEXPSUM: grad_f = sum_{dims not in f} grad_out * exp(sum_f lp_f - lse)), which is what
+    autograd derives from the reference's op sequence (utils.py:218-220) up to the eps term,
+  * plans the order in which K dims are eliminated (replaces opt_einsum.contract_path,
+    reduce_Ks.py:264-265, which only ever chose an order).
+"""
+import math
+
+import torch as t
+
+from . import native as N
+
+
+# --------------------------------------------------------------------------- descriptor building
+def _space(factors, extra=()):
+    """Ordered union of dim keys with sizes."""
+    sizes = {}
+    for x, dims in list(factors) + list(extra):
+        if x.ndim != len(dims):
+            raise AssertionError(f"factor has {x.ndim} positional dims but {len(dims)} dim keys")
+        for d, s in zip(dims, x.shape):
+            if sizes.setdefault(d, s) != s:
+                raise Exception(f"size mismatch for dim {d}: {sizes[d]} vs {s}")
+    return sizes
+
+
+def _strides(x, dims, space):
+    """Element stride of ``x`` along each dim of the space (0 where x lacks the dim or it has size 1)."""
+    st = {d: (s if n > 1 else 0) for d, s, n in zip(dims, x.stride(), x.shape)}
+    return [st.get(d, 0) for d in space]
+
+
+def _out_order(factors, keep, sizes):
+    """Keep dims ordered like the largest factor stores them (so the kernel's stores coalesce)."""
+    dom = max(factors, key=lambda f: f[0].numel())
+    st = dict(zip(dom[1], dom[0].stride()))
+    big = 1 << 62
+    return sorted(keep, key=lambda d: -(st.get(d, big) or big))
+
+
+def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=None, add_const=0.0,
+            scales=None):
+    space = list(sizes)
+    if len(space) > N.MAX_DIMS:
+        raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
+    if len(factors) > N.MAX_FACTORS:
+        raise N.NativeError(f"alan_amd: {len(factors)} factors in one contraction step (max {N.MAX_FACTORS})")
+    desc = N.ReduceDesc()
+    desc.mode = mode
+    desc.ndim = len(space)
+    for i, d in enumerate(space):
+        desc.size[i] = sizes[d]
+        desc.role[i] = roles[d]
+    desc.n_factors = len(factors)
+    device = out.device
+    for i, (x, dims) in enumerate(factors):
+        N.require_device(x, "log-prob factor")
+        if x.device != device:
+            raise N.NativeError("alan_amd: factors live on different devices")
+        N.fill_tensor(desc.factor[i], x, _strides(x, list(dims), space), 1.0 if scales is None else scales[i])
+    if weight is not None:
+        N.fill_tensor(desc.weight, weight[0], _strides(weight[0], list(weight[1]), space))
+    N.fill_tensor(desc.out, out, _strides(out, list(out_dims), space))
+    if lse_out is not None:
+        N.fill_tensor(desc.lse_out, lse_out[0], _strides(lse_out[0], list(lse_out[1]), space))
+    desc.add_const = add_const
+    N.run_reduce(desc, device)
+
+
+def _result_dtype(tensors):
+    dt = tensors[0].dtype
+    for x in tensors[1:]:
+        dt = t.promote_types(dt, x.dtype)
+    if dt not in (t.float32, t.float64):
+        raise N.NativeError(f"alan_amd: unsupported factor dtype {dt}")
+    return dt
+
+
+# --------------------------------------------------------------------------- autograd function
+class _Reduce(t.autograd.Function):
+    """out[keep] = sum_plate  LSE_reduce( sum_f factor_f )  (+ add_const);  mode SUM when no reduce dims."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        dimlists, reduce, plate, add_const = spec
+        factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
+        sizes = _space(factors)
+        for d in (*reduce, *plate):
+            if d not in sizes:
+                raise Exception(f"dim {d} to reduce is not on any factor")
+        keep = [d for d in sizes if d not in reduce and d not in plate]
+        dtype = _result_dtype(list(tensors))
+        device = tensors[0].device
+        out_dims = _out_order(factors, keep, sizes)
+        out = t.empty([sizes[d] for d in out_dims], dtype=dtype, device=device)
+        lse = None
+        if reduce:
+            roles = {d: (N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP) for d in sizes}
+            if plate and any(x.requires_grad for x in tensors):
+                lse_dims = _out_order(factors, keep + list(plate), sizes)
+                lse = (t.empty([sizes[d] for d in lse_dims], dtype=dtype, device=device), lse_dims)
+            _launch(N.MODE_LSE, factors, sizes, roles, out, out_dims, lse_out=lse, add_const=add_const)
+            if lse is None:
+                lse = (out, out_dims)   # add_const is 0 whenever a backward is needed through here
+        else:
+            roles = {d: (N.REDUCE if d in plate else N.KEEP) for d in sizes}
+            _launch(N.MODE_SUM, factors, sizes, roles, out, out_dims, add_const=add_const)
+        ctx.spec = (dimlists, tuple(reduce), tuple(plate), add_const, tuple(out_dims), sizes)
+        ctx.lse_dims = None if lse is None else tuple(lse[1])
+        ctx.has_lse = bool(reduce)
+        saved = list(tensors) + ([lse[0]] if reduce else [])
+        ctx.save_for_backward(*saved)
+        ctx.out_dims = tuple(out_dims)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dimlists, reduce, plate, add_const, out_dims, sizes = ctx.spec
+        saved = ctx.saved_tensors
+        nf = len(dimlists)
+        tensors = saved[:nf]
+        factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
+        grad_out = grad_out.detach()
+        grads = []
+        for i, (x, dims) in enumerate(factors):
+            if not ctx.needs_input_grad[i + 1]:
+                grads.append(None)
+                continue
+            g = t.empty(x.shape, dtype=x.dtype, device=x.device)
+            roles = {d: (N.KEEP if d in dims else N.REDUCE) for d in sizes}
+            if ctx.has_lse:
+                lse = saved[nf]
+                _launch(N.MODE_WEXPSUM, factors + [(lse, ctx.lse_dims)], sizes, roles, g, dims,
+                        weight=(grad_out, out_dims), scales=[1.0] * nf + [-1.0])
+            else:
+                _launch(N.MODE_SUM, [(grad_out, out_dims)], sizes, roles, g, dims)
+            grads.append(g)
+        return (None, *grads)
+
+
+def reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
+    """Fused ``sum(factors)`` -> log-sum-exp over ``reduce`` -> sum over ``plate``.
+    Returns (tensor, dims)."""
+    factors = [(x, tuple(d)) for x, d in factors]
+    reduce, plate = tuple(reduce), tuple(plate)
+    if add_const != 0.0 and any(x.requires_grad for x, _ in factors) and reduce and not plate:
+        # keep the saved log-sum-exp free of the constant: apply it outside
+        out, dims = reduce_factors(factors, reduce, plate, 0.0)
+        return out + add_const, dims
+    spec = (tuple(d for _, d in factors), reduce, plate, float(add_const))
+    out = _Reduce.apply(spec, *[x for x, _ in factors])
+    sizes = _space(factors)
+    keep = [d for d in sizes if d not in reduce and d not in plate]
+    return out, tuple(_out_order([(x.detach(), d) for x, d in factors], keep, sizes))
+
+
+# --------------------------------------------------------------------------- elimination planner
+def plan_elimination(dimsets, sizes, Ks):
+    """Order of K eliminations.  Returns a list of steps ``(factor_ids, Ks_now)`` over a growing list of
+    factors (each step appends its result).  Greedy smallest-intermediate-first variable elimination;
+    a step absorbs every other K whose factors fit inside the step's index space, so e.g. the
+    movielens top level (a[Ka], b[Kb], T[Ka,Kb]) is ONE launch rather than the reference's two
+    pairwise steps (reduce_Ks.py:270-281)."""
+    Ks = [k for k in Ks]
+    live = {i: set(ds) for i, ds in enumerate(dimsets)}
+    steps = []
+    nxt = len(dimsets)
+    remaining = [k for k in Ks if any(k in ds for ds in live.values())]
+    while remaining:
+        best = None
+        for k in remaining:
+            grp = [i for i, ds in live.items() if k in ds]
+            union = set().union(*[live[i] for i in grp])
+            cost = math.prod(sizes[d] for d in union)
+            if best is None or cost < best[0]:
+                best = (cost, k, grp, union)
+        _, k, grp, union = best
+        grp = list(grp)
+        # absorb factors of other Ks that live entirely inside this step's index space
+        changed = True
+        while changed:
+            changed = False
+            for k2 in remaining:
+                g2 = [i for i, ds in live.items() if k2 in ds]
+                if all(live[i] <= union for i in g2) and not set(g2) <= set(grp) \
+                        and len(set(grp) | set(g2)) <= N.MAX_FACTORS - 1:
+                    grp = sorted(set(grp) | set(g2))
+                    changed = True
+        if len(grp) > N.MAX_FACTORS - 1:
+            # too many factors for one launch: pre-add the smallest ones (plain broadcast sum)
+            grp_sorted = sorted(grp, key=lambda i: math.prod(sizes[d] for d in live[i]))
+            pre = grp_sorted[: len(grp) - (N.MAX_FACTORS - 2)]
+            steps.append((tuple(pre), ()))
+            live[nxt] = set().union(*[live[i] for i in pre])
+            for i in pre:
+                del live[i]
+            nxt += 1
+            continue
+        others = set().union(*[ds for i, ds in live.items() if i not in grp]) if len(live) > len(grp) else set()
+        now = tuple(kk for kk in remaining if kk in union and kk not in others)
+        steps.append((tuple(grp), now))
+        live[nxt] = {d for d in union if d not in now}
+        for i in grp:
+            del live[i]
+        nxt += 1
+        remaining = [kk for kk in remaining if kk not in now]
+    if len(live) > 1:
+        ids = sorted(live)
+        while len(ids) > N.MAX_FACTORS:
+            steps.append((tuple(ids[: N.MAX_FACTORS]), ()))
+            ids = [nxt] + ids[N.MAX_FACTORS:]
+            nxt += 1
+        steps.append((tuple(ids), ()))
+    return steps
+
+
+def contract(factors, Ks, plate=()):
+    """reduce_Ks on positional factors, with the trailing plate sum fused into the last launch.
+    Returns (result, dims, per-step record) -- the record is what sample_Ks-style consumers need."""
+    factors = [(x, tuple(d)) for x, d in factors]
+    sizes = _space(factors)
+    Ks = tuple(Ks)
+    plate = tuple(p for p in plate)
+    for k in Ks:
+        if k not in sizes:
+            raise Exception(f"K dim {k} is not on any factor")
+    steps = plan_elimination([d for _, d in factors], sizes, Ks)
+    if not steps:
+        steps = [(tuple(range(len(factors))), ())] if (plate or len(factors) > 1) else []
+    pool = list(factors)
+    record = []
+    for si, (ids, now) in enumerate(steps):
+        last = si == len(steps) - 1
+        group = [pool[i] for i in ids]
+        record.append((group, now))
+        out, dims = reduce_factors(group, reduce=now, plate=plate if last else ())
+        pool.append((out, dims))
+    if not steps:
+        return factors[0][0], factors[0][1], record
+    out, dims = pool[-1]
+    return out, dims, record

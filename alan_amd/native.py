@@ -1,0 +1,145 @@
+"""
+ctypes binding of libalan_mi355.so (C ABI in include/alan_mi355.h).
+
+There is deliberately no fallback: if the shared library is missing, or a tensor is not on a
+HIP device, the call raises.  PyTorch is used only for device memory and the current stream.
+"""
+import ctypes as C
+import os
+
+import torch as t
+
+MAX_DIMS = 8
+MAX_FACTORS = 6
+
+F32, F64 = 0, 1
+KEEP, REDUCE, PLATE = 0, 1, 2
+MODE_LSE, MODE_SUM, MODE_WEXPSUM = 0, 1, 2
+
+_STATUS = {
+    -1: "bad descriptor",
+    -2: "unsupported dtype/size",
+    -3: "workspace too small",
+    -4: "kernel launch failed",
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libalan_mi355.so")
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Tensor(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("scale", C.c_float),
+        ("stride", C.c_int64 * MAX_DIMS),
+    ]
+
+
+class ReduceDesc(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("ndim", C.c_int32),
+        ("size", C.c_int64 * MAX_DIMS),
+        ("role", C.c_int32 * MAX_DIMS),
+        ("n_factors", C.c_int32),
+        ("factor", Tensor * MAX_FACTORS),
+        ("weight", Tensor),
+        ("out", Tensor),
+        ("lse_out", Tensor),
+        ("add_const", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `make -C alan_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "alan_amd has no CPU or PyTorch fallback for the reduce_Ks hot path.")
+        L = C.CDLL(LIB_PATH)
+        L.alan_reduce.restype = C.c_int
+        L.alan_reduce.argtypes = [C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_reduce_workspace_bytes.restype = C.c_size_t
+        L.alan_reduce_workspace_bytes.argtypes = [C.POINTER(ReduceDesc)]
+        L.alan_chain_workspace_bytes.restype = C.c_size_t
+        L.alan_chain_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+        L.alan_chain_logmmexp.restype = C.c_int
+        L.alan_chain_logmmexp.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_abi_version.restype = C.c_int
+        L.alan_build_target.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_chain_workspace_bytes",
+           "alan_chain_logmmexp", "alan_abi_version", "alan_build_target")
+
+
+def dtype_code(dtype):
+    if dtype == t.float32:
+        return F32
+    if dtype == t.float64:
+        return F64
+    raise NativeError(f"alan_amd: unsupported dtype {dtype} (float32/float64 only)")
+
+
+def require_device(x, what="tensor"):
+    if not x.is_cuda:
+        raise NativeError(
+            f"alan_amd: {what} is on {x.device}; the reduce_Ks hot path runs only as HIP kernels on an "
+            "MI355X (no CPU fallback). Move the Problem to the GPU with problem.to('cuda').")
+
+
+def check(status, what):
+    if status != 0:
+        raise NativeError(f"{what} failed: {_STATUS.get(status, status)}")
+
+
+def fill_tensor(dst, x, strides, scale=1.0):
+    dst.data = x.data_ptr()
+    dst.dtype = dtype_code(x.dtype)
+    dst.scale = scale
+    for i, s in enumerate(strides):
+        dst.stride[i] = s
+
+
+def current_stream(device):
+    return t.cuda.current_stream(device).cuda_stream
+
+
+def run_reduce(desc, device):
+    L = lib()
+    nbytes = L.alan_reduce_workspace_bytes(C.byref(desc))
+    ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
+    rc = L.alan_reduce(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,
+                       current_stream(device))
+    check(rc, "alan_reduce")
+
+
+def chain_logmmexp(ms, want_chain=False):
+    """ms: [T,K,K] device tensor -> (vec[K], chain[K,K] or None)."""
+    require_device(ms, "timeseries factor")
+    L = lib()
+    T, K, K2 = ms.shape
+    assert K == K2
+    code = dtype_code(ms.dtype)
+    vec = t.empty(K, dtype=ms.dtype, device=ms.device)
+    chain = t.empty(K, K, dtype=ms.dtype, device=ms.device) if want_chain else None
+    nbytes = L.alan_chain_workspace_bytes(T, K, code)
+    ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
+    rc = L.alan_chain_logmmexp(ms.data_ptr(), code, T, K, ms.stride(0), ms.stride(1), ms.stride(2),
+                               chain.data_ptr() if want_chain else None, vec.data_ptr(),
+                               ws.data_ptr(), nbytes, current_stream(ms.device))
+    check(rc, "alan_chain_logmmexp")
+    return vec, chain

@@ -1,0 +1,108 @@
+/*
+ * alan_mi355.h -- C ABI of libalan_mi355.so: the MI355X (gfx950) implementation of alan's
+ * tensorised marginal-likelihood hot path.
+ *
+ * The reference (alan-ppl/alan) is pure Python and has no FFI of its own; these entry points
+ * are what a binding for the path would call, one per reference function on the path:
+ *
+ *   alan_reduce(mode = ALAN_MODE_LSE)      reduce_Ks.py:249-251  logsumexp_sum(Ks, *lps)
+ *                                          utils.py:207-222       logsumexp_dims  (eps-in-log epilogue)
+ *                                          utils.py:224-225       logmeanexp_dims (add_const = -sum log K)
+ *                                          Sampler.py:118-134     SamplerMP.reduce_logQ
+ *     ... with dims of role ALAN_PLATE     logpq.py:149           lp.sum(new_platedim) fused behind the LSE
+ *   alan_reduce(mode = ALAN_MODE_SUM)      logpq.py:149-153       plate sum / Split accumulate (prev_lpq + lp)
+ *   alan_reduce(mode = ALAN_MODE_WEXPSUM)  backward of the above (what autograd derives from utils.py:218-220):
+ *                                          grad_f = sum_{dims not in f} grad_out * exp(sum_f lp_f - lse)
+ *   alan_chain_logmmexp                    utils.py:478-510 chain_logmmexp  (+ logpq.py:139 logsumexp(-1))
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller.
+ *     The library never allocates, frees or synchronises; all work is enqueued on `stream`.
+ *   - Tensors are described over one shared list of dims ("the space"): size[d], role[d] and, per
+ *     tensor, an element stride per dim (0 = the tensor does not carry that dim => broadcast).
+ *   - Return value: 0 on success, negative alan_status_t otherwise.  Nothing throws across the ABI.
+ *   - Re-entrant and thread-safe: no global mutable state; the device is whatever is current.
+ */
+#ifndef ALAN_MI355_H
+#define ALAN_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALAN_MAX_DIMS 8
+#define ALAN_MAX_FACTORS 6
+
+typedef enum {
+    ALAN_OK = 0,
+    ALAN_ERR_BAD_DESC = -1,       /* malformed descriptor (ndim, sizes, roles, null pointers) */
+    ALAN_ERR_UNSUPPORTED = -2,    /* dtype / size outside what the kernels implement */
+    ALAN_ERR_WORKSPACE = -3,      /* caller-provided workspace too small */
+    ALAN_ERR_LAUNCH = -4          /* hipLaunchKernel reported an error */
+} alan_status_t;
+
+typedef enum { ALAN_F32 = 0, ALAN_F64 = 1 } alan_dtype_t;
+
+/* role of a dim of the space */
+typedef enum {
+    ALAN_KEEP = 0,    /* survives into the output */
+    ALAN_REDUCE = 1,  /* reduced by the mode's operator (log-sum-exp / sum / weighted exp-sum) */
+    ALAN_PLATE = 2    /* ALAN_MODE_LSE only: summed AFTER the log-sum-exp (logpq.py:149) */
+} alan_role_t;
+
+typedef enum {
+    ALAN_MODE_LSE = 0,     /* out = log(sum_R exp(x - max_R x) + eps(dtype)) + max_R x,  x = sum_f scale_f * factor_f */
+    ALAN_MODE_SUM = 1,     /* out = sum_R x */
+    ALAN_MODE_WEXPSUM = 2  /* out = sum_R weight * exp(x) */
+} alan_mode_t;
+
+typedef struct {
+    const void *data;                 /* device pointer to element 0 */
+    int32_t dtype;                    /* alan_dtype_t */
+    float scale;                      /* factor enters the sum as scale * value (1 or -1) */
+    int64_t stride[ALAN_MAX_DIMS];    /* element stride per dim of the space; 0 = broadcast */
+} alan_tensor_t;
+
+typedef struct {
+    int32_t mode;                         /* alan_mode_t */
+    int32_t ndim;                         /* <= ALAN_MAX_DIMS */
+    int64_t size[ALAN_MAX_DIMS];
+    int32_t role[ALAN_MAX_DIMS];          /* alan_role_t */
+    int32_t n_factors;                    /* 1 .. ALAN_MAX_FACTORS */
+    alan_tensor_t factor[ALAN_MAX_FACTORS];
+    alan_tensor_t weight;                 /* ALAN_MODE_WEXPSUM: multiplicative weight; data NULL otherwise */
+    alan_tensor_t out;                    /* written; strides over KEEP dims; dtype = compute dtype */
+    alan_tensor_t lse_out;                /* optional (data may be NULL). With PLATE dims: receives the per-(KEEP,PLATE)
+                                             log-sum-exp values (the backward's saved tensor); strides over KEEP+PLATE */
+    double add_const;                     /* added to every output element */
+} alan_reduce_desc_t;
+
+/* Bytes of scratch alan_reduce() needs for this descriptor (0 is possible). */
+size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *desc);
+
+/* Enqueue the reduction.  `workspace` must be at least alan_reduce_workspace_bytes(desc) bytes,
+ * 256-byte aligned, and stay alive until the stream has passed this call. */
+int alan_reduce(const alan_reduce_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Timeseries plate (utils.py:478-510, logpq.py:132-143).
+ *   ms         [T, K, K] log transition factors, element strides (sT, sRow, sCol)
+ *   out_chain  optional [K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)
+ *   out_vec    optional [K]   contiguous: logsumexp(chain, -1)                    (what the ELBO uses)
+ * Associative re-bracketing of the reference's pairwise tree: results agree to rounding. */
+size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
+int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K,
+                        int64_t sT, int64_t sRow, int64_t sCol,
+                        void *out_chain, void *out_vec,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
+int alan_abi_version(void);
+const char *alan_build_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALAN_MI355_H */

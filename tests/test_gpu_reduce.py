@@ -1,0 +1,216 @@
+"""GPU parity tests of the HIP contraction engine (through the C ABI) against the CPU oracle and
+the reference-generated golden fixtures.  Tolerances: fp32 results within 2e-5 relative / 2e-5
+absolute of the reference's own fp32 output (north_star: ELBO within 1e-4 relative); fp64 1e-10."""
+import itertools
+import math
+
+import pytest
+import torch as t
+
+from conftest import load_golden
+from oracle import alan_oracle as orc
+from alan_amd import engine as E
+from alan_amd import native as N
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def tol(dtype):
+    return dict(rtol=2e-5, atol=2e-5) if dtype == t.float32 else dict(rtol=1e-10, atol=1e-10)
+
+
+def same(a, a_dims, b, b_dims, **kw):
+    assert set(a_dims) == set(b_dims), (a_dims, b_dims)
+    a = a.detach().cpu()
+    a = orc.align((a, tuple(a_dims)), tuple(b_dims)) if a_dims else a
+    kw = kw or tol(b.dtype)
+    t.testing.assert_close(a.reshape(b.shape), b, equal_nan=True, **kw)
+
+
+def dev(factors, requires_grad=False):
+    return [(x.to(DEV).requires_grad_(requires_grad), d) for x, d in factors]
+
+
+# ------------------------------------------------------------------ golden: logsumexp_dims
+@pytest.mark.parametrize("case", load_golden("lse_dims.pt"), ids=lambda c: c["name"])
+def test_logsumexp_dims_golden(case):
+    if not case["reduce"]:
+        pytest.skip("identity")
+    out, dims = E.reduce_factors(dev([(case["x"], case["names"])]), reduce=case["reduce"])
+    assert out.dtype == case["out"].dtype
+    same(out, dims, case["out"], case["out_names"])
+    if "mean_out" in case:
+        sz = dict(zip(case["names"], case["x"].shape))
+        c = -sum(math.log(sz[d]) for d in case["reduce"])
+        out, dims = E.reduce_factors(dev([(case["x"], case["names"])]), reduce=case["reduce"], add_const=c)
+        same(out, dims, case["mean_out"], case["mean_out_names"])
+
+
+# ------------------------------------------------------------------ golden: reduce_Ks seam
+@pytest.mark.parametrize("case", load_golden("seam_synthetic.pt"), ids=lambda c: c["name"])
+def test_reduce_Ks_synthetic_golden(case):
+    want_grad = "grads_weighted" in case
+    factors = dev(case["factors"], want_grad)
+    out, dims, _ = E.contract(factors, case["Ks"])
+    assert out.dtype == case["out"].dtype
+    same(out, dims, case["out"], case["out_names"])
+    if not case["name"].startswith("all_neg_inf"):
+        same(out.double(), dims, case["brute_f64"], case["brute_names"], rtol=2e-5, atol=2e-5)
+    if want_grad:
+        go = orc.align((case["grad_out"], case["out_names"]), dims) if dims else case["grad_out"]
+        grads = t.autograd.grad(out, [x for x, _ in factors], go.reshape(out.shape).to(DEV))
+        for g, ref in zip(grads, case["grads_weighted"]):
+            t.testing.assert_close(g.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", load_golden("seam_recorded.pt"),
+                         ids=lambda c: f"{c['model']}-K{c['K']}-{c['call']}")
+def test_reduce_Ks_recorded_golden(case):
+    out, dims, _ = E.contract(dev(case["factors"]), case["Ks"])
+    assert out.dtype == case["out"].dtype
+    same(out, dims, case["out"], case["out_names"], rtol=2e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------ oracle: fused plate sum + backward
+@pytest.mark.parametrize("K,M", [(3, 7), (10, 33), (30, 40)])
+@pytest.mark.parametrize("layout", ["ref", "kz_first", "kz_mid"])
+def test_movielens_plate_fused(K, M, layout):
+    g = t.Generator().manual_seed(K * 100 + M)
+    F = -0.5 * t.randn(M, K, K, K, generator=g) ** 2 - 0.92 - math.log(K)
+    gz = -0.5 * t.randn(M, K, generator=g) ** 2 - 0.92 - math.log(K)
+    Fd = ("plate_1", "K_mu", "K_psi", "K_z")
+    if layout == "kz_first":
+        F, Fd = F.permute(3, 0, 1, 2).contiguous(), ("K_z", "plate_1", "K_mu", "K_psi")
+    elif layout == "kz_mid":
+        F, Fd = F.permute(0, 3, 1, 2).contiguous(), ("plate_1", "K_z", "K_mu", "K_psi")
+    cpu = [(F, Fd), (gz, ("plate_1", "K_z"))]
+    (ref, ref_dims), ref_grads = orc.reduce_Ks_grads(cpu, ("K_z",), plate="plate_1")
+    factors = dev(cpu, True)
+    out, dims, _ = E.contract(factors, ("K_z",), plate=("plate_1",))
+    same(out, dims, ref, ref_dims, rtol=2e-5, atol=2e-4)
+    grads = t.autograd.grad(out.sum(), [x for x, _ in factors])
+    for gd, rg in zip(grads, ref_grads):
+        t.testing.assert_close(gd.cpu(), rg, rtol=1e-4, atol=1e-6)
+
+
+def test_split_chunks_sum_to_full_plate():
+    """logpq.py:43-57,151-153: summing per-chunk results == the unsplit plate (Split.py:84-95 sizes)."""
+    K, M = 10, 50
+    g = t.Generator().manual_seed(3)
+    F = (-0.5 * t.randn(M, K, K, K, generator=g) ** 2).to(DEV)
+    gz = (-0.5 * t.randn(M, K, generator=g) ** 2).to(DEV)
+    full, fd, _ = E.contract([(F, ("p", "a", "b", "z")), (gz, ("p", "z"))], ("z",), plate=("p",))
+    acc, start = None, 0
+    for n in orc.split_sizes(M, 7):
+        part, pd, _ = E.contract([(F[start:start + n], ("p", "a", "b", "z")), (gz[start:start + n], ("p", "z"))],
+                                 ("z",), plate=("p",))
+        assert pd == fd
+        acc = part if acc is None else acc + part
+        start += n
+    t.testing.assert_close(acc, full, rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------ oracle: layout / geometry fuzz
+def _rand_case(seed):
+    g = t.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(t.randint(lo, hi + 1, (1,), generator=g))
+    ndim = ri(1, 5)
+    names = [f"d{i}" for i in range(ndim)]
+    sizes = {n: ri(1, 9) if ri(0, 3) else ri(20, 70) for n in names}
+    nf = ri(1, 4)
+    factors = []
+    for f in range(nf):
+        own = [n for n in names if ri(0, 2) > 0] or [names[0]]
+        if f == 0:
+            own = list(names)
+        perm = [own[i] for i in t.randperm(len(own), generator=g).tolist()]
+        dtype = t.float64 if ri(0, 5) == 0 else t.float32
+        x = (t.randn([sizes[n] for n in perm], generator=g, dtype=dtype) * 3.0)
+        if ri(0, 3) == 0 and x.ndim >= 2:           # non-contiguous view
+            x = x.transpose(0, 1).contiguous().transpose(0, 1)
+        factors.append((x, tuple(perm)))
+    nred = ri(0, ndim)
+    red = tuple(names[i] for i in t.randperm(ndim, generator=g).tolist()[:nred])
+    rest = [n for n in names if n not in red]
+    plate = tuple(rest[:1]) if (rest and ri(0, 2) == 0) else ()
+    return factors, red, plate
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_against_oracle(seed):
+    factors, red, plate = _rand_case(seed)
+    ref = orc.logsumexp_sum(red, *factors)
+    for p in plate:
+        ref = orc.plate_sum(ref, p)
+    out, dims = E.reduce_factors(dev(factors), reduce=red, plate=plate)
+    assert out.dtype == ref[0].dtype
+    same(out, dims, ref[0], ref[1], rtol=3e-5, atol=3e-4)
+
+
+@pytest.mark.parametrize("n_out,n_red", [(1, 5), (1, 900), (1, 10000), (3, 70000), (5000, 2), (70000, 1),
+                                         (257, 64), (64, 257), (100000, 30), (2, 300000)])
+def test_geometry_extremes(n_out, n_red):
+    g = t.Generator().manual_seed(n_out + n_red)
+    x = t.randn(n_out, n_red, generator=g) * 5
+    ref, _ = orc.logsumexp_dims((x, ("o", "r")), ("r",))
+    out, dims = E.reduce_factors(dev([(x, ("o", "r"))]), reduce=("r",))
+    same(out, dims, ref, ("o",), rtol=2e-5, atol=2e-5)
+    xt = x.t().contiguous()
+    out, dims = E.reduce_factors(dev([(xt, ("r", "o"))]), reduce=("r",))
+    same(out, dims, ref, ("o",), rtol=2e-5, atol=2e-5)
+
+
+def test_neg_inf_semantics():
+    x = t.randn(6, 40)
+    x[0, 3] = float("-inf")          # single -inf: fine
+    x[1, 0] = float("-inf")          # leading -inf: fine
+    x[2, :] = float("-inf")          # whole slice: NaN, as utils.py:218-220 gives (x - max = NaN)
+    ref, _ = orc.logsumexp_dims((x, ("o", "r")), ("r",))
+    assert t.isnan(ref[2]) and t.isfinite(ref[[0, 1, 3, 4, 5]]).all()
+    for xx, dd in [(x, ("o", "r")), (x.t().contiguous(), ("r", "o"))]:
+        out, dims = E.reduce_factors(dev([(xx, dd)]), reduce=("r",))
+        same(out, dims, ref, ("o",))
+
+
+def test_empty_Ks_is_identity_or_plain_sum():
+    x = t.randn(10, 3)
+    y = t.randn(3)
+    out, dims, _ = E.contract(dev([(x, ("T", "K"))]), ())
+    same(out, dims, x, ("T", "K"), rtol=0, atol=0)
+    out, dims, _ = E.contract(dev([(x, ("T", "K")), (y, ("K",))]), ())
+    same(out, dims, x + y, ("T", "K"), rtol=1e-6, atol=1e-6)
+    out, dims, _ = E.contract(dev([(x, ("T", "K"))]), (), plate=("T",))
+    same(out, dims, x.sum(0), ("K",), rtol=1e-6, atol=1e-5)
+
+
+def test_errors_mirror_reference():
+    x = t.randn(4, 3, device=DEV)
+    with pytest.raises(Exception):
+        E.contract([(x, ("a", "k"))], ("nope",))
+    with pytest.raises(AssertionError):
+        E.contract([(x, ("a",))], ())
+
+
+# ------------------------------------------------------------------ chain (timeseries)
+def _chain_input(case):
+    if case["ms"] is not None:
+        return case["ms"]
+    g = t.Generator().manual_seed(case["seed"])
+    dtype = getattr(t, case["dtype"].split(".")[-1])
+    T, K = case["T"], case["K"]
+    return -0.5 * t.randn(T, K, K, generator=g, dtype=dtype) ** 2 - 0.9189 - math.log(K)
+
+
+@pytest.mark.parametrize("case", [c for c in load_golden("chain.pt") if "T" in c],
+                         ids=lambda c: f"T{c['T']}K{c['K']}")
+def test_chain_logmmexp_golden(case):
+    ms = _chain_input(case).to(DEV)
+    vec, chain = N.chain_logmmexp(ms, want_chain=True)
+    kw = dict(rtol=2e-5, atol=5e-5) if ms.dtype == t.float32 else dict(rtol=1e-10, atol=1e-10)
+    t.testing.assert_close(chain.cpu(), case["chain"], **kw)
+    t.testing.assert_close(vec.cpu(), case["out"], **kw)
+    # strided input (time axis last in memory)
+    ms2 = ms.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    vec2, _ = N.chain_logmmexp(ms2)
+    t.testing.assert_close(vec2, vec, rtol=0, atol=0)

@@ -1,0 +1,102 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the header declares,
+refuses malformed descriptors, and the Python front end refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch as t
+
+from alan_amd import native as N
+from alan_amd import engine as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "alan_mi355.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(alan_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = N.lib()
+    syms = _declared_symbols()
+    assert set(syms) == set(N.EXPORTS)
+    for s in syms:
+        assert getattr(L, s) is not None
+    assert L.alan_abi_version() == 1
+    assert L.alan_build_target() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    # alan_tensor_t: ptr(8) + int32 + float + 8*int64 ; alan_reduce_desc_t per the header
+    assert ctypes.sizeof(N.Tensor) == 8 + 4 + 4 + 8 * N.MAX_DIMS
+    expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8
+    assert ctypes.sizeof(N.ReduceDesc) == expect
+
+
+def test_bad_descriptors_are_rejected_without_touching_the_gpu():
+    L = N.lib()
+    d = N.ReduceDesc()
+    d.ndim = 99
+    assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
+    d = N.ReduceDesc()
+    d.ndim = 1
+    d.size[0] = 4
+    d.role[0] = 7
+    assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
+    d.role[0] = N.PLATE
+    d.mode = N.MODE_SUM          # PLATE only valid with LSE
+    assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
+    d.mode = N.MODE_LSE
+    d.role[0] = N.REDUCE
+    d.n_factors = 1              # null factor pointer
+    assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
+    assert L.alan_chain_logmmexp(None, 0, 4, 3, 9, 3, 1, None, None, None, 0, None) == -1
+
+
+def test_workspace_query():
+    L = N.lib()
+    d = N.ReduceDesc()
+    d.mode = N.MODE_LSE
+    d.ndim = 3
+    for i, (s, r) in enumerate([(10, N.PLATE), (3, N.KEEP), (5, N.REDUCE)]):
+        d.size[i], d.role[i] = s, r
+    d.out.dtype = N.F32
+    assert L.alan_reduce_workspace_bytes(ctypes.byref(d)) == 256      # 30 floats, 256-aligned
+    d.role[0] = N.KEEP
+    assert L.alan_reduce_workspace_bytes(ctypes.byref(d)) == 0
+    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) > 100 * 30 * 30 * 4
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    x = t.zeros(3, 4)
+    with pytest.raises(N.NativeError, match="no CPU fallback"):
+        E.reduce_factors([(x, ("a", "k"))], reduce=("k",))
+    with pytest.raises(N.NativeError):
+        N.chain_logmmexp(t.zeros(4, 3, 3))
+
+
+def test_planner_single_launch_for_movielens_shapes():
+    sizes = {"M": 300, "Ka": 30, "Kb": 30, "Kz": 30}
+    steps = E.plan_elimination([("M", "Ka", "Kb", "Kz"), ("M", "Kz")], sizes, ["Kz"])
+    assert steps == [((0, 1), ("Kz",))]
+    steps = E.plan_elimination([("Ka",), ("Kb",), ("Ka", "Kb")], sizes, ["Ka", "Kb"])
+    assert len(steps) == 1 and set(steps[0][1]) == {"Ka", "Kb"} and set(steps[0][0]) == {0, 1, 2}
+
+
+def test_planner_chain_is_pairwise_not_joint():
+    sizes = {"K1": 30, "K2": 30, "K3": 30, "K4": 30}
+    steps = E.plan_elimination([("K1", "K2"), ("K2", "K3"), ("K3", "K4")], sizes, ["K1", "K2", "K3", "K4"])
+    # never materialise more than K^2 elements' worth of index space x K
+    for ids, now in steps:
+        assert len(now) >= 1
+    eliminated = [k for _, now in steps for k in now]
+    assert sorted(eliminated) == ["K1", "K2", "K3", "K4"]
+
+
+def test_planner_empty_Ks():
+    assert E.plan_elimination([("T", "K")], {"T": 10, "K": 3}, []) == []
+    steps = E.plan_elimination([("T", "K"), ("K",)], {"T": 10, "K": 3}, [])
+    assert steps == [((0, 1), ())]
