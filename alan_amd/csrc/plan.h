@@ -39,6 +39,8 @@ struct Canon {
     KTensor f[MAXF];
     KTensor w;       // w.p == nullptr when absent
     KTensor o;       // output: ks only
+    KTensor l;       // optional per-(KEEP,PLATE) log-sum-exp output (l.p == nullptr when absent): ks only
+    bool kplate[MAXD];     // canonical keep dim j is a PLATE dim (summed after the log-sum-exp)
     int dominant = 0;      // index of the largest factor
     int64_t n_out = 1, n_red = 1;
     bool red_contig = false;   // dominant factor's unit-stride dim is the innermost reduce dim
@@ -48,15 +50,25 @@ struct Canon {
 // keep_mask / red_mask: bit d set => dim d of the descriptor is a keep / reduce dim.  Dims in
 // neither mask must have size 1 for every tensor that is read (they are ignored).
 int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask,
-                 const alan_tensor_t &out, Canon &c);
+                 const alan_tensor_t &out, Canon &c, uint32_t plate_mask = 0,
+                 const alan_tensor_t *lse_out = nullptr);
 
 int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl);
 
 int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream);
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
-// fit it (caller then falls back to the group kernel).
-int try_launch_rows(const Canon &c, int mode, int compute_dtype, int out_dtype, double add_const,
-                    hipStream_t stream);
+// fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the
+// plate sum is fused (per-workgroup partial sums over a chunk of the plate + a tiny second stage).
+struct RowsPlan {
+    bool ok = false;
+    int L = 0, RB = 0, threads = 0, logG = 0, gs_off = 0;
+    uint32_t NO = 0, P = 1, n_windows = 0, n_chunks = 1, p_chunk = 1;
+    size_t lds_bytes = 0, partial_bytes = 0;
+    bool rot = false, vec2 = false;
+};
+RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype);
+int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
+                size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace alan

@@ -12,7 +12,7 @@ static bool valid_dtype(int32_t dt) { return dt == ALAN_F32 || dt == ALAN_F64; }
 static size_t dtype_bytes(int32_t dt) { return dt == ALAN_F64 ? 8 : 4; }
 
 int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask,
-                 const alan_tensor_t &out, Canon &c) {
+                 const alan_tensor_t &out, Canon &c, uint32_t plate_mask, const alan_tensor_t *lse_out) {
     if (d.ndim < 0 || d.ndim > MAXD) return ALAN_ERR_BAD_DESC;
     if (d.n_factors < 1 || d.n_factors > MAXF) return ALAN_ERR_BAD_DESC;
     for (int i = 0; i < d.ndim; ++i)
@@ -70,17 +70,24 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
     c.o.p = out.data;
     c.o.dtype = out.dtype;
     c.o.scale = 1.f;
+    const bool has_l = lse_out != nullptr && lse_out->data != nullptr;
+    c.l.p = has_l ? lse_out->data : nullptr;
+    c.l.dtype = has_l ? lse_out->dtype : out.dtype;
+    c.l.scale = 1.f;
 
     // merge adjacent dims that every tensor strides through contiguously
     auto build = [&](const int *idx, int n, bool keep, int64_t *size_out) -> int {
         int m = 0;
-        int64_t fs[MAXF][MAXD], ws[MAXD], os[MAXD];
+        int64_t fs[MAXF][MAXD], ws[MAXD], os[MAXD], ls[MAXD];
+        bool pl[MAXD];
         for (int j = 0; j < n; ++j) {
             const int i = idx[j];
             bool merged = false;
+            const bool is_plate = keep && ((plate_mask >> i) & 1);
             if (m > 0) {
                 const int64_t sz = d.size[i];
-                bool ok = true;
+                bool ok = pl[m - 1] == is_plate;
+                if (ok && keep && has_l) ok = ls[m - 1] == lse_out->stride[i] * sz;
                 for (int f = 0; f < c.nf && ok; ++f) ok = fs[f][m - 1] == d.factor[f].stride[i] * sz;
                 if (ok && has_w) ok = ws[m - 1] == d.weight.stride[i] * sz;
                 if (ok && keep) ok = os[m - 1] == out.stride[i] * sz;
@@ -89,6 +96,7 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
                     for (int f = 0; f < c.nf; ++f) fs[f][m - 1] = d.factor[f].stride[i];
                     ws[m - 1] = d.weight.stride[i];
                     os[m - 1] = out.stride[i];
+                    if (has_l) ls[m - 1] = lse_out->stride[i];
                     merged = true;
                 }
             }
@@ -97,13 +105,19 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
                 for (int f = 0; f < c.nf; ++f) fs[f][m] = d.factor[f].stride[i];
                 ws[m] = has_w ? d.weight.stride[i] : 0;
                 os[m] = keep ? out.stride[i] : 0;
+                ls[m] = (keep && has_l) ? lse_out->stride[i] : 0;
+                pl[m] = is_plate;
                 ++m;
             }
         }
         for (int j = 0; j < m; ++j) {
             for (int f = 0; f < c.nf; ++f) (keep ? c.f[f].ks : c.f[f].rs)[j] = fs[f][j];
             (keep ? c.w.ks : c.w.rs)[j] = ws[j];
-            if (keep) c.o.ks[j] = os[j];
+            if (keep) {
+                c.o.ks[j] = os[j];
+                c.l.ks[j] = ls[j];
+                c.kplate[j] = pl[j];
+            }
         }
         return m;
     };
@@ -195,13 +209,21 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     int rc = canonicalise(d, keep_mask, red_mask, out, c);
     if (rc != ALAN_OK) return rc;
     const int compute = out.dtype;
-    rc = try_launch_rows(c, mode, compute, out.dtype, add_const, stream);
-    if (rc != ALAN_ERR_UNSUPPORTED) return rc;
+    const RowsPlan rp = plan_rows(c, mode, compute);
+    if (rp.ok) return launch_rows(c, rp, mode, add_const, nullptr, 0, stream);
     GroupDesc gd;
     GroupLaunch gl;
     rc = plan_group(c, out.dtype, add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
     return launch_group(gd, gl, mode, compute, stream);
+}
+
+// The fused plan for "log-sum-exp over REDUCE then sum over PLATE", if the rows kernel can take it.
+static bool plan_fused_plate(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint32_t plate,
+                             Canon &c, RowsPlan &rp) {
+    if (canonicalise(d, keep | plate, red, d.out, c, plate, &d.lse_out) != ALAN_OK) return false;
+    rp = plan_rows(c, ALAN_MODE_LSE, d.out.dtype);
+    return rp.ok;
 }
 
 static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, uint32_t &plate) {
@@ -229,7 +251,13 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
-    if (!plate || !red || d->lse_out.data) return 0;
+    if (!plate || !red) return 0;
+    {
+        Canon c;
+        RowsPlan rp;
+        if (plan_fused_plate(*d, keep, red, plate, c, rp)) return (rp.partial_bytes + 255) & ~(size_t)255;
+    }
+    if (d->lse_out.data) return 0;
     int64_t numel = 1;
     for (int i = 0; i < d->ndim; ++i)
         if (d->role[i] != ALAN_REDUCE) numel *= d->size[i];
@@ -251,6 +279,12 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream);
 
     // ---- log-sum-exp over REDUCE, then sum over PLATE (logpq.py:128,149)
+    {
+        Canon c;
+        RowsPlan rp;
+        if (plan_fused_plate(*d, keep, red, plate, c, rp))
+            return launch_rows(c, rp, ALAN_MODE_LSE, d->add_const, workspace, workspace_bytes, stream);
+    }
     alan_tensor_t v;
     if (d->lse_out.data) {
         v = d->lse_out;

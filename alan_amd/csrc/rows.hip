@@ -1,9 +1,400 @@
-// rows kernel: LDS-staged fast path (see reduce.hip header).  Placeholder until implemented:
-// every problem is routed to the group kernel.
+// rows kernel: the LDS-staged fast path of alan_reduce for the dominant shape of the hot path --
+// the reduced K dim is the contiguous (innermost) dim of the largest factor, e.g. movielens
+// F[plate_1, K_mu, K_psi, K_z] (+ g[plate_1, K_z]) reduced over K_z, then summed over plate_1
+// (logpq.py:128,149; reduce_Ks.py:249-251; utils.py:218-220).
+//
+// Data movement (HBM-bound; ~4 B and ~10 VALU ops per element):
+//   * a workgroup owns a window of RB consecutive rows and walks a chunk of the plate; per plate
+//     index it copies the window's contiguous slab (RB*L floats) HBM -> LDS with 16-byte loads,
+//     fully coalesced whatever L is (rows of 30 floats are only 8-byte aligned);
+//   * thread t then owns row t in LDS: pass 1 adds the small factors (L1/L2-resident) and takes the
+//     exact row max, pass 2 sums exp(x - max): the reference's two-pass arithmetic, so -inf / NaN
+//     corner cases fall out identically;  row stride L words with 8-byte reads is conflict-free for
+//     L = 2 (mod 4) (K = 10, 30) and 2-way for K = 100; pathological strides use a rotated start;
+//   * the plate sum is accumulated in a register across the chunk; each workgroup writes one partial
+//     per row, and a tiny second stage adds the chunks (deterministic: no float atomics).
+#include <algorithm>
+#include <cstring>
+
 #include "plan.h"
 
 namespace alan {
 
-int try_launch_rows(const Canon &, int, int, int, double, hipStream_t) { return ALAN_ERR_UNSUPPORTED; }
+struct RowsDesc {
+    const float *F;
+    int64_t total;          // elements of F reachable from F (tail guard for 16-byte loads)
+    int32_t L, RB;
+    uint32_t NO, P, p_chunk;
+    int32_t nshared, ngen, nki, gs_off;
+    KTensor sh[MAXF];       // "shared" secondary factors: constant over the window (no inner keep dims)
+    int64_t sh_ps[MAXF];    //   stride along the plate dim
+    KTensor gen[MAXF];      // general secondary factors: ks over INNER keep dims, rs[0] along the row
+    int64_t gen_ps[MAXF];
+    FastDiv kdiv[MAXD];     // inner keep dims
+    float *out;             // final output (n_chunks == 1) ...
+    int64_t oks[MAXD];
+    float *partial;         // ... or per-chunk partials [n_chunks, NO]
+    float *lse;             // optional per-row log-sum-exp values
+    int64_t lks[MAXD], l_ps;
+    float add_const;
+};
+
+constexpr int ROWS_UNR = 8;  // 16-byte loads in flight per thread (one slab <= 256*8*16 B = 32 KiB)
+
+template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN>
+__global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
+    extern __shared__ __align__(16) float lds[];
+    constexpr int G = 1 << LOGG;
+    const int t = threadIdx.x;
+    const int L = d.L;
+    const uint32_t o0 = blockIdx.x * (uint32_t)d.RB;
+    const uint32_t nrows = min((uint32_t)d.RB, d.NO - o0);
+    const uint32_t p0 = blockIdx.y * d.p_chunk;
+    const uint32_t p1 = min(d.P, p0 + d.p_chunk);
+    const int gl = t & (G - 1);
+    const bool has_row = (uint32_t)(t >> LOGG) < nrows;
+    const int r = has_row ? (t >> LOGG) : (int)nrows - 1;
+    float *gs = lds + d.gs_off;
+
+    // ---- this thread's row: offsets of the general secondary factors / outputs (fixed across the plate)
+    int64_t sb[GEN ? MAXF : 1];
+#pragma unroll
+    for (int f = 0; f < (GEN ? MAXF : 1); ++f) sb[f] = 0;
+    int64_t ob = 0, lb = 0;
+    {
+        uint32_t o = o0 + (uint32_t)r;
+        for (int k = d.nki - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(o, d.kdiv[k]);
+            const int64_t idx = (int64_t)(o - q * d.kdiv[k].d);
+            o = q;
+            if (GEN) {
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f)
+                    if (f < d.ngen) sb[f] += idx * d.gen[f].ks[k];
+            }
+            ob += idx * d.oks[k];
+            lb += idx * d.lks[k];
+        }
+    }
+    const int j0 = ROT ? (r % L) : 0;
+
+    // slab of plate index p: 16-byte loads from a 16-byte aligned-down start into registers
+    float4 v[ROWS_UNR];
+    auto slab_fetch = [&](uint32_t p) {
+        const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
+        const int64_t a0 = e0 & ~(int64_t)3;
+        const int n4 = ((int)(e0 - a0) + (int)nrows * L + 3) >> 2;
+        const float4 *src = reinterpret_cast<const float4 *>(d.F + a0);
+        if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the last one)
+#pragma unroll
+            for (int u = 0; u < ROWS_UNR; ++u) {
+                const int i = u * 256 + t;
+                if (i < n4) v[u] = src[i];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < ROWS_UNR; ++u) {
+                const int i = u * 256 + t;
+                if (i < n4) {
+                    const float *s = d.F + a0 + 4 * (int64_t)i;
+                    const int64_t left = d.total - (a0 + 4 * (int64_t)i);
+                    v[u].x = left > 0 ? s[0] : 0.f;
+                    v[u].y = left > 1 ? s[1] : 0.f;
+                    v[u].z = left > 2 ? s[2] : 0.f;
+                    v[u].w = left > 3 ? s[3] : 0.f;
+                }
+            }
+        }
+    };
+
+    float acc = 0.f;
+    slab_fetch(p0);
+    for (uint32_t p = p0; p < p1; ++p) {
+        const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
+        const int shift = (int)(e0 & 3);
+        const int n4 = (shift + (int)nrows * L + 3) >> 2;
+        {
+            float4 *dst = reinterpret_cast<float4 *>(lds);
+#pragma unroll
+            for (int u = 0; u < ROWS_UNR; ++u) {
+                const int i = u * 256 + t;
+                if (i < n4) dst[i] = v[u];
+            }
+        }
+        if (d.nshared > 0) {
+            for (int j = t; j < L; j += 256) {
+                float g = 0.f;
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f)
+                    if (f < d.nshared)
+                        g += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)j * d.sh[f].rs[0]];
+                gs[j] = g;
+            }
+        }
+        __syncthreads();
+        if (p + 1 < p1) slab_fetch(p + 1);  // in flight while this slab is reduced
+
+        float *row = lds + shift + r * L;
+        float val;
+        if (MODE == ALAN_MODE_LSE) {
+            float m = -__builtin_huge_valf();
+            if (GEN) {
+                // pass 1: x = F + small factors, written back in place; exact row max
+                for (int j = gl; j < L; j += G) {
+                    int jj = j + j0;
+                    if (ROT && jj >= L) jj -= L;
+                    float x = row[jj];
+                    if (d.nshared > 0) x += gs[jj];
+#pragma unroll
+                    for (int f = 0; f < MAXF; ++f)
+                        if (f < d.ngen)
+                            x += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
+                                                             (int64_t)jj * d.gen[f].rs[0]];
+                    row[jj] = x;
+                    m = fmaxf(m, x);
+                }
+            } else if (VEC2) {
+                const float2 *r2 = reinterpret_cast<const float2 *>(row);
+                const float2 *g2 = reinterpret_cast<const float2 *>(gs);
+                if (d.nshared > 0) {
+                    for (int q = gl; q < (L >> 1); q += G) {
+                        const float2 x = r2[q], g = g2[q];
+                        m = fmaxf(m, fmaxf(x.x + g.x, x.y + g.y));
+                    }
+                } else {
+                    for (int q = gl; q < (L >> 1); q += G) {
+                        const float2 x = r2[q];
+                        m = fmaxf(m, fmaxf(x.x, x.y));
+                    }
+                }
+            } else {
+                for (int j = gl; j < L; j += G) {
+                    int jj = j + j0;
+                    if (ROT && jj >= L) jj -= L;
+                    float x = row[jj];
+                    if (d.nshared > 0) x += gs[jj];
+                    m = fmaxf(m, x);
+                }
+            }
+#pragma unroll
+            for (int ofs = G >> 1; ofs > 0; ofs >>= 1) m = fmaxf(m, __shfl_xor(m, ofs));
+            // pass 2: sum exp(x - max)   (utils.py:219)
+            float s = 0.f;
+            const bool add_g = d.nshared > 0 && !GEN;
+            if (VEC2) {
+                const float2 *r2 = reinterpret_cast<const float2 *>(row);
+                const float2 *g2 = reinterpret_cast<const float2 *>(gs);
+                float s1 = 0.f;
+                if (add_g) {
+                    for (int q = gl; q < (L >> 1); q += G) {
+                        const float2 x = r2[q], g = g2[q];
+                        s += __expf(x.x + g.x - m);
+                        s1 += __expf(x.y + g.y - m);
+                    }
+                } else {
+                    for (int q = gl; q < (L >> 1); q += G) {
+                        const float2 x = r2[q];
+                        s += __expf(x.x - m);
+                        s1 += __expf(x.y - m);
+                    }
+                }
+                s += s1;
+            } else {
+                for (int j = gl; j < L; j += G) {
+                    int jj = j + j0;
+                    if (ROT && jj >= L) jj -= L;
+                    float x = row[jj];
+                    if (add_g) x += gs[jj];
+                    s += __expf(x - m);
+                }
+            }
+#pragma unroll
+            for (int ofs = G >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
+            val = logf(s + Num<float>::eps) + m;  // utils.py:220
+        } else {  // ALAN_MODE_SUM
+            float s = 0.f;
+            for (int j = gl; j < L; j += G) {
+                int jj = j + j0;
+                if (ROT && jj >= L) jj -= L;
+                float x = row[jj];
+                if (d.nshared > 0) x += gs[jj];
+                if (GEN) {
+#pragma unroll
+                    for (int f = 0; f < MAXF; ++f)
+                        if (f < d.ngen)
+                            x += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
+                                                             (int64_t)jj * d.gen[f].rs[0]];
+                }
+                s += x;
+            }
+#pragma unroll
+            for (int ofs = G >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
+            val = s;
+        }
+        if (has_row && gl == 0) {
+            if (d.lse) d.lse[lb + (int64_t)p * d.l_ps] = val;
+            acc += val;
+        }
+        __syncthreads();
+    }
+    if (has_row && gl == 0) {
+        if (d.partial)
+            d.partial[(int64_t)blockIdx.y * d.NO + o0 + r] = acc;
+        else
+            d.out[ob] = acc + d.add_const;
+    }
+}
+
+static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+
+RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
+    RowsPlan rp;
+    if (compute_dtype != ALAN_F32 || (mode != ALAN_MODE_LSE && mode != ALAN_MODE_SUM)) return rp;
+    if (c.nr != 1 || !c.red_contig) return rp;
+    const int64_t L = c.rsize[0];
+    if (L < 8 || L > 256) return rp;
+    for (int f = 0; f < c.nf; ++f)
+        if (c.f[f].dtype != ALAN_F32) return rp;
+    if (c.o.dtype != ALAN_F32 || (c.l.p && c.l.dtype != ALAN_F32)) return rp;
+    const KTensor &dom = c.f[c.dominant];
+    if ((reinterpret_cast<uintptr_t>(dom.p) & 15) != 0) return rp;
+    if (dom.scale != 1.f) return rp;
+    int64_t run = L;  // the dominant factor must be dense with rows of L
+    for (int j = c.nk - 1; j >= 0; --j) {
+        if (dom.ks[j] != run) return rp;
+        run *= c.ksize[j];
+    }
+    for (int f = 0; f < c.nf; ++f)
+        if (f != c.dominant && c.f[f].scale != 1.f) return rp;
+    // at most one (merged) plate dim, and it must be the outermost dim of the dominant factor
+    int nplate = 0;
+    for (int j = 0; j < c.nk; ++j) nplate += c.kplate[j] ? 1 : 0;
+    if (nplate > 1 || (nplate == 1 && !c.kplate[0])) return rp;
+    if (c.n_out * L < 16384) return rp;  // latency regime: the group kernel is as good
+
+    rp.L = (int)L;
+    rp.P = nplate ? (uint32_t)c.ksize[0] : 1u;
+    rp.NO = (uint32_t)(c.n_out / rp.P);
+    rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
+    int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
+    rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
+    rp.RB = (int)((rp.NO + rp.n_windows - 1) / rp.n_windows);
+    rp.threads = 256;
+    const uint32_t target_blocks = 2048;
+    uint32_t nch = std::max(1u, std::min(rp.P, target_blocks / std::max(1u, rp.n_windows)));
+    rp.p_chunk = (rp.P + nch - 1) / nch;
+    rp.n_chunks = (rp.P + rp.p_chunk - 1) / rp.p_chunk;
+    rp.gs_off = (int)((((int64_t)rp.RB * L + 3 + 3) / 4) * 4);
+    rp.lds_bytes = (size_t)(rp.gs_off + ((L + 3) / 4) * 4) * 4;
+    rp.partial_bytes = (nplate && rp.n_chunks > 1) ? (size_t)rp.n_chunks * rp.NO * 4 : 0;
+    rp.rot = gcd_i((int)L, 64) >= 16;
+    rp.vec2 = !rp.rot && (L % 2 == 0);
+    rp.ok = true;
+    return rp;
+}
+
+int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
+                size_t workspace_bytes, hipStream_t stream) {
+    if (!rp.ok) return ALAN_ERR_UNSUPPORTED;
+    const bool fused = rp.P > 1 || (c.nk > 0 && c.kplate[0]);
+    const bool two_stage = fused && rp.n_chunks > 1;
+    if (two_stage && (!workspace || workspace_bytes < rp.partial_bytes)) return ALAN_ERR_WORKSPACE;
+
+    RowsDesc d;
+    std::memset(&d, 0, sizeof(d));
+    const KTensor &dom = c.f[c.dominant];
+    d.F = (const float *)dom.p;
+    d.total = c.n_out * rp.L;
+    d.L = rp.L;
+    d.RB = rp.RB;
+    d.NO = rp.NO;
+    d.P = rp.P;
+    d.p_chunk = rp.p_chunk;
+    d.gs_off = rp.gs_off;
+    const int k0 = (c.nk > 0 && c.kplate[0]) ? 1 : 0;  // first inner keep dim
+    d.nki = c.nk - k0;
+    for (int j = 0; j < d.nki; ++j) d.kdiv[j] = make_fastdiv((uint32_t)c.ksize[k0 + j]);
+    for (int f = 0; f < c.nf; ++f) {
+        if (f == c.dominant) continue;
+        bool shared = true;  // constant over the window: no inner keep dim
+        for (int j = 0; j < d.nki; ++j) shared = shared && c.f[f].ks[k0 + j] == 0;
+        KTensor &dst = shared ? d.sh[d.nshared] : d.gen[d.ngen];
+        dst.p = c.f[f].p;
+        dst.dtype = c.f[f].dtype;
+        dst.scale = 1.f;
+        for (int j = 0; j < d.nki; ++j) dst.ks[j] = c.f[f].ks[k0 + j];
+        dst.rs[0] = c.f[f].rs[0];
+        (shared ? d.sh_ps[d.nshared] : d.gen_ps[d.ngen]) = k0 ? c.f[f].ks[0] : 0;
+        ++(shared ? d.nshared : d.ngen);
+    }
+    d.out = (float *)const_cast<void *>(c.o.p);
+    for (int j = 0; j < d.nki; ++j) d.oks[j] = c.o.ks[k0 + j];
+    d.partial = two_stage ? (float *)workspace : nullptr;
+    d.lse = (float *)const_cast<void *>(c.l.p);
+    for (int j = 0; j < d.nki; ++j) d.lks[j] = c.l.ks[k0 + j];
+    d.l_ps = k0 ? c.l.ks[0] : 0;
+    d.add_const = two_stage ? 0.f : (float)add_const;
+
+    const dim3 grid(rp.n_windows, rp.n_chunks);
+    const dim3 block(256);
+#define ALAN_ROWS4(MODE, G, V, R, GN) \
+    hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN>), grid, block, rp.lds_bytes, stream, d)
+#define ALAN_ROWS3(MODE, G, V, R)                       \
+    if (d.ngen > 0) ALAN_ROWS4(MODE, G, false, R, true); \
+    else ALAN_ROWS4(MODE, G, V, R, false)
+#define ALAN_ROWS2(MODE, V, R)                        \
+    switch (rp.logG) {                                \
+        case 0: ALAN_ROWS3(MODE, 0, V, R); break;     \
+        case 1: ALAN_ROWS3(MODE, 1, V, R); break;     \
+        case 2: ALAN_ROWS3(MODE, 2, V, R); break;     \
+        default: ALAN_ROWS3(MODE, 3, V, R); break;    \
+    }
+    if (mode == ALAN_MODE_LSE) {
+        if (rp.rot) { ALAN_ROWS2(ALAN_MODE_LSE, false, true) }
+        else if (rp.vec2) { ALAN_ROWS2(ALAN_MODE_LSE, true, false) }
+        else { ALAN_ROWS2(ALAN_MODE_LSE, false, false) }
+    } else {
+        if (rp.rot) { ALAN_ROWS2(ALAN_MODE_SUM, false, true) }
+        else { ALAN_ROWS2(ALAN_MODE_SUM, false, false) }
+    }
+#undef ALAN_ROWS4
+#undef ALAN_ROWS2
+#undef ALAN_ROWS3
+    if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+    if (!two_stage) return ALAN_OK;
+
+    // ---- second stage: out[o] = sum_chunk partial[chunk, o]  (+ add_const), via the group kernel
+    Canon s2;
+    s2.nk = d.nki;
+    s2.nr = 1;
+    s2.nf = 1;
+    s2.dominant = 0;
+    s2.rsize[0] = rp.n_chunks;
+    s2.f[0].p = workspace;
+    s2.f[0].dtype = ALAN_F32;
+    s2.f[0].scale = 1.f;
+    s2.f[0].rs[0] = rp.NO;
+    int64_t st = 1;
+    for (int j = d.nki - 1; j >= 0; --j) {
+        s2.ksize[j] = c.ksize[k0 + j];
+        s2.f[0].ks[j] = st;
+        st *= s2.ksize[j];
+        s2.o.ks[j] = c.o.ks[k0 + j];
+        s2.kplate[j] = false;
+    }
+    s2.w.p = nullptr;
+    s2.l.p = nullptr;
+    s2.o.p = c.o.p;
+    s2.o.dtype = c.o.dtype;
+    s2.n_out = rp.NO;
+    s2.n_red = rp.n_chunks;
+    s2.red_contig = false;
+    s2.keep_contig = true;
+    GroupDesc gd;
+    GroupLaunch gl;
+    int rc = plan_group(s2, c.o.dtype, add_const, gd, gl);
+    if (rc != ALAN_OK) return rc;
+    return launch_group(gd, gl, ALAN_MODE_SUM, ALAN_F32, stream);
+}
 
 }  // namespace alan
