@@ -1,1 +1,21 @@
-"""alan_amd: MI355X-native implementation of alan's tensorised marginal-likelihood hot path."""
+"""
+alan_amd -- MI355X-native implementation of alan's tensorised marginal-likelihood hot path
+(sample -> per-factor log-probs -> reduce_Ks / logsumexp_dims -> plate sum -> ELBO), behind alan's
+own Plate / BoundPlate / Problem / Sample API (src/alan/__init__.py:1-16 of the reference).
+
+Host code (model definition, sampling, per-factor log-probs) is Python on PyTorch-ROCm; the
+contraction itself is hand-written HIP for gfx950 in libalan_mi355.so (include/alan_mi355.h).
+There is no CPU fallback: evaluating an ELBO needs the library and a GPU.
+"""
+from .model import Plate, Group, Data
+from .timeseries import Timeseries
+from .samplers import CategoricalSampler, PermutationSampler, IndependentSampler
+from .dist import *          # noqa: F401,F403  (Normal, Bernoulli, ..., OptParam, QEMParam, TorchDimDist)
+from .dist import OptParam, QEMParam, TorchDimDist, new_dist
+from .bound import BoundPlate, Problem
+from .split import Split, no_checkpoint, checkpoint
+from .sample import Sample
+from .contract import (reduce_Ks, collect_lps, logsumexp_sum, logsumexp_dims, logmeanexp_dims,
+                       chain_logmmexp)
+
+samplers = [CategoricalSampler, PermutationSampler]

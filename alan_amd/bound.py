@@ -1,0 +1,230 @@
+"""
+``BoundPlate`` (a Plate + plate sizes + inputs + parameters) and ``Problem`` (P, Q, data) --
+BoundPlate.py / Problem.py of the reference, restricted to what the ELBO path needs.  Parameters
+declared with OptParam become ``nn.Parameter``s; QEMParam values are kept as buffers (sampling and
+log-probs work) but the QEM optimiser itself is out of scope of this build.
+"""
+import torch as t
+import torch.nn as nn
+
+from .dims import Dim, dims_of, named_to_dim, dim_to_named
+from .dist import Dist
+from .model import Plate, check_name, flatten_tree, tensordict2tree
+from .samplers import PermutationSampler, Sampler, IndependentSampler, on_device
+from .timeseries import Timeseries
+
+
+class _NamedStore(nn.Module):
+    """Dict of named tensors held as buffers or parameters (so .to(device) moves them)."""
+
+    def __init__(self, tensors, as_parameters=False):
+        super().__init__()
+        self._keys, self._names = [], {}
+        for k, v in tensors.items():
+            assert isinstance(v, t.Tensor), f"{k} must be a tensor"
+            assert not hasattr(self, f"t_{k}")
+            self._keys.append(k)
+            self._names[k] = v.names
+            raw = v.rename(None)
+            if as_parameters:
+                self.register_parameter(f"t_{k}", nn.Parameter(raw.clone()))
+            else:
+                self.register_buffer(f"t_{k}", raw.clone())
+
+    def to_dict(self):
+        return {k: getattr(self, f"t_{k}").refine_names(*self._names[k]) for k in self._keys}
+
+
+def _plate_names(x):
+    return [n for n in x.names if n is not None]
+
+
+def expand_named(x, names, all_platesizes):
+    """Give a parameter's initial value every plate dim of the variable it belongs to."""
+    have = _plate_names(x)
+    for n in (*have, *names):
+        if n not in all_platesizes:
+            raise Exception(f"{n} is a plate dimension, but is not given in all_platesizes")
+    extra = [n for n in names if n not in have]
+    if not extra:
+        return x.align_to(*names, ...) if have else x
+    shape = [all_platesizes[n] for n in extra]
+    out = x.rename(None).expand(*shape, *x.shape).contiguous()
+    return out.refine_names(*extra, *x.names).align_to(*names, ...)
+
+
+class BoundPlate(nn.Module):
+    def __init__(self, plate, all_platesizes=None, inputs=None, extra_opt_params=None):
+        super().__init__()
+        self.register_buffer("_device_tensor", t.zeros(()))
+        assert isinstance(plate, Plate)
+        self.plate = plate
+        all_platesizes = {} if all_platesizes is None else dict(all_platesizes)
+        for pn in plate.all_platenames():
+            if pn not in all_platesizes:
+                raise Exception(f"Every plate must have a platesize specified in all_platesizes, but {pn} "
+                                "doesn't have a specified size")
+        self.all_platesizes = all_platesizes
+        inputs = {} if inputs is None else dict(inputs)
+        extra_opt_params = {} if extra_opt_params is None else dict(extra_opt_params)
+        for k, v in {**inputs, **extra_opt_params}.items():
+            if not isinstance(v, t.Tensor):
+                raise Exception(f"`inputs` and `extra_opt_params` must be provided as a plain named tensor, "
+                                f"but {k} is of type {type(v)}")
+            for n in _plate_names(v):
+                if n not in all_platesizes:
+                    raise Exception(f"Dimension name {n} used on input/extra_opt_param {k}, but not provided "
+                                    "in all_platesizes")
+                if v.size(n) != all_platesizes[n]:
+                    raise Exception(f"Dimension mismatch for input {k} along dimension {n}; all_platesizes "
+                                    f"gives {all_platesizes[n]}, while {k} is {v.size(n)}")
+
+        g2p = plate.groupvarname2platenames()
+        opt, qem = dict(extra_opt_params), {}
+        self.opt_paramname2trans = {k: (lambda x: x) for k in opt}
+        for varname, (groupname, dist) in plate.varname2groupvarname_dist().items():
+            for pname, (argname, param) in dist.opt_qem_params.items():
+                if pname in opt or pname in qem:
+                    raise Exception(f"Param is trying to add parameter named {pname}, but there's already a "
+                                    "parameter with this name")
+                value = expand_named(param.init, g2p[groupname], all_platesizes)
+                if dist.qem_dist:
+                    qem[pname] = value
+                else:
+                    opt[pname] = value
+                    self.opt_paramname2trans[pname] = param.trans
+
+        self._inputs = _NamedStore(inputs)
+        self._opt_params = _NamedStore(opt, as_parameters=True)
+        self._qem_params = _NamedStore(qem)
+        self._dists = nn.ModuleDict({k: d for k, d in plate.varname2dist().items()})
+
+        names = [*inputs, *opt, *qem]
+        for n in names:
+            check_name(n)
+        if len(set(names)) != len(names):
+            raise Exception("BoundPlate has overlapping names in inputs, opt_params, and/or qem_params")
+        clash = set(names).intersection(plate.all_prog_names())
+        if clash:
+            raise Exception("The program in BoundPlate has plate/random variable names that overlap with the "
+                            f"inputs/params.  Specifically {clash}.")
+        self.sample()      # checks all dependencies resolve
+
+    @property
+    def device(self):
+        return self._device_tensor.device
+
+    def inputs(self):
+        return self._inputs.to_dict()
+
+    def opt_params(self):
+        return {k: self.opt_paramname2trans[k](v) for k, v in self._opt_params.to_dict().items()}
+
+    def qem_params(self):
+        return self._qem_params.to_dict()
+
+    def inputs_params_flat_named(self):
+        return {**self.inputs(), **self.opt_params(), **self.qem_params()}
+
+    def inputs_params(self, all_platedims):
+        flat = {k: named_to_dim(v, all_platedims) for k, v in self.inputs_params_flat_named().items()}
+        return tensordict2tree(self.plate, flat)
+
+    def groupvarname2platenames(self):
+        return self.plate.groupvarname2platenames()
+
+    def varname2groupvarname(self):
+        return self.plate.varname2groupvarname()
+
+    def _sample(self, K, reparam, sampler, all_platedims):
+        assert isinstance(K, int) and isinstance(reparam, bool) and issubclass(sampler, Sampler)
+        Kdims = self.plate.groupvarname2Kdim(K)
+        with on_device(self.device):
+            tree = self.plate.sample(None, {}, self.inputs_params(all_platedims), [], all_platedims, Kdims,
+                                     sampler, reparam)
+        return tree, Kdims
+
+    def sample(self, sample_size=1):
+        """One (or N) joint sample(s) from the model as a flat dict of named tensors."""
+        all_platedims = {n: Dim(n, s) for n, s in self.all_platesizes.items()}
+        platedims = list(all_platedims.values())
+        tree, _ = self._sample(sample_size, False, PermutationSampler, all_platedims)
+        out = {}
+        N = Dim("N", sample_size)
+        for k, v in flatten_tree(tree).items():
+            Ks = [d for d in dims_of(v) if d not in set(platedims)]
+            v = v.order(*Ks) if Ks else v
+            if sample_size > 1:
+                v = v[N] if Ks else v
+            else:
+                for _ in Ks:
+                    v = v.squeeze(0)
+            out[k] = dim_to_named(v.detach(), order=[N, *platedims] if sample_size > 1 else platedims)
+        return out
+
+
+def _same_structure(name, P, Q, data_tree):
+    """P and Q must list the same variables/plates; Q marks observed variables with Data() and
+    ``data`` must provide exactly those (checking.py of the reference, condensed)."""
+    from .model import Data
+    if set(P.flat_prog) != set(Q.flat_prog):
+        raise Exception(f"P and Q have different variables in plate {name}: "
+                        f"{sorted(set(P.flat_prog) ^ set(Q.flat_prog))}")
+    for k, q in Q.flat_prog.items():
+        p = P.flat_prog[k]
+        if isinstance(q, Plate):
+            if not isinstance(p, Plate):
+                raise Exception(f"{k} is a Plate in Q but not in P")
+            _same_structure(k, p, q, data_tree.get(k, {}))
+        elif isinstance(q, Data):
+            if k not in data_tree:
+                raise Exception(f"{k} is Data() in Q but no data was provided for it")
+        elif k in data_tree:
+            raise Exception(f"data provided for {k}, which Q treats as a latent variable")
+
+
+class Problem(nn.Module):
+    def __init__(self, P, Q, data):
+        super().__init__()
+        if not isinstance(P, BoundPlate) or not isinstance(Q, BoundPlate):
+            raise Exception("P and Q must be `BoundPlate`s, not e.g. `Plate`s.  You can convert just using "
+                            "`bound_plate_P = BoundPlate(plate_P)` if it doesn't have any inputs or parameters")
+        self.register_buffer("_device_tensor", t.zeros(()))
+        self.P, self.Q = P, Q
+        if P.all_platesizes != Q.all_platesizes:
+            raise Exception(f"all_platesizes does not match between P and Q.  In P it is {P.all_platesizes}, "
+                            f"while in Q it is {Q.all_platesizes}")
+        self.all_platedims = {n: Dim(n, s) for n, s in P.all_platesizes.items()}
+        self._data = _NamedStore(data)
+        _same_structure(None, P.plate, Q.plate, self.data)
+        pin, qin = P.inputs_params_flat_named(), Q.inputs_params_flat_named()
+        for k in set(pin) & set(qin):
+            if pin[k].shape != qin[k].shape or not t.equal(pin[k].rename(None), qin[k].rename(None)):
+                raise Exception(f"input/parameter {k} is defined differently on P and Q")
+
+    @property
+    def data(self):
+        flat = {k: named_to_dim(v, self.all_platedims) for k, v in self._data.to_dict().items()}
+        return tensordict2tree(self.P.plate, flat)
+
+    @property
+    def device(self):
+        return self._device_tensor.device
+
+    def check_device(self):
+        if not (self.device == self.P.device and self.device == self.Q.device):
+            raise Exception("Device issue: Problem, P and/or Q aren't all on the same device.  The easiest way "
+                            "to make sure everything works is to call e.g. problem.to('cuda'), rather than "
+                            "e.g. P.to('cuda').")
+
+    def inputs_params(self):
+        flat = {**self.P.inputs_params_flat_named(), **self.Q.inputs_params_flat_named()}
+        flat = {k: named_to_dim(v, self.all_platedims) for k, v in flat.items()}
+        return tensordict2tree(self.P.plate, flat)
+
+    def sample(self, K, reparam=True, sampler=PermutationSampler):
+        """K samples of every latent from Q, each latent group on its own K dim (Problem.py:71-97)."""
+        from .sample import Sample
+        self.check_device()
+        tree, Kdims = self.Q._sample(K, reparam, sampler, self.all_platedims)
+        return Sample(problem=self, sample=tree, groupvarname2Kdim=Kdims, sampler=sampler, reparam=reparam)

@@ -1,0 +1,103 @@
+"""
+Small helpers over functorch.dim ("torchdim") first-class dimensions.
+
+alan represents every sample / log-prob as a torchdim tensor whose K- and plate-dims are first
+class ``Dim`` objects.  The HIP engine works on positional strided tensors, so this module is the
+bridge: ``unwrap`` turns a torchdim tensor into (positional view, dims) without copying, ``wrap``
+goes back.  (Role of the reference's generic_dims/generic_order/generic_getitem, utils.py:229-273.)
+"""
+import functorch.dim
+import torch as t
+from functorch.dim import Dim
+
+DimTensor = functorch.dim.Tensor
+AnyTensor = (t.Tensor, DimTensor)
+
+
+def is_dimtensor(x):
+    return isinstance(x, DimTensor)
+
+
+def is_tensor(x):
+    return isinstance(x, AnyTensor)
+
+
+def dims_of(x):
+    """First-class dims carried by ``x`` (empty for plain tensors and numbers)."""
+    return tuple(x.dims) if is_dimtensor(x) else ()
+
+
+def check_dims(dims, what="dims"):
+    """Same complaints as utils.py:154-171: list/tuple, unique, all ``Dim``."""
+    if not isinstance(dims, (list, tuple)):
+        raise Exception(f"{what} must be a list or tuple")
+    if len(set(dims)) != len(dims):
+        raise Exception(f"Non-unique elements in {what}")
+    for d in dims:
+        if not isinstance(d, Dim):
+            raise Exception(f"dim in {what} is not torchdim dimension")
+
+
+def dim_in(d, seq):
+    """Identity membership: ``Dim`` overloads ``==`` to build a tensor, so never use ``in`` on a
+    list/tuple of dims."""
+    return any(d is e for e in seq)
+
+
+def union_dims(tensors):
+    """Ordered union of the dims of several tensors."""
+    seen = {}
+    for x in tensors:
+        for d in dims_of(x):
+            seen.setdefault(d, None)
+    return tuple(seen)
+
+
+def unwrap(x, dims=None):
+    """torchdim tensor -> positional tensor whose leading dims are ``dims`` (default: x's own dims,
+    in the order torchdim reports them).  A view: strides are whatever the producer left behind."""
+    if dims is None:
+        dims = dims_of(x)
+    dims = tuple(dims)
+    if not dims:
+        return x, ()
+    return x.order(*dims), dims
+
+
+def wrap(x, dims):
+    """Positional tensor -> torchdim tensor binding the leading positional dims to ``dims``."""
+    dims = tuple(dims)
+    if not dims:
+        return x
+    return x[dims]
+
+
+def named_to_dim(x, platedims):
+    """Named tensor -> torchdim tensor (names must be plate names); unnamed dims stay positional."""
+    if not isinstance(x, t.Tensor):
+        return x
+    for n in x.names:
+        if n is not None and n not in platedims:
+            raise Exception(f"No torchdim dimension for named dimension {n}")
+    idx = [slice(None) if n is None else platedims[n] for n in x.names]
+    x = x.rename(None)
+    return x[tuple(idx)] if any(isinstance(i, Dim) for i in idx) else x
+
+
+def dim_to_named(x, order=None):
+    """torchdim tensor -> named tensor (dims first, in ``order`` if given)."""
+    ds = dims_of(x)
+    if order is not None:
+        have = set(ds)
+        ds = tuple(d for d in order if d in have)
+    if not ds:
+        return x
+    pos = x.order(*ds)
+    return pos.refine_names(*[str(d) for d in ds], *([None] * (pos.ndim - len(ds))))
+
+
+def sum_positional(x):
+    """Sum out every positional dim (utils.py:147-152 ``sum_non_dim``)."""
+    if is_tensor(x) and x.ndim > 0:
+        return x.sum(tuple(range(x.ndim)))
+    return x

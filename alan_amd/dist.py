@@ -1,0 +1,273 @@
+"""
+Distribution layer (host side, stays on PyTorch-ROCm as north_star specifies): wraps
+``torch.distributions`` so parameters and samples may be torchdim tensors, and provides the
+user-facing ``alan.Normal(...)``-style specs.  Mirrors dist.py / TorchDimDist.py of the reference in
+behaviour; the implementation differs in one respect that matters to the HIP path:
+``TorchDimDist.log_prob`` lays the resulting factor out with the dims in a caller-chosen order, and
+the plate recursion asks for  [plates..., parent Ks..., own K]  so that the K dim which reduce_Ks
+eliminates is the CONTIGUOUS dim of the big factor -- the layout the rows kernel streams at HBM rate.
+"""
+import inspect
+import types
+
+import torch as t
+import torch.distributions as td
+import torch.nn as nn
+
+from .dims import Dim, dims_of, is_dimtensor, is_tensor, sum_positional, union_dims
+
+Number = (int, float)
+
+# torch >= 2.10 made arg_constraints an instance property for these
+_EVENT_NDIM_FALLBACK = {
+    "Uniform": {"low": 0, "high": 0},
+    "Wishart": {"df": 0, "covariance_matrix": 2, "precision_matrix": 2, "scale_tril": 2},
+}
+
+
+def _arg_event_ndim(dist_cls, name):
+    ac = dist_cls.__dict__.get("arg_constraints", getattr(dist_cls, "arg_constraints", None))
+    if isinstance(ac, dict) and name in ac:
+        return ac[name].event_dim
+    return _EVENT_NDIM_FALLBACK.get(dist_cls.__name__, {}).get(name, 0)
+
+
+def _arg_is_discrete(dist_cls, name):
+    ac = getattr(dist_cls, "arg_constraints", None)
+    if isinstance(ac, dict) and name in ac:
+        return bool(ac[name].is_discrete)
+    return False
+
+
+def _positional(x, dim_order, lead_pad):
+    """torchdim/plain tensor -> plain tensor laid out [dim_order (1 where absent)..., 1*lead_pad, own positional...]."""
+    own = set(dims_of(x))
+    present = [d for d in dim_order if d in own]
+    assert len(present) == len(own), "tensor carries a dim outside the requested order"
+    pos = x.order(*present) if present else x
+    idx = tuple(slice(None) if d in own else None for d in dim_order) + (None,) * lead_pad
+    return pos[idx] if idx else pos
+
+
+class TorchDimDist:
+    """A torch.distributions distribution whose parameters are torchdim tensors."""
+
+    def __init__(self, dist, **kwargs):
+        self.dist = dist
+        self.kwargs = {k: (v if is_tensor(v) else t.as_tensor(v)) for k, v in kwargs.items()}
+        self.all_arg_dims = union_dims(self.kwargs.values())
+        self.sample_event_ndim = dist.support.event_dim
+        self.arg_event_ndim = {k: _arg_event_ndim(dist, k) for k in self.kwargs}
+        self.arg_batch_ndim = {k: v.ndim - self.arg_event_ndim[k] for k, v in self.kwargs.items()}
+        self.sample_batch_ndim = max(self.arg_batch_ndim.values())
+
+    def _build(self, dim_order, n_sample_pad=0):
+        """Instantiate the torch distribution with every parameter laid out
+        [dim_order..., 1*n_sample_pad, batch (left-padded)..., event...]."""
+        args = {}
+        for k, v in self.kwargs.items():
+            pad = n_sample_pad + self.sample_batch_ndim - self.arg_batch_ndim[k]
+            args[k] = _positional(v, dim_order, pad)
+        return self.dist(**args)
+
+    def sample(self, reparam, sample_dims, sample_shape=()):
+        """Sample with exactly the dims ``sample_dims`` (a superset of the parameters' dims) and the
+        positional shape [*sample_shape, *batch, *event]."""
+        sample_dims = list(sample_dims)
+        if len(set(sample_dims)) != len(sample_dims):
+            raise Exception("Non-unique elements in sample_dims")
+        assert set(self.all_arg_dims).issubset(sample_dims)
+        if reparam and not self.dist.has_rsample:
+            raise Exception(f"Trying to do reparameterised sampling of {self.dist}, which is not implemented "
+                            "by PyTorch (likely because it is a distribution over discrete random variables).")
+        extra = [d for d in sample_dims if d not in set(self.all_arg_dims)]
+        d = self._build(self.all_arg_dims)
+        draw = d.rsample if reparam else d.sample
+        x = draw(sample_shape=t.Size([*sample_shape, *[e.size for e in extra]]))
+        idx = (slice(None),) * len(sample_shape) + (*extra, *self.all_arg_dims)
+        return x[idx] if (extra or self.all_arg_dims) else x
+
+    def log_prob(self, x, dim_order=None):
+        """log p(x) as a torchdim tensor over (x's dims) U (parameter dims); positional sample/batch
+        dims are summed out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of
+        the result: ``lead`` dims outermost, ``last`` dims innermost, any others in between."""
+        assert is_tensor(x)
+        every = list(union_dims([x, *self.kwargs.values()]))
+        if dim_order is not None:
+            lead, last = dim_order
+            rank = {d: i for i, d in enumerate(lead)}
+            rank.update({d: len(lead) + 1 + i for i, d in enumerate(last)})
+            every.sort(key=lambda d: rank.get(d, len(lead)))    # other dims sit between lead and last
+        n_sample = x.ndim - self.sample_batch_ndim - self.sample_event_ndim
+        assert n_sample >= 0
+        d = self._build(every, n_sample)
+        own = set(dims_of(x))
+        pos = x.order(*[dd for dd in every if dd in own]) if own else x
+        pos = pos[tuple(slice(None) if dd in own else None for dd in every)] if every else pos
+        lp = d.log_prob(pos)
+        extra = lp.ndim - len(every)
+        if extra > 0:
+            lp = lp.sum(tuple(range(len(every), lp.ndim)))
+        return lp[tuple(every)] if every else lp
+
+
+# --------------------------------------------------------------------------------------------
+def function_arguments(f):
+    """Argument names of a model lambda; alan insists on plain positional signatures (utils.py:17-43)."""
+    spec = inspect.getfullargspec(f)
+    if spec.varargs is not None:
+        raise Exception("In Alan, functions may not have *args")
+    if spec.varkw is not None:
+        raise Exception("In Alan, functions may not have **kwargs")
+    if spec.defaults is not None or spec.kwonlydefaults is not None:
+        raise Exception("In Alan, functions may not have defaults")
+    if spec.kwonlyargs:
+        raise Exception("In Alan, functions may not have keyword only arguments")
+    if spec.annotations:
+        raise Exception("In Alan, functions may not have type annotations")
+    return spec.args
+
+
+class Param:
+    """Marker base for parameters declared inline in a distribution."""
+
+
+def _as_init(init):
+    if isinstance(init, Number):
+        init = t.tensor(float(init))
+    assert isinstance(init, t.Tensor)
+    return init
+
+
+class OptParam(Param):
+    """A parameter learned by gradient descent (Param.py:18-25)."""
+
+    def __init__(self, init, transformation=None, ignore_platenames=(), name=None):
+        self.init = _as_init(init)
+        self.trans = transformation if transformation is not None else (lambda x: x)
+        self.ignore_platenames = ignore_platenames
+        self.name = name
+
+
+class QEMParam(Param):
+    """A parameter of a QEM-updated distribution (Param.py:27-32).  alan_amd keeps the parameter
+    (so sampling / log-probs work) but does not implement the QEM optimiser (out of scope)."""
+
+    def __init__(self, init, ignore_platenames=(), name=None):
+        self.init = _as_init(init)
+        self.trans = lambda x: x
+        self.ignore_platenames = ignore_platenames
+        self.name = name
+
+
+class Dist(nn.Module):
+    """A named random variable: torch distribution class + how to get each argument from scope."""
+
+    is_timeseries = False
+
+    def __init__(self, varname, dist, args, kwargs, sample_shape=t.Size([])):
+        super().__init__()
+        self.varname = varname
+        self.dist = dist
+        self.sample_shape = t.Size(sample_shape)
+        self.register_buffer("_device_tensor", t.zeros(()))
+        bound = inspect.signature(dist).bind(*args, **kwargs).arguments
+
+        n_qem = sum(isinstance(v, QEMParam) for v in bound.values())
+        n_opt = sum(isinstance(v, OptParam) for v in bound.values())
+        self.qem_dist, self.opt_dist = n_qem > 0, n_opt > 0
+        if (self.qem_dist or self.opt_dist) and len(self.sample_shape) > 0:
+            raise Exception("You can't use sample_shape with QEM or Opt parameters")
+        if self.qem_dist and n_qem != len(bound):
+            raise Exception("If one parameter on a distribution is a QEMParam, then all parameters on that "
+                            "distribution should be QEM distributions")
+
+        self.opt_qem_params = {}          # paramname -> (distargname, Param)
+        self._names, self._funcs, self._consts = {}, {}, {}
+        used = []
+        for argname, v in bound.items():
+            if isinstance(v, Param):
+                if varname is None:
+                    raise Exception("You can't use QEMParam / OptParam in a timeseries at present")
+                pname = v.name if v.name is not None else f"{varname}_{argname}"
+                self.opt_qem_params[pname] = (argname, v)
+                v = pname
+            if isinstance(v, str):
+                self._names[argname] = v
+                used.append(v)
+            elif isinstance(v, types.FunctionType):
+                self._funcs[argname] = (v, function_arguments(v))
+                used.extend(self._funcs[argname][1])
+            elif isinstance(v, t.Tensor):
+                self.register_buffer(f"_const_{argname}", v.rename(None))
+                self._consts[argname] = None
+            else:
+                assert isinstance(v, Number), f"unsupported argument {v!r} for {varname}"
+                val = v if _arg_is_discrete(dist, argname) else float(v)
+                self.register_buffer(f"_const_{argname}", t.tensor(val))
+                self._consts[argname] = None
+        self.all_args = list(dict.fromkeys(used))
+
+    @property
+    def device(self):
+        return self._device_tensor.device
+
+    def tdd(self, scope):
+        kw = {}
+        for a in self._consts:
+            kw[a] = getattr(self, f"_const_{a}")
+        for a, name in self._names.items():
+            kw[a] = scope[name]
+        for a, (fn, argnames) in self._funcs.items():
+            val = fn(*[scope[n] for n in argnames])
+            if not is_tensor(val):
+                raise Exception("Lambda on a distribution returned a non-Tensor")
+            kw[a] = val
+        return TorchDimDist(self.dist, **kw)
+
+    def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm=None):
+        return self.tdd(scope).sample(reparam, [*active_platedims, K_dim], self.sample_shape)
+
+    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None):
+        return self.tdd(scope).log_prob(x, dim_order=dim_order), None
+
+
+class _DistSpec:
+    """What the user writes, e.g. ``Normal('a', 1.)``; becomes a Dist once its variable name is known."""
+    dist = None
+    nargs = None
+
+    def __init__(self, *args, sample_shape=t.Size([]), **kwargs):
+        if len(args) + len(kwargs) != self.nargs:
+            raise Exception(f"Wrong number of arguments provided to {type(self)}")
+        self.args, self.kwargs, self.sample_shape = args, kwargs, sample_shape
+
+    def finalize(self, varname):
+        return Dist(varname, self.dist, self.args, self.kwargs, self.sample_shape)
+
+
+_REGISTRY = {
+    "Bernoulli": 1, "Beta": 2, "Binomial": 2, "Categorical": 1, "Cauchy": 2, "Chi2": 1,
+    "ContinuousBernoulli": 1, "Dirichlet": 1, "Exponential": 1, "FisherSnedecor": 2, "Gamma": 2,
+    "Geometric": 1, "Gumbel": 2, "HalfCauchy": 1, "HalfNormal": 1, "Kumaraswamy": 2, "LKJCholesky": 2,
+    "Laplace": 2, "LogNormal": 2, "LowRankMultivariateNormal": 3, "Multinomial": 2,
+    "MultivariateNormal": 2, "NegativeBinomial": 2, "Normal": 2, "OneHotCategorical": 1, "Pareto": 2,
+    "Poisson": 1, "RelaxedBernoulli": 2, "LogitRelaxedBernoulli": 2, "RelaxedOneHotCategorical": 2,
+    "StudentT": 3, "Uniform": 2, "VonMises": 2, "Weibull": 2, "Wishart": 2,
+}
+
+__all__ = ["TorchDimDist", "Dist", "OptParam", "QEMParam", "new_dist"]
+
+
+def new_dist(name, dist, nargs):
+    """Register a distribution class under ``alan_amd.<name>`` (dist.py:357-366)."""
+    cls = type(name, (_DistSpec,), {"dist": dist, "nargs": nargs})
+    globals()[name] = cls
+    if name not in __all__:
+        __all__.append(name)
+    return cls
+
+
+for _name, _nargs in _REGISTRY.items():
+    if hasattr(td, _name):
+        new_dist(_name, getattr(td, _name), _nargs)

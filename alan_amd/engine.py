@@ -144,14 +144,44 @@ class _Reduce(t.autograd.Function):
         return (None, *grads)
 
 
+class _Tokens:
+    """Dim keys -> small ints and back.  functorch ``Dim`` overloads ``==`` (it builds a tensor), so
+    keys may only ever be compared through a dict; internally the engine works on ints."""
+
+    def __init__(self):
+        self.fwd, self.back = {}, []
+
+    def __call__(self, key):
+        if key not in self.fwd:
+            self.fwd[key] = len(self.back)
+            self.back.append(key)
+        return self.fwd[key]
+
+    def many(self, keys):
+        return tuple(self(k) for k in keys)
+
+    def keys(self, toks):
+        return tuple(self.back[i] for i in toks)
+
+
 def reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     """Fused ``sum(factors)`` -> log-sum-exp over ``reduce`` -> sum over ``plate``.
     Returns (tensor, dims)."""
+    tok = _Tokens()
+    factors = [(x, tok.many(d)) for x, d in factors]
+    for d in (*reduce, *plate):
+        if d not in tok.fwd:
+            raise Exception(f"dim {d} to reduce is not on any factor")
+    out, dims = _reduce_factors(factors, tok.many(reduce), tok.many(plate), add_const)
+    return out, tok.keys(dims)
+
+
+def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     factors = [(x, tuple(d)) for x, d in factors]
     reduce, plate = tuple(reduce), tuple(plate)
     if add_const != 0.0 and any(x.requires_grad for x, _ in factors) and reduce and not plate:
         # keep the saved log-sum-exp free of the constant: apply it outside
-        out, dims = reduce_factors(factors, reduce, plate, 0.0)
+        out, dims = _reduce_factors(factors, reduce, plate, 0.0)
         return out + add_const, dims
     spec = (tuple(d for _, d in factors), reduce, plate, float(add_const))
     out = _Reduce.apply(spec, *[x for x, _ in factors])
@@ -223,13 +253,14 @@ def plan_elimination(dimsets, sizes, Ks):
 def contract(factors, Ks, plate=()):
     """reduce_Ks on positional factors, with the trailing plate sum fused into the last launch.
     Returns (result, dims, per-step record) -- the record is what sample_Ks-style consumers need."""
-    factors = [(x, tuple(d)) for x, d in factors]
+    tok = _Tokens()
+    factors = [(x, tok.many(d)) for x, d in factors]
     sizes = _space(factors)
-    Ks = tuple(Ks)
-    plate = tuple(p for p in plate)
-    for k in Ks:
-        if k not in sizes:
-            raise Exception(f"K dim {k} is not on any factor")
+    for k in (*Ks, *plate):
+        if k not in tok.fwd:
+            raise Exception(f"dim {k} to sum is not on any factor")
+    Ks = tok.many(Ks)
+    plate = tok.many(plate)
     steps = plan_elimination([d for _, d in factors], sizes, Ks)
     if not steps:
         steps = [(tuple(range(len(factors))), ())] if (plate or len(factors) > 1) else []
@@ -238,10 +269,10 @@ def contract(factors, Ks, plate=()):
     for si, (ids, now) in enumerate(steps):
         last = si == len(steps) - 1
         group = [pool[i] for i in ids]
-        record.append((group, now))
-        out, dims = reduce_factors(group, reduce=now, plate=plate if last else ())
+        record.append(([(x, tok.keys(d)) for x, d in group], tok.keys(now)))
+        out, dims = _reduce_factors(group, reduce=now, plate=plate if last else ())
         pool.append((out, dims))
     if not steps:
-        return factors[0][0], factors[0][1], record
+        return factors[0][0], tok.keys(factors[0][1]), record
     out, dims = pool[-1]
-    return out, dims, record
+    return out, tok.keys(dims), record

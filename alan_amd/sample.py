@@ -1,0 +1,88 @@
+"""
+``Sample``: K particles per latent group drawn from Q, and the ELBO entry points
+``elbo_vi / elbo_rws / elbo_nograd`` (Sample.py:69-148 of the reference).  The returned value is a
+0-dim tensor on the Problem's device; every K dim has been summed out on the HIP engine.
+"""
+import torch as t
+
+from .dims import dims_of, is_tensor, sum_positional
+from .logpq import logPQ_plate
+from .model import tensordict2tree
+from .split import Split, checkpoint, no_checkpoint
+
+
+def _detach_tree(tree):
+    return {k: (_detach_tree(v) if isinstance(v, dict) else v.detach()) for k, v in tree.items()}
+
+
+class Sample:
+    def __init__(self, problem, sample, groupvarname2Kdim, sampler, reparam):
+        self.problem = problem
+        self.groupvarname2Kdim = groupvarname2Kdim
+        self.sampler = sampler
+        self.reparam = reparam
+        if reparam:
+            self.reparam_sample = sample
+            self.detached_sample = _detach_tree(sample)
+        else:
+            self.detached_sample = sample
+
+    @property
+    def device(self):
+        return self.problem.device
+
+    @property
+    def P(self):
+        return self.problem.P
+
+    @property
+    def Q(self):
+        return self.problem.Q
+
+    @property
+    def all_platedims(self):
+        return self.problem.all_platedims
+
+    def _elbo(self, sample, extra_log_factors, computation_strategy):
+        extra = {} if extra_log_factors is None else {k: sum_positional(v) for k, v in extra_log_factors.items()}
+        extra = tensordict2tree(self.P.plate, extra)
+        lp, *_ = logPQ_plate(
+            name=None, P=self.P.plate, Q=self.Q.plate, sample=sample,
+            inputs_params=self.problem.inputs_params(), data=self.problem.data,
+            extra_log_factors=extra, scope={}, active_platedims=[], all_platedims=self.all_platedims,
+            groupvarname2Kdim=self.groupvarname2Kdim,
+            varname2groupvarname=self.problem.Q.varname2groupvarname(),
+            sampler=self.sampler, computation_strategy=computation_strategy)
+        assert dims_of(lp) == (), "every K and plate dim should have been eliminated"
+        return lp
+
+    def elbo_vi(self, computation_strategy=checkpoint):
+        """ELBO with reparameterised gradients (requires ``problem.sample(K, reparam=True)``)."""
+        if not self.reparam:
+            raise Exception("To compute the ELBO with the right gradients for VI you must construct a "
+                            "reparameterised sample using `problem.sample(K, reparam=True)`")
+        return self._elbo(self.reparam_sample, None, computation_strategy)
+
+    def elbo_rws(self, computation_strategy=checkpoint):
+        """ELBO on the detached sample (gradients flow to parameters only, as RWS wants)."""
+        return self._elbo(self.detached_sample, None, computation_strategy)
+
+    def elbo_nograd(self, computation_strategy=checkpoint):
+        with t.no_grad():
+            return self._elbo(self.detached_sample, None, computation_strategy)
+
+    # ---- the path's backward in production use (Sample.py:208-272): posterior weights over K ----
+    def marginal_weights(self, computation_strategy=checkpoint):
+        """For each latent group, the posterior marginal over its K particles (and active plates):
+        d ELBO / d J for a zero source term J added as an extra log-factor on that group's dims."""
+        g2p = self.Q.groupvarname2platenames()
+        Js, names = [], []
+        for g, Kdim in self.groupvarname2Kdim.items():
+            ds = [Kdim, *[self.all_platedims[p] for p in g2p[g]]]
+            J = t.zeros([d.size for d in ds], device=self.device, requires_grad=True)
+            Js.append(J)
+            names.append((g, ds))
+        extra = {f"__J_{g}": J[tuple(ds)] for J, (g, ds) in zip(Js, names)}
+        L = self._elbo(self.detached_sample, extra, computation_strategy)
+        grads = t.autograd.grad(L, Js)
+        return {g: gr[tuple(ds)] for gr, (g, ds) in zip(grads, names)}

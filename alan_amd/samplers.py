@@ -1,0 +1,99 @@
+"""
+How a child group picks which parent particles to condition on when Q is not factorised
+(Sampler.py of the reference).  ``resample_scope`` re-indexes every parent from its own K dim onto
+the child's K dim; ``reduce_logQ`` averages Q's log-prob over the parent K dims (the mixture
+proposal) -- that average is a log-mean-exp and runs on the HIP engine (utils.py:224-225).
+"""
+import torch as t
+
+from .contract import logmeanexp_dims
+from .dims import Dim, dims_of
+
+
+class Sampler:
+    @classmethod
+    def resample_scope(cls, scope, active_platedims, Kdim):
+        by_K = {}
+        for name, x in scope.items():
+            Ks = [d for d in dims_of(x) if d not in set(active_platedims)]
+            assert len(Ks) <= 1, f"{name} carries several K dims: {Ks}"
+            by_K.setdefault(Ks[0] if Ks else None, {})[name] = x
+        out = {}
+        for K_var, group in by_K.items():
+            if K_var is None:
+                out.update(group)
+                continue
+            first = next(iter(group.values()))
+            for x in group.values():        # variables of one Group share dims exactly
+                assert set(dims_of(x)) == set(dims_of(first))
+            perm = cls.perm(dims=set(dims_of(first)), Kdim=K_var)
+            for name, x in group.items():
+                out[name] = x.order(K_var)[perm, ...][Kdim]
+        allowed = {Kdim, *active_platedims}
+        for x in out.values():
+            assert set(dims_of(x)) <= allowed
+        return out
+
+
+class SamplerMP(Sampler):
+    @staticmethod
+    def reduce_logQ(lq, active_platedims, Kdim):
+        """[plates, parent Ks, K] -> [plates, K]: log of the mean over parent particles."""
+        parents = tuple(d for d in dims_of(lq) if d is not Kdim and d not in set(active_platedims))
+        return logmeanexp_dims(lq, parents)
+
+
+def _like(dims, Kdim):
+    others = [d for d in dims if d is not Kdim]
+    return others, [d.size for d in others]
+
+
+class PermutationSampler(SamplerMP):
+    """Every parent particle gets exactly one child: an independent random permutation of K for each
+    element of the other dims."""
+
+    @staticmethod
+    def perm(dims, Kdim):
+        assert isinstance(dims, set) and isinstance(Kdim, Dim)
+        others, sizes = _like(dims, Kdim)
+        keys = t.rand(Kdim.size, *sizes, device=_device())
+        idx = keys.argsort(0)
+        return idx[(slice(None), *others)] if others else idx
+
+
+class CategoricalSampler(SamplerMP):
+    """Each child picks a parent particle uniformly at random (with replacement)."""
+
+    @staticmethod
+    def perm(dims, Kdim):
+        assert isinstance(dims, set) and isinstance(Kdim, Dim)
+        others, sizes = _like(dims, Kdim)
+        idx = t.randint(0, Kdim.size, (Kdim.size, *sizes), device=_device())
+        return idx[(slice(None), *others)] if others else idx
+
+
+class IndependentSampler(Sampler):
+    @staticmethod
+    def perm(dims, Kdim):
+        return t.arange(Kdim.size, device=_device())
+
+
+_DEVICE = [t.device("cpu")]
+
+
+def _device():
+    return _DEVICE[0]
+
+
+class on_device:
+    """Context manager: samplers draw their index tensors on this device."""
+
+    def __init__(self, device):
+        self.device = t.device(device)
+
+    def __enter__(self):
+        self.prev = _DEVICE[0]
+        _DEVICE[0] = self.device
+
+    def __exit__(self, *a):
+        _DEVICE[0] = self.prev

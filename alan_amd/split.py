@@ -1,0 +1,132 @@
+"""
+Computation strategies (Split.py of the reference): ``no_checkpoint``, ``checkpoint`` and
+``Split(platename, split_size)``.
+
+In the reference Split is a sequential loop over chunks of one plate on one device
+(logpq.py:43-57).  Here the same chunking is also the multi-GPU shard axis: with
+``Split(..., shard=True)`` under an initialised ``torch.distributed`` process group each rank
+evaluates only its own chunks and the per-rank partial log-marginals -- a [K_parents...] tensor --
+are combined with ONE ``all_reduce(SUM)`` (RCCL over xGMI on MI355X).  It is a plain sum, not a
+log-sum-exp, because independent plate elements multiply (logpq.py:149-153).
+"""
+import warnings
+
+import torch as t
+import torch.distributed as dist
+
+from .dims import Dim, dims_of, is_tensor
+
+
+class NoSplit:
+    platename = None
+    shard = False
+
+    def split_args(self, name, sample, inputs_params, extra_log_factors, data, all_platedims):
+        return [dict(sample=sample, inputs_params=inputs_params, extra_log_factors=extra_log_factors,
+                     data=data, all_platedims=all_platedims)]
+
+
+class NoCheckpoint(NoSplit):
+    pass
+
+
+class Checkpoint(NoSplit):
+    pass
+
+
+no_checkpoint = NoCheckpoint()
+checkpoint = Checkpoint()
+
+
+def chunk_sizes(orig_size, split_size):
+    """Chunk sizes along the plate (Split.py:84-95): full chunks, then the remainder; a remainder of 1
+    borrows one element from the previous chunk when split_size > 2."""
+    assert orig_size > split_size
+    sizes = (orig_size // split_size) * [split_size]
+    rem = orig_size % split_size
+    if rem:
+        sizes.append(rem)
+    if split_size > 2 and sizes[-1] == 1:
+        sizes[-2] -= 1
+        sizes[-1] += 1
+    if sizes[-1] == 1:
+        warnings.warn("Split produced a chunk of size 1")
+    return sizes
+
+
+class Split:
+    """``computation_strategy=Split(platename, split_size)``; ``shard=True`` distributes the chunks over
+    the ranks of ``group`` (default: the world group) -- see module docstring."""
+
+    def __init__(self, platename, split_size, shard=False, group=None):
+        assert isinstance(platename, str)
+        assert isinstance(split_size, int)
+        self.platename, self.split_size = platename, split_size
+        self.shard, self.group = bool(shard), group
+
+    def split_args(self, name, sample, inputs_params, extra_log_factors, data, all_platedims):
+        whole = dict(sample=sample, inputs_params=inputs_params, extra_log_factors=extra_log_factors,
+                     data=data, all_platedims=all_platedims)
+        if name != self.platename:
+            return [whole]
+        orig = all_platedims[self.platename]
+        sizes = chunk_sizes(orig.size, self.split_size)
+        new_dims = [Dim(f"{self.platename}_split_{i}", s) for i, s in enumerate(sizes)]
+
+        def split_tree(tree):
+            outs = [{} for _ in sizes]
+            for k, v in tree.items():
+                if isinstance(v, dict):
+                    for o, sub in zip(outs, split_tree(v)):
+                        o[k] = sub
+                else:
+                    assert is_tensor(v)
+                    assert orig in set(dims_of(v)), f"{k} lacks the plate dim {orig} being split"
+                    others = [d for d in dims_of(v) if d is not orig]
+                    pos = v.order(orig, *others)
+                    for o, piece, nd in zip(outs, pos.split(sizes, 0), new_dims):
+                        o[k] = piece[(nd, *others)]
+            return outs
+
+        trees = {key: split_tree(whole[key]) for key in ("sample", "inputs_params", "extra_log_factors", "data")}
+        return [dict(sample=trees["sample"][i], inputs_params=trees["inputs_params"][i],
+                     extra_log_factors=trees["extra_log_factors"][i], data=trees["data"][i],
+                     all_platedims={**all_platedims, self.platename: new_dims[i]})
+                for i in range(len(sizes))]
+
+    # ---- multi-GPU ------------------------------------------------------------------------
+    def sharded(self):
+        return self.shard and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def my_chunks(self, n_chunks):
+        """Contiguous block of chunk indices for this rank (balanced to within one chunk)."""
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if n_chunks < world:
+            raise Exception(f"Split produces {n_chunks} chunks but there are {world} ranks; choose a smaller "
+                            "split_size so that every rank gets at least one chunk")
+        base, extra = divmod(n_chunks, world)
+        start = rank * base + min(rank, extra)
+        return range(start, start + base + (1 if rank < extra else 0))
+
+
+class _AllReduceSum(t.autograd.Function):
+    """Sum of per-rank partial log-marginals.  Everything downstream is replicated on every rank, so
+    the gradient wrt this rank's partial is the incoming gradient, unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        x = x.contiguous().clone()
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def all_reduce_sum(lp, group=None):
+    """all_reduce(SUM) of a torchdim tensor; dims are matched across ranks by name."""
+    ds = sorted(dims_of(lp), key=str)
+    pos = lp.order(*ds) if ds else lp
+    out = _AllReduceSum.apply(pos, group)
+    return out[tuple(ds)] if ds else out
