@@ -7,7 +7,7 @@ log-probs work) but the QEM optimiser itself is out of scope of this build.
 import torch as t
 import torch.nn as nn
 
-from .dims import Dim, dims_of, named_to_dim, dim_to_named
+from .dims import PT, Dim, dims_of, named_to_dim, dim_to_named
 from .dist import Dist
 from .model import Plate, check_name, flatten_tree, tensordict2tree
 from .samplers import PermutationSampler, Sampler, IndependentSampler, on_device
@@ -37,6 +37,31 @@ class _NamedStore(nn.Module):
 
 def _plate_names(x):
     return [n for n in x.names if n is not None]
+
+
+def named_to_pt(names, raw, platedims):
+    """(names, unnamed tensor) -> PT with the plate dims leading (a view; permutes only if needed)."""
+    lead = [i for i, n in enumerate(names) if n is not None]
+    rest = [i for i, n in enumerate(names) if n is None]
+    if lead + rest != list(range(len(names))):
+        raw = raw.permute(*lead, *rest)
+    return PT(raw, [platedims[names[i]] for i in lead])
+
+
+def pt_tree(plate, flat, platenames_of):
+    """Place each PT at the deepest plate it carries (cf. model.tensordict2tree, without torchdim)."""
+    from .model import empty_tree
+    root = empty_tree(plate)
+    for name, p in flat.items():
+        mine = {platenames_of[i] for i in p.ids if i in platenames_of}
+        branch = root
+        while mine:
+            nxt = [q for q in mine if isinstance(branch.get(q), dict)]
+            assert len(nxt) == 1, f"{name}: plates {mine} do not form a nested path"
+            branch = branch[nxt[0]]
+            mine.remove(nxt[0])
+        branch[name] = p
+    return root
 
 
 def expand_named(x, names, all_platesizes):
@@ -130,6 +155,18 @@ class BoundPlate(nn.Module):
         flat = {k: named_to_dim(v, all_platedims) for k, v in self.inputs_params_flat_named().items()}
         return tensordict2tree(self.plate, flat)
 
+    def inputs_params_flat_pt(self, all_platedims):
+        """Inputs and (transformed) parameters as PTs -- no named-tensor or torchdim ops on this path."""
+        out = {}
+        for store, trans in ((self._inputs, None), (self._opt_params, self.opt_paramname2trans),
+                             (self._qem_params, None)):
+            for k in store._keys:
+                raw = getattr(store, f"t_{k}")
+                if trans is not None:
+                    raw = trans[k](raw)
+                out[k] = named_to_pt(store._names[k], raw, all_platedims)
+        return out
+
     def groupvarname2platenames(self):
         return self.plate.groupvarname2platenames()
 
@@ -221,6 +258,20 @@ class Problem(nn.Module):
         flat = {**self.P.inputs_params_flat_named(), **self.Q.inputs_params_flat_named()}
         flat = {k: named_to_dim(v, self.all_platedims) for k, v in flat.items()}
         return tensordict2tree(self.P.plate, flat)
+
+    # ---- PT views used by the ELBO path (Sample._elbo) -------------------------------------
+    def _platenames_of(self):
+        return {id(d): n for n, d in self.all_platedims.items()}
+
+    def inputs_params_pt(self):
+        flat = {**self.P.inputs_params_flat_pt(self.all_platedims),
+                **self.Q.inputs_params_flat_pt(self.all_platedims)}
+        return pt_tree(self.P.plate, flat, self._platenames_of())
+
+    def data_pt(self):
+        flat = {k: named_to_pt(self._data._names[k], getattr(self._data, f"t_{k}"), self.all_platedims)
+                for k in self._data._keys}
+        return pt_tree(self.P.plate, flat, self._platenames_of())
 
     def sample(self, K, reparam=True, sampler=PermutationSampler):
         """K samples of every latent from Q, each latent group on its own K dim (Problem.py:71-97)."""

@@ -68,7 +68,13 @@ struct RowsPlan {
     bool rot = false, vec2 = false;
 };
 RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype);
+// Optional hipEvent pair recorded around the dominant kernel of a call (alan_reduce_desc_t.ev_*).
+struct EvPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+    void begin(hipStream_t s) const { if (start) (void)hipEventRecord(start, s); }
+    void end(hipStream_t s) const { if (stop) (void)hipEventRecord(stop, s); }
+};
 int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
-                size_t workspace_bytes, hipStream_t stream);
+                size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 
 }  // namespace alan

@@ -204,18 +204,22 @@ static void plate_workspace_layout(const alan_reduce_desc_t &d, alan_tensor_t &v
 }
 
 static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_mask, int mode,
-                      const alan_tensor_t &out, double add_const, hipStream_t stream) {
+                      const alan_tensor_t &out, double add_const, hipStream_t stream,
+                      const EvPair &ev = EvPair()) {
     Canon c;
     int rc = canonicalise(d, keep_mask, red_mask, out, c);
     if (rc != ALAN_OK) return rc;
     const int compute = out.dtype;
     const RowsPlan rp = plan_rows(c, mode, compute);
-    if (rp.ok) return launch_rows(c, rp, mode, add_const, nullptr, 0, stream);
+    if (rp.ok) return launch_rows(c, rp, mode, add_const, nullptr, 0, stream, ev);
     GroupDesc gd;
     GroupLaunch gl;
     rc = plan_group(c, out.dtype, add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
-    return launch_group(gd, gl, mode, compute, stream);
+    ev.begin(stream);
+    rc = launch_group(gd, gl, mode, compute, stream);
+    ev.end(stream);
+    return rc;
 }
 
 // The fused plan for "log-sum-exp over REDUCE then sum over PLATE", if the rows kernel can take it.
@@ -270,20 +274,23 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     uint32_t keep, red, plate;
     int rc = classify(*d, keep, red, plate);
     if (rc != ALAN_OK) return rc;
+    EvPair ev;
+    ev.start = (hipEvent_t)d->ev_start;
+    ev.stop = (hipEvent_t)d->ev_stop;
 
     if (d->mode == ALAN_MODE_LSE && red == 0) {
         // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,
         // followed by the plate sum if any.
-        return run_single(*d, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
+        return run_single(*d, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream, ev);
     }
-    if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream);
+    if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream, ev);
 
     // ---- log-sum-exp over REDUCE, then sum over PLATE (logpq.py:128,149)
     {
         Canon c;
         RowsPlan rp;
         if (plan_fused_plate(*d, keep, red, plate, c, rp))
-            return launch_rows(c, rp, ALAN_MODE_LSE, d->add_const, workspace, workspace_bytes, stream);
+            return launch_rows(c, rp, ALAN_MODE_LSE, d->add_const, workspace, workspace_bytes, stream, ev);
     }
     alan_tensor_t v;
     if (d->lse_out.data) {
@@ -297,7 +304,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         v.data = workspace;
     }
     v.scale = 1.f;
-    rc = run_single(*d, keep | plate, red, ALAN_MODE_LSE, v, 0.0, stream);
+    rc = run_single(*d, keep | plate, red, ALAN_MODE_LSE, v, 0.0, stream, ev);
     if (rc != ALAN_OK) return rc;
 
     alan_reduce_desc_t s2;

@@ -294,7 +294,7 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
 }
 
 int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
-                size_t workspace_bytes, hipStream_t stream) {
+                size_t workspace_bytes, hipStream_t stream, const EvPair &ev) {
     if (!rp.ok) return ALAN_ERR_UNSUPPORTED;
     const bool fused = rp.P > 1 || (c.nk > 0 && c.kplate[0]);
     const bool two_stage = fused && rp.n_chunks > 1;
@@ -337,6 +337,7 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);
+    ev.begin(stream);
 #define ALAN_ROWS4(MODE, G, V, R, GN) \
     hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN>), grid, block, rp.lds_bytes, stream, d)
 #define ALAN_ROWS3(MODE, G, V, R)                       \
@@ -358,6 +359,7 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
         else { ALAN_ROWS2(ALAN_MODE_SUM, false, false) }
     }
 #undef ALAN_ROWS4
+    ev.end(stream);
 #undef ALAN_ROWS2
 #undef ALAN_ROWS3
     if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;

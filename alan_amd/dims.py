@@ -101,3 +101,84 @@ def sum_positional(x):
     if is_tensor(x) and x.ndim > 0:
         return x.sum(tuple(range(x.ndim)))
     return x
+
+
+# ---------------------------------------------------------------------------------------------
+# PT: the host stack's internal tensor representation.  functorch.dim in torch 2.10 is implemented
+# in Python (every op, and even hash(Dim), costs tens of microseconds), so the plate recursion does
+# NOT compute on torchdim tensors: it carries (plain positional tensor, leading Dim objects) pairs and
+# only wraps into torchdim when calling a user's model lambda.
+class PT:
+    __slots__ = ("x", "dims", "ids")
+
+    def __init__(self, x, dims=()):
+        self.x = x
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @staticmethod
+    def of(v):
+        """torchdim tensor / plain tensor / number -> PT"""
+        if isinstance(v, PT):
+            return v
+        if is_dimtensor(v):
+            ds = tuple(v.dims)
+            return PT(v.order(*ds), ds)
+        if not isinstance(v, t.Tensor):
+            v = t.as_tensor(v)
+        return PT(v, ())
+
+    def dim(self):
+        """-> torchdim tensor (or the plain tensor when there are no first-class dims)"""
+        return self.x[self.dims] if self.dims else self.x
+
+    @property
+    def n_pos(self):
+        return self.x.ndim - len(self.dims)
+
+    def size_of(self, dim_id):
+        return self.x.shape[self.ids.index(dim_id)]
+
+    def has(self, d):
+        return id(d) in self.ids
+
+    def detach(self):
+        return PT(self.x.detach(), self.dims)
+
+
+def pt_order(pts, lead=(), last=()):
+    """Ordered union of the dims of several PTs: ``lead`` dims first, ``last`` dims last, others between.
+    Returns (dims, ids)."""
+    seen = {}
+    for p in pts:
+        for d, i in zip(p.dims, p.ids):
+            if i not in seen:
+                seen[i] = d
+    rank = {id(d): k for k, d in enumerate(lead)}
+    mid = len(rank)
+    for k, d in enumerate(last):
+        rank[id(d)] = mid + 1 + k
+    ids = sorted(seen, key=lambda i: rank.get(i, mid))
+    return tuple(seen[i] for i in ids), tuple(ids)
+
+
+def pt_align(p, ids, pad=0):
+    """Plain tensor view of ``p`` laid out [ids (size 1 where absent)..., 1*pad, own positional...]."""
+    x = p.x
+    nd = len(p.dims)
+    if nd:
+        pos = {i: k for k, i in enumerate(p.ids)}
+        perm = [pos[i] for i in ids if i in pos]
+        if perm != list(range(nd)):
+            x = x.permute(*perm, *range(nd, x.ndim))
+        idx = tuple(slice(None) if i in pos else None for i in ids) + (None,) * pad
+    else:
+        idx = (None,) * (len(ids) + pad)
+    return x[idx] if idx else x
+
+
+def pt_add(a, b, alpha=1.0):
+    """a + alpha*b with broadcasting over first-class dims (no positional dims allowed)."""
+    dims, ids = pt_order((a, b))
+    xa, xb = pt_align(a, ids), pt_align(b, ids)
+    return PT(xa + xb if alpha == 1.0 else t.add(xa, xb, alpha=alpha), dims)

@@ -14,7 +14,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import Dim, dims_of, is_dimtensor, is_tensor, sum_positional, union_dims
+from .dims import PT, Dim, dims_of, is_dimtensor, is_tensor, pt_align, pt_order, sum_positional, union_dims
 
 Number = (int, float)
 
@@ -39,76 +39,71 @@ def _arg_is_discrete(dist_cls, name):
     return False
 
 
-def _positional(x, dim_order, lead_pad):
-    """torchdim/plain tensor -> plain tensor laid out [dim_order (1 where absent)..., 1*lead_pad, own positional...]."""
-    own = set(dims_of(x))
-    present = [d for d in dim_order if d in own]
-    assert len(present) == len(own), "tensor carries a dim outside the requested order"
-    pos = x.order(*present) if present else x
-    idx = tuple(slice(None) if d in own else None for d in dim_order) + (None,) * lead_pad
-    return pos[idx] if idx else pos
+VALIDATE_ARGS = False
+"""torch.distributions argument validation.  Off by default: on a GPU every validated construction
+costs a device synchronisation (``constraint.check(value).all()``), which dominates small ELBO evals.
+Set ``alan_amd.dist.VALIDATE_ARGS = True`` to get the reference's behaviour (exceptions on invalid
+parameters / samples)."""
 
 
 class TorchDimDist:
-    """A torch.distributions distribution whose parameters are torchdim tensors."""
+    """A torch.distributions distribution whose parameters are torchdim tensors (or PTs)."""
 
     def __init__(self, dist, **kwargs):
         self.dist = dist
-        self.kwargs = {k: (v if is_tensor(v) else t.as_tensor(v)) for k, v in kwargs.items()}
-        self.all_arg_dims = union_dims(self.kwargs.values())
+        self.kwargs = {k: PT.of(v) for k, v in kwargs.items()}
+        self.all_arg_dims, self.all_arg_ids = pt_order(self.kwargs.values())
         self.sample_event_ndim = dist.support.event_dim
         self.arg_event_ndim = {k: _arg_event_ndim(dist, k) for k in self.kwargs}
-        self.arg_batch_ndim = {k: v.ndim - self.arg_event_ndim[k] for k, v in self.kwargs.items()}
+        self.arg_batch_ndim = {k: v.n_pos - self.arg_event_ndim[k] for k, v in self.kwargs.items()}
         self.sample_batch_ndim = max(self.arg_batch_ndim.values())
 
-    def _build(self, dim_order, n_sample_pad=0):
+    def _build(self, ids, n_sample_pad=0):
         """Instantiate the torch distribution with every parameter laid out
-        [dim_order..., 1*n_sample_pad, batch (left-padded)..., event...]."""
+        [ids (1 where absent)..., 1*n_sample_pad, batch (left-padded)..., event...]."""
         args = {}
         for k, v in self.kwargs.items():
             pad = n_sample_pad + self.sample_batch_ndim - self.arg_batch_ndim[k]
-            args[k] = _positional(v, dim_order, pad)
-        return self.dist(**args)
+            args[k] = pt_align(v, ids, pad)
+        return self.dist(**args, validate_args=VALIDATE_ARGS)
 
     def sample(self, reparam, sample_dims, sample_shape=()):
         """Sample with exactly the dims ``sample_dims`` (a superset of the parameters' dims) and the
-        positional shape [*sample_shape, *batch, *event]."""
+        positional shape [*sample_shape, *batch, *event].  Returns a torchdim tensor."""
         sample_dims = list(sample_dims)
-        if len(set(sample_dims)) != len(sample_dims):
+        ids = [id(d) for d in sample_dims]
+        if len(set(ids)) != len(ids):
             raise Exception("Non-unique elements in sample_dims")
-        assert set(self.all_arg_dims).issubset(sample_dims)
+        assert set(self.all_arg_ids).issubset(ids)
         if reparam and not self.dist.has_rsample:
             raise Exception(f"Trying to do reparameterised sampling of {self.dist}, which is not implemented "
                             "by PyTorch (likely because it is a distribution over discrete random variables).")
-        extra = [d for d in sample_dims if d not in set(self.all_arg_dims)]
-        d = self._build(self.all_arg_dims)
+        have = set(self.all_arg_ids)
+        extra = [d for d in sample_dims if id(d) not in have]
+        d = self._build(self.all_arg_ids)
         draw = d.rsample if reparam else d.sample
         x = draw(sample_shape=t.Size([*sample_shape, *[e.size for e in extra]]))
         idx = (slice(None),) * len(sample_shape) + (*extra, *self.all_arg_dims)
         return x[idx] if (extra or self.all_arg_dims) else x
 
-    def log_prob(self, x, dim_order=None):
-        """log p(x) as a torchdim tensor over (x's dims) U (parameter dims); positional sample/batch
-        dims are summed out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of
-        the result: ``lead`` dims outermost, ``last`` dims innermost, any others in between."""
-        assert is_tensor(x)
-        every = list(union_dims([x, *self.kwargs.values()]))
-        if dim_order is not None:
-            lead, last = dim_order
-            rank = {d: i for i, d in enumerate(lead)}
-            rank.update({d: len(lead) + 1 + i for i, d in enumerate(last)})
-            every.sort(key=lambda d: rank.get(d, len(lead)))    # other dims sit between lead and last
-        n_sample = x.ndim - self.sample_batch_ndim - self.sample_event_ndim
+    def log_prob_pt(self, x, dim_order=None):
+        """log p(x) as a PT over (x's dims) U (parameter dims); positional sample/batch dims are summed
+        out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of the result:
+        ``lead`` dims outermost, ``last`` dims innermost, any others in between."""
+        x = PT.of(x)
+        lead, last = dim_order if dim_order is not None else ((), ())
+        dims, ids = pt_order((x, *self.kwargs.values()), lead, last)
+        n_sample = x.n_pos - self.sample_batch_ndim - self.sample_event_ndim
         assert n_sample >= 0
-        d = self._build(every, n_sample)
-        own = set(dims_of(x))
-        pos = x.order(*[dd for dd in every if dd in own]) if own else x
-        pos = pos[tuple(slice(None) if dd in own else None for dd in every)] if every else pos
-        lp = d.log_prob(pos)
-        extra = lp.ndim - len(every)
-        if extra > 0:
-            lp = lp.sum(tuple(range(len(every), lp.ndim)))
-        return lp[tuple(every)] if every else lp
+        d = self._build(ids, n_sample)
+        lp = d.log_prob(pt_align(x, ids))
+        if lp.ndim > len(ids):
+            lp = lp.sum(tuple(range(len(ids), lp.ndim)))
+        return PT(lp, dims)
+
+    def log_prob(self, x, dim_order=None):
+        assert is_tensor(x)
+        return self.log_prob_pt(x, dim_order).dim()
 
 
 # --------------------------------------------------------------------------------------------
@@ -212,14 +207,16 @@ class Dist(nn.Module):
     def device(self):
         return self._device_tensor.device
 
-    def tdd(self, scope):
+    def tdd(self, scope, dimcache=None):
+        """Bind the distribution's arguments from ``scope`` (values: PT or torchdim tensors).  Model
+        lambdas receive torchdim tensors; ``dimcache`` memoises the PT -> torchdim wrapping per eval."""
         kw = {}
         for a in self._consts:
-            kw[a] = getattr(self, f"_const_{a}")
+            kw[a] = PT(getattr(self, f"_const_{a}"), ())
         for a, name in self._names.items():
             kw[a] = scope[name]
         for a, (fn, argnames) in self._funcs.items():
-            val = fn(*[scope[n] for n in argnames])
+            val = fn(*[_as_dim(scope[n], n, dimcache) for n in argnames])
             if not is_tensor(val):
                 raise Exception("Lambda on a distribution returned a non-Tensor")
             kw[a] = val
@@ -228,8 +225,20 @@ class Dist(nn.Module):
     def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm=None):
         return self.tdd(scope).sample(reparam, [*active_platedims, K_dim], self.sample_shape)
 
-    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None):
-        return self.tdd(scope).log_prob(x, dim_order=dim_order), None
+    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None):
+        """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""
+        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order), None
+
+
+def _as_dim(v, name, cache):
+    if not isinstance(v, PT):
+        return v
+    if cache is None:
+        return v.dim()
+    key = (name, id(v))
+    if key not in cache:
+        cache[key] = v.dim()
+    return cache[key]
 
 
 class _DistSpec:

@@ -70,7 +70,11 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
     if lse_out is not None:
         N.fill_tensor(desc.lse_out, lse_out[0], _strides(lse_out[0], list(lse_out[1]), space))
     desc.add_const = add_const
-    N.run_reduce(desc, device)
+    # algorithmic bytes of this call: every distinct input element once + the output once
+    algo = sum(x.numel() * x.element_size() for x, _ in factors) + out.numel() * out.element_size()
+    if weight is not None:
+        algo += weight[0].numel() * weight[0].element_size()
+    N.run_reduce(desc, device, algo)
 
 
 def _result_dtype(tensors):
@@ -151,11 +155,20 @@ class _Tokens:
     def __init__(self):
         self.fwd, self.back = {}, []
 
+    @staticmethod
+    def _k(key):
+        # hash(Dim) goes through torchdim's Python dispatcher (~40 us); identity is what we mean anyway
+        return key if isinstance(key, (str, int, tuple)) else id(key)
+
     def __call__(self, key):
-        if key not in self.fwd:
-            self.fwd[key] = len(self.back)
+        k = self._k(key)
+        if k not in self.fwd:
+            self.fwd[k] = len(self.back)
             self.back.append(key)
-        return self.fwd[key]
+        return self.fwd[k]
+
+    def __contains__(self, key):
+        return self._k(key) in self.fwd
 
     def many(self, keys):
         return tuple(self(k) for k in keys)
@@ -170,7 +183,7 @@ def reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     tok = _Tokens()
     factors = [(x, tok.many(d)) for x, d in factors]
     for d in (*reduce, *plate):
-        if d not in tok.fwd:
+        if d not in tok:
             raise Exception(f"dim {d} to reduce is not on any factor")
     out, dims = _reduce_factors(factors, tok.many(reduce), tok.many(plate), add_const)
     return out, tok.keys(dims)
@@ -257,7 +270,7 @@ def contract(factors, Ks, plate=()):
     factors = [(x, tok.many(d)) for x, d in factors]
     sizes = _space(factors)
     for k in (*Ks, *plate):
-        if k not in tok.fwd:
+        if k not in tok:
             raise Exception(f"dim {k} to sum is not on any factor")
     Ks = tok.many(Ks)
     plate = tok.many(plate)

@@ -51,6 +51,8 @@ class ReduceDesc(C.Structure):
         ("out", Tensor),
         ("lse_out", Tensor),
         ("add_const", C.c_double),
+        ("ev_start", C.c_void_p),
+        ("ev_stop", C.c_void_p),
     ]
 
 
@@ -118,8 +120,13 @@ def current_stream(device):
     return t.cuda.current_stream(device).cuda_stream
 
 
-def run_reduce(desc, device):
+_TIMER = [None]     # set by profiling.KernelTimer
+
+
+def run_reduce(desc, device, algo_bytes=0):
     L = lib()
+    if _TIMER[0] is not None:
+        _TIMER[0].attach(desc, algo_bytes)
     nbytes = L.alan_reduce_workspace_bytes(C.byref(desc))
     ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
     rc = L.alan_reduce(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,

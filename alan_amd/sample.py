@@ -5,7 +5,7 @@
 """
 import torch as t
 
-from .dims import dims_of, is_tensor, sum_positional
+from .dims import PT, dims_of, is_tensor, sum_positional
 from .logpq import logPQ_plate
 from .model import tensordict2tree
 from .split import Split, checkpoint, no_checkpoint
@@ -13,6 +13,10 @@ from .split import Split, checkpoint, no_checkpoint
 
 def _detach_tree(tree):
     return {k: (_detach_tree(v) if isinstance(v, dict) else v.detach()) for k, v in tree.items()}
+
+
+def _pt_tree(tree):
+    return {k: (_pt_tree(v) if isinstance(v, dict) else PT.of(v)) for k, v in tree.items()}
 
 
 class Sample:
@@ -26,6 +30,14 @@ class Sample:
             self.detached_sample = _detach_tree(sample)
         else:
             self.detached_sample = sample
+        self._pt_cache = {}
+
+    def _as_pt(self, tree):
+        """torchdim sample tree -> PT tree, converted once per Sample (the trees are immutable)."""
+        key = id(tree)
+        if key not in self._pt_cache:
+            self._pt_cache[key] = _pt_tree(tree)
+        return self._pt_cache[key]
 
     @property
     def device(self):
@@ -44,17 +56,29 @@ class Sample:
         return self.problem.all_platedims
 
     def _elbo(self, sample, extra_log_factors, computation_strategy):
-        extra = {} if extra_log_factors is None else {k: sum_positional(v) for k, v in extra_log_factors.items()}
-        extra = tensordict2tree(self.P.plate, extra)
+        problem = self.problem
+        extra = {}
+        if extra_log_factors:
+            flat = {k: PT.of(sum_positional(v)) for k, v in extra_log_factors.items()}
+            from .bound import pt_tree
+            extra = pt_tree(self.P.plate, flat, problem._platenames_of())
+        else:
+            from .model import empty_tree
+            extra = empty_tree(self.P.plate)
         lp, *_ = logPQ_plate(
-            name=None, P=self.P.plate, Q=self.Q.plate, sample=sample,
-            inputs_params=self.problem.inputs_params(), data=self.problem.data,
+            name=None, P=self.P.plate, Q=self.Q.plate, sample=self._as_pt(sample),
+            inputs_params=problem.inputs_params_pt(), data=problem.data_pt(),
             extra_log_factors=extra, scope={}, active_platedims=[], all_platedims=self.all_platedims,
             groupvarname2Kdim=self.groupvarname2Kdim,
-            varname2groupvarname=self.problem.Q.varname2groupvarname(),
-            sampler=self.sampler, computation_strategy=computation_strategy)
-        assert dims_of(lp) == (), "every K and plate dim should have been eliminated"
-        return lp
+            varname2groupvarname=self._v2g(),
+            sampler=self.sampler, computation_strategy=computation_strategy, dimcache={})
+        assert lp.dims == (), "every K and plate dim should have been eliminated"
+        return lp.x
+
+    def _v2g(self):
+        if not hasattr(self, "_v2g_cache"):
+            self._v2g_cache = self.problem.Q.varname2groupvarname()
+        return self._v2g_cache
 
     def elbo_vi(self, computation_strategy=checkpoint):
         """ELBO with reparameterised gradients (requires ``problem.sample(K, reparam=True)``)."""

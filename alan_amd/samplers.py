@@ -4,10 +4,13 @@ How a child group picks which parent particles to condition on when Q is not fac
 the child's K dim; ``reduce_logQ`` averages Q's log-prob over the parent K dims (the mixture
 proposal) -- that average is a log-mean-exp and runs on the HIP engine (utils.py:224-225).
 """
+import math
+
 import torch as t
 
+from . import engine as E
 from .contract import logmeanexp_dims
-from .dims import Dim, dims_of
+from .dims import PT, Dim, dims_of
 
 
 class Sampler:
@@ -38,9 +41,19 @@ class Sampler:
 class SamplerMP(Sampler):
     @staticmethod
     def reduce_logQ(lq, active_platedims, Kdim):
-        """[plates, parent Ks, K] -> [plates, K]: log of the mean over parent particles."""
-        parents = tuple(d for d in dims_of(lq) if d is not Kdim and d not in set(active_platedims))
-        return logmeanexp_dims(lq, parents)
+        """[plates, parent Ks, K] -> [plates, K]: log of the mean over parent particles
+        (Sampler.py:118-134).  Accepts / returns a PT (the plate recursion) or a torchdim tensor."""
+        if not isinstance(lq, PT):
+            parents = tuple(d for d in dims_of(lq) if d is not Kdim and d not in set(active_platedims))
+            return logmeanexp_dims(lq, parents)
+        keep = {id(Kdim), *(id(d) for d in active_platedims)}
+        parents = tuple(d for d in lq.dims if id(d) not in keep)
+        if not parents:
+            return lq
+        assert lq.n_pos == 0
+        c = -sum(math.log(lq.size_of(id(d))) for d in parents)
+        out, dims = E.reduce_factors([(lq.x, lq.dims)], reduce=parents, add_const=c)
+        return PT(out, dims)
 
 
 def _like(dims, Kdim):

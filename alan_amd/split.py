@@ -14,7 +14,7 @@ import warnings
 import torch as t
 import torch.distributed as dist
 
-from .dims import Dim, dims_of, is_tensor
+from .dims import PT, Dim, dims_of, is_tensor
 
 
 class NoSplit:
@@ -79,6 +79,11 @@ class Split:
                 if isinstance(v, dict):
                     for o, sub in zip(outs, split_tree(v)):
                         o[k] = sub
+                elif isinstance(v, PT):
+                    assert v.has(orig), f"{k} lacks the plate dim {orig} being split"
+                    ax = v.ids.index(id(orig))
+                    for o, piece, nd in zip(outs, v.x.split(sizes, ax), new_dims):
+                        o[k] = PT(piece, (*v.dims[:ax], nd, *v.dims[ax + 1:]))
                 else:
                     assert is_tensor(v)
                     assert orig in set(dims_of(v)), f"{k} lacks the plate dim {orig} being split"
@@ -125,7 +130,12 @@ class _AllReduceSum(t.autograd.Function):
 
 
 def all_reduce_sum(lp, group=None):
-    """all_reduce(SUM) of a torchdim tensor; dims are matched across ranks by name."""
+    """all_reduce(SUM) of a PT (or torchdim tensor); dims are matched across ranks by name."""
+    from .dims import pt_align
+    if isinstance(lp, PT):
+        ds = sorted(lp.dims, key=str)
+        pos = pt_align(lp, tuple(id(d) for d in ds))
+        return PT(_AllReduceSum.apply(pos, group), ds)
     ds = sorted(dims_of(lp), key=str)
     pos = lp.order(*ds) if ds else lp
     out = _AllReduceSum.apply(pos, group)

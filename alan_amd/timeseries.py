@@ -7,7 +7,7 @@ reference).  Sampling is sequential over T on the host; ``log_prob`` produces th
 import torch as t
 import torch.nn as nn
 
-from .dims import Dim, dims_of, is_tensor
+from .dims import PT, Dim, dims_of, is_tensor
 from .dist import Dist, _DistSpec
 
 
@@ -65,10 +65,13 @@ class Timeseries(nn.Module):
         stacked = t.stack(steps, 0)                      # [T, K, *other, ...event]
         return stacked[(T_dim, *order)]
 
-    def log_prob(self, sample, scope, T_dim, K_dim, dim_order=None):
-        """Returns (lp[T, K_init, K, ...], K_init): the previous state is indexed by the K dim of the
-        initial-state variable (Timeseries.py:205-245)."""
+    def log_prob(self, sample, scope, T_dim, K_dim, dim_order=None, dimcache=None):
+        """Returns (lp[T, K_init, K, ...] as a PT, K_init): the previous state is indexed by the K dim of
+        the initial-state variable (Timeseries.py:205-245)."""
         assert isinstance(T_dim, Dim) and isinstance(K_dim, Dim)
+        if isinstance(sample, PT):
+            sample = sample.dim()
+        scope = {k: (v.dim() if (isinstance(v, PT) and k == self.init) else v) for k, v in scope.items()}
         sdims = set(dims_of(sample))
         assert K_dim in sdims and T_dim in sdims
         init = scope[self.init]
@@ -83,12 +86,12 @@ class Timeseries(nn.Module):
         prev = t.cat([init_pos.unsqueeze(len(lead)), shifted_pos], len(lead))
         prev = prev[(*lead, T_dim)]
         scope = dict(scope)
-        scope["prev"] = prev
+        scope["prev"] = PT.of(prev)
+        scope[self.init] = PT.of(init)
         order = None
         if dim_order is not None:
             lead, last = dim_order
             order = ([d for d in lead if d not in {Kinit, K_dim}], [Kinit, K_dim])
-        lp, _ = self.trans.log_prob(sample, scope, dim_order=order)
-        ldims = set(dims_of(lp))
-        assert Kinit in ldims and K_dim in ldims and T_dim in ldims
+        lp, _ = self.trans.log_prob(PT.of(sample), scope, dim_order=order, dimcache=dimcache)
+        assert lp.has(Kinit) and lp.has(K_dim) and lp.has(T_dim)
         return lp, Kinit

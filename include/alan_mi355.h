@@ -78,6 +78,9 @@ typedef struct {
     alan_tensor_t lse_out;                /* optional (data may be NULL). With PLATE dims: receives the per-(KEEP,PLATE)
                                              log-sum-exp values (the backward's saved tensor); strides over KEEP+PLATE */
     double add_const;                     /* added to every output element */
+    void *ev_start, *ev_stop;             /* optional hipEvent_t pair (NULL = off): recorded on `stream` immediately
+                                             before / after the DOMINANT kernel of this call (the one that streams the
+                                             largest factor), so a caller can time that kernel alone (bench.py) */
 } alan_reduce_desc_t;
 
 /* Bytes of scratch alan_reduce() needs for this descriptor (0 is possible). */

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # alan_tensor_t: ptr(8) + int32 + float + 8*int64 ; alan_reduce_desc_t per the header
     assert ctypes.sizeof(N.Tensor) == 8 + 4 + 4 + 8 * N.MAX_DIMS
-    expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8
+    expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8 + 16
     assert ctypes.sizeof(N.ReduceDesc) == expect
 
 
