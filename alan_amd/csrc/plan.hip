@@ -39,8 +39,15 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
     c.dominant = dom;
 
     // order dims by the dominant factor's stride (outermost first); dims the dominant factor lacks
-    // are ordered by the largest stride any other tensor gives them and go outermost.
+    // are ordered by the largest stride any other tensor gives them and go outermost.  When the
+    // OUTPUT is the biggest tensor of the call (a producer: small inputs broadcast into a big
+    // result) the keep dims follow the output's layout instead, so that the stores coalesce.
+    double out_ext = 1;
+    for (int i = 0; i < d.ndim; ++i)
+        if ((keep_mask >> i) & 1) out_ext *= (double)d.size[i];
+    const bool out_dominates = out_ext > best;
     auto sort_key = [&](int i) -> int64_t {
+        if (out_dominates && ((keep_mask >> i) & 1) && out.stride[i] != 0) return iabs64(out.stride[i]);
         int64_t s = iabs64(d.factor[dom].stride[i]);
         if (s != 0) return s;
         int64_t alt = 0;
@@ -242,8 +249,10 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
         }
     }
     if (plate && d.mode != ALAN_MODE_LSE) return ALAN_ERR_BAD_DESC;
-    if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM && d.mode != ALAN_MODE_WEXPSUM)
+    if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM && d.mode != ALAN_MODE_WEXPSUM &&
+        d.mode != ALAN_MODE_NORMAL)
         return ALAN_ERR_BAD_DESC;
+    if (d.mode == ALAN_MODE_NORMAL && d.n_factors != 3) return ALAN_ERR_BAD_DESC;
     return ALAN_OK;
 }
 

@@ -51,17 +51,13 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
     // ---- stream over the reduce index
     T m = Num<T>::ninf(), s = T(0);
     for (uint32_t r = gl; r < d.n_red; r += G) {
-        T x = T(0);
-        T w = T(1);
+        int64_t off[MAXF];
+        int64_t woff = wbase;
         if (d.nr == 1) {
 #pragma unroll
-            for (int f = 0; f < MAXF; ++f)
-                if (f < d.nf)
-                    x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, base[f] + (int64_t)r * d.f[f].rs[0]);
-            if (MODE == ALAN_MODE_WEXPSUM) w = load_as<T>(d.w.p, d.w.dtype, wbase + (int64_t)r * d.w.rs[0]);
+            for (int f = 0; f < MAXF; ++f) off[f] = base[f] + (int64_t)r * d.f[f < d.nf ? f : 0].rs[0];
+            if (MODE == ALAN_MODE_WEXPSUM) woff += (int64_t)r * d.w.rs[0];
         } else {
-            int64_t off[MAXF];
-            int64_t woff = wbase;
 #pragma unroll
             for (int f = 0; f < MAXF; ++f) off[f] = base[f];
             uint32_t rr = r;
@@ -74,17 +70,28 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
                     if (f < d.nf) off[f] += idx * d.f[f].rs[k];
                 if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.w.rs[k];
             }
-#pragma unroll
-            for (int f = 0; f < MAXF; ++f)
-                if (f < d.nf) x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
-            if (MODE == ALAN_MODE_WEXPSUM) w = load_as<T>(d.w.p, d.w.dtype, woff);
         }
-        if (MODE == ALAN_MODE_LSE)
+        if (MODE == ALAN_MODE_NORMAL) {
+            // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))
+            const T v = load_as<T>(d.f[0].p, d.f[0].dtype, off[0]);
+            const T loc = load_as<T>(d.f[1].p, d.f[1].dtype, off[1]);
+            const T sc = load_as<T>(d.f[2].p, d.f[2].dtype, off[2]);
+            const T z = v - loc;
+            s += -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+            continue;
+        }
+        T x = T(0);
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (f < d.nf) x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
+        if (MODE == ALAN_MODE_LSE) {
             lse_push(m, s, x);
-        else if (MODE == ALAN_MODE_SUM)
+        } else if (MODE == ALAN_MODE_SUM) {
             s += x;
-        else
+        } else {
+            const T w = load_as<T>(d.w.p, d.w.dtype, woff);
             s += w * Num<T>::exp(x);
+        }
     }
 
     // ---- combine the G lanes of the group
@@ -141,6 +148,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_LSE: return launch_group_T<T, ALAN_MODE_LSE>(gd, gl, stream);  \
         case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream);  \
         case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream); \
+        case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream); \
     }
     if (compute_dtype == ALAN_F32) {
         ALAN_DISPATCH(float)

@@ -46,6 +46,10 @@ Set ``alan_amd.dist.VALIDATE_ARGS = True`` to get the reference's behaviour (exc
 parameters / samples)."""
 
 
+FUSE_NORMAL = True
+"""Route gradient-free Normal log-probs on the GPU to the fused HIP producer kernel."""
+
+
 class TorchDimDist:
     """A torch.distributions distribution whose parameters are torchdim tensors (or PTs)."""
 
@@ -95,6 +99,11 @@ class TorchDimDist:
         dims, ids = pt_order((x, *self.kwargs.values()), lead, last)
         n_sample = x.n_pos - self.sample_batch_ndim - self.sample_event_ndim
         assert n_sample >= 0
+        if self._fusable(x):
+            from . import engine as E
+            loc, scale = self.kwargs["loc"], self.kwargs["scale"]
+            out = E.normal_logprob((x.x, x.dims), (loc.x, loc.dims), (scale.x, scale.dims), dims)
+            return PT(out, dims)
         d = self._build(ids, n_sample)
         lp = d.log_prob(pt_align(x, ids))
         if lp.ndim > len(ids):
@@ -104,6 +113,18 @@ class TorchDimDist:
     def log_prob(self, x, dim_order=None):
         assert is_tensor(x)
         return self.log_prob_pt(x, dim_order).dim()
+
+    def _fusable(self, x):
+        """Normal log-probs on the GPU with no gradient to record go to the fused HIP producer
+        (alan_reduce mode NORMAL); everything else stays on torch.distributions."""
+        if not FUSE_NORMAL or self.dist is not td.Normal or set(self.kwargs) != {"loc", "scale"}:
+            return False
+        ts = [x.x, self.kwargs["loc"].x, self.kwargs["scale"].x]
+        if not all(v.is_cuda and v.dtype in (t.float32, t.float64) for v in ts):
+            return False
+        if t.is_grad_enabled() and any(v.requires_grad for v in ts):
+            return False
+        return True
 
 
 # --------------------------------------------------------------------------------------------

@@ -203,6 +203,28 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     return out, tuple(_out_order([(x.detach(), d) for x, d in factors], keep, sizes))
 
 
+# --------------------------------------------------------------------------- fused factor producer
+def normal_logprob(value, loc, scale, out_dims):
+    """log N(value; loc, scale) summed over every positional (sample/batch/event) dim, as ONE launch
+    (alan_reduce mode NORMAL): the [.., K, K, K, d] broadcast the reference materialises
+    (TorchDimDist.py:127-162) never exists.  Each argument is (tensor, leading first-class dims);
+    trailing positional dims are right-aligned.  Returns a tensor laid out as ``out_dims``."""
+    tok = _Tokens()
+    npos = max(x.ndim - len(d) for x, d in (value, loc, scale))
+    factors = []
+    for x, d in (value, loc, scale):
+        k = x.ndim - len(d)
+        keys = tok.many(d) + tuple(tok(("_e", npos - k + j)) for j in range(k))
+        factors.append((x.detach(), keys))
+    sizes = _space(factors)
+    odims = tok.many(out_dims)
+    roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
+    dtype = _result_dtype([x for x, _ in factors])
+    out = t.empty([sizes[d] for d in odims], dtype=dtype, device=value[0].device)
+    _launch(N.MODE_NORMAL, factors, sizes, roles, out, odims)
+    return out
+
+
 # --------------------------------------------------------------------------- elimination planner
 def plan_elimination(dimsets, sizes, Ks):
     """Order of K eliminations.  Returns a list of steps ``(factor_ids, Ks_now)`` over a growing list of

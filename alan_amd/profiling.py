@@ -26,7 +26,7 @@ def hip():
 class KernelTimer:
     def __init__(self, min_bytes=0):
         self.min_bytes = min_bytes
-        self.records = []          # (algorithmic_bytes, ev_start, ev_stop)
+        self.records = []          # (mode, algorithmic_bytes, ev_start, ev_stop)
 
     def __enter__(self):
         self._prev = N._TIMER[0]
@@ -43,18 +43,18 @@ class KernelTimer:
         a, b = C.c_void_p(), C.c_void_p()
         assert h.hipEventCreate(C.byref(a)) == 0 and h.hipEventCreate(C.byref(b)) == 0
         desc.ev_start, desc.ev_stop = a.value, b.value
-        self.records.append((algo_bytes, a, b))
+        self.records.append((int(desc.mode), algo_bytes, a, b))
 
     def results(self):
-        """[(algorithmic_bytes, milliseconds)] -- call after the stream has been synchronised."""
+        """[(mode, algorithmic_bytes, milliseconds)] -- call after the stream has been synchronised."""
         h = hip()
         out = []
-        for nbytes, a, b in self.records:
+        for mode, nbytes, a, b in self.records:
             ms = C.c_float()
             h.hipEventSynchronize(b)
             rc = h.hipEventElapsedTime(C.byref(ms), a, b)
             if rc == 0:
-                out.append((nbytes, ms.value))
+                out.append((mode, nbytes, ms.value))
             h.hipEventDestroy(a)
             h.hipEventDestroy(b)
         self.records = []

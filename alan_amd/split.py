@@ -115,18 +115,24 @@ class Split:
 
 
 class _AllReduceSum(t.autograd.Function):
-    """Sum of per-rank partial log-marginals.  Everything downstream is replicated on every rank, so
-    the gradient wrt this rank's partial is the incoming gradient, unchanged."""
+    """Sum of per-rank partial log-marginals.
+
+    Backward: everything downstream of the sum is REPLICATED on every rank, everything upstream is
+    this rank's shard.  Scaling the incoming gradient by the world size makes the usual data-parallel
+    convention exact: AVERAGE parameter gradients over ranks (DistributedDataParallel, or
+    all_reduce(AVG)) and you get d ELBO / d theta of the unsharded model -- sharded terms are summed,
+    replicated terms (computed identically W times) are not over-counted."""
 
     @staticmethod
     def forward(ctx, x, group):
+        ctx.world = dist.get_world_size(group)
         x = x.contiguous().clone()
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
         return x
 
     @staticmethod
     def backward(ctx, g):
-        return g, None
+        return g * ctx.world, None
 
 
 def all_reduce_sum(lp, group=None):

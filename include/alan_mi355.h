@@ -13,6 +13,8 @@
  *   alan_reduce(mode = ALAN_MODE_SUM)      logpq.py:149-153       plate sum / Split accumulate (prev_lpq + lp)
  *   alan_reduce(mode = ALAN_MODE_WEXPSUM)  backward of the above (what autograd derives from utils.py:218-220):
  *                                          grad_f = sum_{dims not in f} grad_out * exp(sum_f lp_f - lse)
+ *   alan_reduce(mode = ALAN_MODE_NORMAL)   TorchDimDist.py:127-162 log_prob of a Normal over the K cross-product with
+ *                                          the event-dim sum (utils.py:147-152) fused in: the factor PRODUCER
  *   alan_chain_logmmexp                    utils.py:478-510 chain_logmmexp  (+ logpq.py:139 logsumexp(-1))
  *
  * Conventions
@@ -56,7 +58,11 @@ typedef enum {
 typedef enum {
     ALAN_MODE_LSE = 0,     /* out = log(sum_R exp(x - max_R x) + eps(dtype)) + max_R x,  x = sum_f scale_f * factor_f */
     ALAN_MODE_SUM = 1,     /* out = sum_R x */
-    ALAN_MODE_WEXPSUM = 2  /* out = sum_R weight * exp(x) */
+    ALAN_MODE_WEXPSUM = 2, /* out = sum_R weight * exp(x) */
+    ALAN_MODE_NORMAL = 3   /* fused factor PRODUCER (TorchDimDist.py:127-162 + utils.py:147-152 for td.Normal):
+                              exactly 3 factors (value, loc, scale);
+                              out = sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
+                              R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised */
 } alan_mode_t;
 
 typedef struct {

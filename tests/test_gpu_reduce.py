@@ -10,6 +10,7 @@ import torch as t
 from conftest import load_golden
 from oracle import alan_oracle as orc
 from alan_amd import engine as E
+from alan_amd import engine as E_
 from alan_amd import native as N
 
 pytestmark = pytest.mark.gpu
@@ -214,3 +215,43 @@ def test_chain_logmmexp_golden(case):
     ms2 = ms.permute(1, 2, 0).contiguous().permute(2, 0, 1)
     vec2, _ = N.chain_logmmexp(ms2)
     t.testing.assert_close(vec2, vec, rtol=0, atol=0)
+
+
+# ------------------------------------------------------------------ fused Normal factor producer
+@pytest.mark.parametrize("M,K,E,dtype", [(7, 3, 18, t.float32), (40, 10, 18, t.float32), (300, 30, 18, t.float32),
+                                         (5, 4, 1, t.float64), (9, 5, 7, t.float32)])
+def test_normal_producer_matches_torch_distributions(M, K, E, dtype):
+    """alan_reduce(mode NORMAL) == td.Normal(loc, scale).log_prob(x).sum(event) over the K cross product
+    (TorchDimDist.py:127-162, utils.py:147-152), fp32 to 2e-5 relative."""
+    g = t.Generator().manual_seed(M * K + E)
+    x = t.randn(M, K, E, generator=g, dtype=dtype)
+    loc = t.randn(K, E, generator=g, dtype=dtype)
+    scale = (0.3 * t.randn(K, E, generator=g, dtype=dtype)).exp()
+    ref = t.distributions.Normal(loc[None, :, None, None, :], scale[None, None, :, None, :]).log_prob(
+        x[:, None, None, :, :]).sum(-1)                      # [M, Kmu, Kpsi, Kz]
+    out = E_.normal_logprob((x.to(DEV), ("m", "kz")), (loc.to(DEV), ("kmu",)), (scale.to(DEV), ("kpsi",)),
+                            ("m", "kmu", "kpsi", "kz"))
+    kw = dict(rtol=2e-5, atol=2e-4) if dtype == t.float32 else dict(rtol=1e-12, atol=1e-10)
+    t.testing.assert_close(out.cpu(), ref, **kw)
+
+
+def test_fused_and_torch_log_prob_paths_agree():
+    import alan_amd.dist as D
+    from alan_amd.dims import Dim, PT
+    g = t.Generator().manual_seed(0)
+    M, K, E = 12, 6, 18
+    dm, dz, dmu, dpsi = Dim("plate_1", M), Dim("K_z", K), Dim("K_mu", K), Dim("K_psi", K)
+    x = PT(t.randn(M, K, E, generator=g).to(DEV), (dm, dz))
+    loc = PT(t.randn(K, E, generator=g).to(DEV), (dmu,))
+    sc = PT(t.rand(K, E, generator=g).to(DEV) + 0.5, (dpsi,))
+    order = ([dm], [dz])
+    D.FUSE_NORMAL = True
+    a = D.TorchDimDist(t.distributions.Normal, loc=loc, scale=sc).log_prob_pt(x, order)
+    D.FUSE_NORMAL = False
+    try:
+        b = D.TorchDimDist(t.distributions.Normal, loc=loc, scale=sc).log_prob_pt(x, order)
+    finally:
+        D.FUSE_NORMAL = True
+    assert [str(d) for d in a.dims] == [str(d) for d in b.dims] == ["plate_1", "K_mu", "K_psi", "K_z"]
+    t.testing.assert_close(a.x, b.x, rtol=2e-5, atol=2e-4)
+    assert a.x.is_contiguous()
