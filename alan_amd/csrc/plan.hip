@@ -170,7 +170,7 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
         }
         while (logG < 6 && (c.n_out << logG) < want_threads && (c.n_red >> logG) >= 2) ++logG;
     }
-    gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 2048);
+    gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 512);
     gl.logG = logG;
     if (gl.block) {
         gl.grid = (uint32_t)c.n_out;

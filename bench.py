@@ -74,11 +74,11 @@ def strategy_for(world, K, M=M_USERS):
     return alan.no_checkpoint
 
 
-def timed_evals(sample, strat, steps, warmup, world, timer=None):
+def timed_evals(sample, strat, steps, warmup, world, timer=None, graph=False):
     import torch.distributed as dist
     val = None
     for _ in range(warmup):
-        val = sample.elbo_nograd(strat)
+        val = sample.elbo_nograd(strat, graph=graph)
     if world > 1:
         dist.barrier()
     t.cuda.synchronize()
@@ -86,10 +86,10 @@ def timed_evals(sample, strat, steps, warmup, world, timer=None):
     if timer is not None:
         with timer:
             for _ in range(steps):
-                val = sample.elbo_nograd(strat)
+                val = sample.elbo_nograd(strat, graph=graph)
     else:
         for _ in range(steps):
-            val = sample.elbo_nograd(strat)
+            val = sample.elbo_nograd(strat, graph=graph)
     t.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--K", type=int, default=30)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / scaled roofline / K sweep")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel from Python each step instead of replaying a HIP graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,8 +181,23 @@ def main():
     prob = build_problem("cuda")
     sample = draw(prob, K)
     strat = strategy_for(world, K)
+    use_graph = not args.eager and os.environ.get("ALAN_BENCH_GRAPH", "1") != "0"
     kt = KernelTimer(min_bytes=1 << 20)
-    dt, elbo = timed_evals(sample, strat, args.steps, args.warmup, world, timer=kt)
+    if use_graph:
+        try:
+            dt, elbo = timed_evals(sample, strat, args.steps, args.warmup, world, graph=True)
+        except Exception as e:                           # capture unsupported (e.g. a collective): eager
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+    if use_graph:
+        # per-kernel HIP events cannot be recorded inside a replayed graph: time the same launches
+        # eagerly, same process, same buffers, right after the timed region
+        with kt:
+            for _ in range(args.steps):
+                sample.elbo_nograd(strat)
+            t.cuda.synchronize()
+    else:
+        dt, elbo = timed_evals(sample, strat, args.steps, args.warmup, world, timer=kt)
     res = kt.results()
 
     out = {
@@ -189,6 +206,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"movielens M={M_USERS} N={N_FILMS} d_z={D_Z}, K={K}, elbo_nograd on a fixed sample",
+                   "launch": "HIP graph replay of one captured ELBO evaluation" if use_graph
+                   else "eager (one Python-driven launch per kernel)",
                    "computation_strategy": type(strat).__name__ +
                    (f"('plate_1', {strat.split_size}, shard=True)" if world > 1 else ""),
                    "parallelism": f"plate_1 sharded over {world} rank(s), one all-reduce(SUM) of [K,K] per eval"
@@ -223,7 +242,7 @@ def main():
             s2 = draw(prob, k2)
             st2 = strategy_for(world, k2)
             n2 = 3 if k2 >= 100 else 20
-            d2, _ = timed_evals(s2, st2, n2, 2, world)
+            d2, _ = timed_evals(s2, st2, n2, 2, world, graph=use_graph)
             sweep[f"K{k2}"] = {"evals_per_s": n2 / d2, "ms_per_eval": d2 / n2 * 1e3,
                                "strategy": type(st2).__name__}
             del s2

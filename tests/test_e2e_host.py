@@ -41,3 +41,25 @@ def test_elbo_matches_reference_host_logic(fixture, model, split, oracle_backend
 @pytest.mark.parametrize("fixture,model,split", CASES, ids=[c[0][4:-3] for c in CASES])
 def test_elbo_matches_reference_hip(fixture, model, split):
     _check(fixture, model, split, "cuda")
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_and_sees_parameter_updates():
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda")
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+    eager = sample.elbo_nograd(alan.no_checkpoint)
+    g1 = sample.elbo_nograd(alan.no_checkpoint, graph=True)
+    g2 = sample.elbo_nograd(alan.no_checkpoint, graph=True)          # replay
+    assert float(g1) == float(g2)
+    assert abs(float(g1) - float(eager)) <= 1e-6 * abs(float(eager))
+    with t.no_grad():                                                  # in-place update, same storage
+        for p in prob.Q.parameters():
+            p.add_(0.05)
+    eager2 = sample.elbo_nograd(alan.no_checkpoint)
+    g3 = sample.elbo_nograd(alan.no_checkpoint, graph=True)
+    assert abs(float(eager2) - float(eager)) > 1e-3 * abs(float(eager))
+    assert abs(float(g3) - float(eager2)) <= 1e-6 * abs(float(eager2))
+    split = alan.Split("plate_1", 38)
+    a, b = sample.elbo_nograd(split), sample.elbo_nograd(split, graph=True)
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
