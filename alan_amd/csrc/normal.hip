@@ -1,0 +1,181 @@
+// normal_outer kernel: register-blocked fast path of alan_reduce(mode = ALAN_MODE_NORMAL), the fused
+// PRODUCER of the big log-prob factor (replaces TorchDimDist.py:127-162 + utils.py:147-152 for
+// td.Normal when value, loc and scale carry DISJOINT first-class dims -- e.g. movielens
+//   z[plate_1, K_z, d] ~ Normal(mu_z[K_mu, d], exp(psi_z)[K_psi, d])  ->  F[plate_1, K_mu, K_psi, K_z]).
+//
+//   out[v, l, s] = -sum_e (value[v,e] - loc[l,e])^2 * (0.5 / scale[s,e]^2) - sum_e log scale[s,e] - E log sqrt(2 pi)
+//
+// (same arithmetic as torch.distributions.Normal.log_prob: no expanded square, so no cancellation.)
+// A thread owns one value row in registers and walks the (loc row, scale row) cross product; loc/scale
+// rows are workgroup-uniform, so they come from LDS as broadcast reads: ~1.4 issue slots per (output, e).
+// The kernel is bound by the store of F (HBM write), not by arithmetic.
+#include <algorithm>
+#include <cstring>
+
+#include "plan.h"
+
+namespace alan {
+
+struct NormalDesc {
+    const float *val, *loc, *scl;
+    float *out;
+    int32_t E, Ep;                 // event length, padded to a multiple of 4
+    uint32_t NV, NL, NS, l_chunk;
+    int32_t nv;
+    FastDiv vdiv[MAXD];
+    int64_t v_vs[MAXD], v_os[MAXD];   // value / out strides over the value's keep dims
+    int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
+    int64_t l_os, s_os;               // out strides along the loc / scale dims
+};
+
+template <int EMAX>
+__global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
+    extern __shared__ __align__(16) float lds[];
+    const int E = d.E, Ep = d.Ep;
+    float *w = lds;                       // [NS][Ep], zero padded
+    float *lg = w + (size_t)d.NS * Ep;    // [NS]
+    float *mu = lg + ((d.NS + 3) & ~3u);  // [l_chunk][Ep]
+    const int tid = threadIdx.x;
+    const uint32_t l0 = blockIdx.y * d.l_chunk;
+    const uint32_t l1 = min(d.NL, l0 + d.l_chunk);
+
+    // ---- workgroup-uniform tables
+    for (uint32_t i = tid; i < d.NS * (uint32_t)Ep; i += 256) {
+        const uint32_t is = i / Ep, e = i - is * Ep;
+        float v = 0.f;
+        if ((int)e < E) {
+            const float sc = d.scl[(int64_t)is * d.s_rs + e];
+            v = 0.5f / (sc * sc);
+        }
+        w[i] = v;
+    }
+    for (uint32_t is = tid; is < d.NS; is += 256) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s += logf(d.scl[(int64_t)is * d.s_rs + e]);
+        lg[is] = s + (float)E * 0.91893853320467274178f;
+    }
+    for (uint32_t i = tid; i < (l1 - l0) * (uint32_t)Ep; i += 256) {
+        const uint32_t il = i / Ep, e = i - il * Ep;
+        mu[i] = (int)e < E ? d.loc[(int64_t)(l0 + il) * d.l_rs + e] : 0.f;
+    }
+
+    // ---- this thread's value row
+    const uint32_t r = blockIdx.x * 256u + tid;
+    const bool active = r < d.NV;
+    int64_t voff = 0, ooff = 0;
+    {
+        uint32_t o = active ? r : d.NV - 1u;
+        for (int k = d.nv - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(o, d.vdiv[k]);
+            const int64_t idx = (int64_t)(o - q * d.vdiv[k].d);
+            o = q;
+            voff += idx * d.v_vs[k];
+            ooff += idx * d.v_os[k];
+        }
+    }
+    float v[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) v[e] = (e < E) ? d.val[voff + e] : 0.f;
+    __syncthreads();
+
+    for (uint32_t il = l0; il < l1; ++il) {
+        const float4 *m4 = reinterpret_cast<const float4 *>(mu + (size_t)(il - l0) * Ep);
+        float dd[EMAX];
+#pragma unroll
+        for (int q = 0; q < EMAX / 4; ++q) {
+            if (q * 4 < Ep) {
+                const float4 m = m4[q];
+                const float a = v[4 * q] - m.x, b = v[4 * q + 1] - m.y, c = v[4 * q + 2] - m.z,
+                            e = v[4 * q + 3] - m.w;
+                dd[4 * q] = a * a;
+                dd[4 * q + 1] = b * b;
+                dd[4 * q + 2] = c * c;
+                dd[4 * q + 3] = e * e;
+            }
+        }
+        float *orow = d.out + ooff + (int64_t)il * d.l_os;
+        for (uint32_t is = 0; is < d.NS; ++is) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(w + (size_t)is * Ep);
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < EMAX / 4; ++q) {
+                if (q * 4 < Ep) {
+                    const float4 ww = w4[q];
+                    acc = fmaf(dd[4 * q], ww.x, acc);
+                    acc = fmaf(dd[4 * q + 1], ww.y, acc);
+                    acc = fmaf(dd[4 * q + 2], ww.z, acc);
+                    acc = fmaf(dd[4 * q + 3], ww.w, acc);
+                }
+            }
+            if (active) orow[(int64_t)is * d.s_os] = -acc - lg[is];
+        }
+    }
+}
+
+// Returns ALAN_ERR_UNSUPPORTED when the canonical problem is not an outer-product Normal.
+int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev) {
+    if (c.nf != 3 || c.nr != 1) return ALAN_ERR_UNSUPPORTED;
+    for (int f = 0; f < 3; ++f)
+        if (c.f[f].dtype != ALAN_F32 || c.f[f].rs[0] != 1) return ALAN_ERR_UNSUPPORTED;
+    if (c.o.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    const int64_t E = c.rsize[0];
+    if (E < 1 || E > 64) return ALAN_ERR_UNSUPPORTED;
+
+    NormalDesc d;
+    std::memset(&d, 0, sizeof(d));
+    int nL = 0, nS = 0;
+    int64_t NV = 1;
+    d.NL = d.NS = 1;
+    for (int j = 0; j < c.nk; ++j) {
+        const bool inV = c.f[0].ks[j] != 0, inL = c.f[1].ks[j] != 0, inS = c.f[2].ks[j] != 0;
+        if ((int)inV + (int)inL + (int)inS != 1) return ALAN_ERR_UNSUPPORTED;  // shared or pure-broadcast dim
+        if (inV) {
+            d.vdiv[d.nv] = make_fastdiv((uint32_t)c.ksize[j]);
+            d.v_vs[d.nv] = c.f[0].ks[j];
+            d.v_os[d.nv] = c.o.ks[j];
+            ++d.nv;
+            NV *= c.ksize[j];
+        } else if (inL) {
+            if (nL++) return ALAN_ERR_UNSUPPORTED;
+            d.NL = (uint32_t)c.ksize[j];
+            d.l_rs = c.f[1].ks[j];
+            d.l_os = c.o.ks[j];
+        } else {
+            if (nS++) return ALAN_ERR_UNSUPPORTED;
+            d.NS = (uint32_t)c.ksize[j];
+            d.s_rs = c.f[2].ks[j];
+            d.s_os = c.o.ks[j];
+        }
+    }
+    if (NV * d.NL * d.NS < 65536) return ALAN_ERR_UNSUPPORTED;  // tiny: the generic kernel is fine
+    d.val = (const float *)c.f[0].p;
+    d.loc = (const float *)c.f[1].p;
+    d.scl = (const float *)c.f[2].p;
+    d.out = (float *)const_cast<void *>(c.o.p);
+    d.E = (int)E;
+    d.Ep = (int)((E + 3) & ~3);
+    d.NV = (uint32_t)NV;
+
+    const uint32_t gx = (uint32_t)((NV + 255) / 256);
+    // enough workgroups to fill the chip: split the loc rows over grid.y
+    uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 2048 / std::max(1u, gx)));
+    d.l_chunk = (d.NL + gy - 1) / gy;
+    gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
+    const size_t lds = ((size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep) * sizeof(float);
+    if (lds > 64 * 1024) return ALAN_ERR_UNSUPPORTED;
+
+    ev.begin(stream);
+    const dim3 grid(gx, gy), block(256);
+    if (d.Ep <= 8)
+        hipLaunchKernelGGL(normal_outer_kernel<8>, grid, block, lds, stream, d);
+    else if (d.Ep <= 16)
+        hipLaunchKernelGGL(normal_outer_kernel<16>, grid, block, lds, stream, d);
+    else if (d.Ep <= 32)
+        hipLaunchKernelGGL(normal_outer_kernel<32>, grid, block, lds, stream, d);
+    else
+        hipLaunchKernelGGL(normal_outer_kernel<64>, grid, block, lds, stream, d);
+    ev.end(stream);
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+}
+
+}  // namespace alan

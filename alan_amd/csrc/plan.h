@@ -77,4 +77,7 @@ struct EvPair {
 int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
                 size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 
+// normal.hip: register-blocked Normal producer (value / loc / scale on disjoint dims).
+int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev);
+
 }  // namespace alan

@@ -217,6 +217,10 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     int rc = canonicalise(d, keep_mask, red_mask, out, c);
     if (rc != ALAN_OK) return rc;
     const int compute = out.dtype;
+    if (mode == ALAN_MODE_NORMAL) {
+        rc = try_launch_normal_outer(c, stream, ev);
+        if (rc != ALAN_ERR_UNSUPPORTED) return rc;
+    }
     const RowsPlan rp = plan_rows(c, mode, compute);
     if (rp.ok) return launch_rows(c, rp, mode, add_const, nullptr, 0, stream, ev);
     GroupDesc gd;
