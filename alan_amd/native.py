@@ -78,6 +78,12 @@ def lib():
         L.alan_chain_logmmexp.restype = C.c_int
         L.alan_chain_logmmexp.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_chain_backward_workspace_bytes.restype = C.c_size_t
+        L.alan_chain_backward_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+        L.alan_chain_logmmexp_backward.restype = C.c_int
+        L.alan_chain_logmmexp_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -85,7 +91,8 @@ def lib():
 
 
 EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_chain_workspace_bytes",
-           "alan_chain_logmmexp", "alan_abi_version", "alan_build_target")
+           "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
+           "alan_abi_version", "alan_build_target")
 
 
 def dtype_code(dtype):
@@ -150,3 +157,21 @@ def chain_logmmexp(ms, want_chain=False):
                                ws.data_ptr(), nbytes, current_stream(ms.device))
     check(rc, "alan_chain_logmmexp")
     return vec, chain
+
+
+def chain_logmmexp_backward(ms, out_vec, grad_out):
+    """Gradient of logsumexp(chain_logmmexp(ms), -1) wrt ms: [T,K,K]."""
+    require_device(ms, "timeseries factor")
+    L = lib()
+    T, K, _ = ms.shape
+    code = dtype_code(ms.dtype)
+    grad = t.empty(T, K, K, dtype=ms.dtype, device=ms.device)
+    out_vec = out_vec.contiguous()
+    grad_out = grad_out.to(ms.dtype).contiguous()
+    nbytes = L.alan_chain_backward_workspace_bytes(T, K, code)
+    ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
+    rc = L.alan_chain_logmmexp_backward(ms.data_ptr(), code, T, K, ms.stride(0), ms.stride(1), ms.stride(2),
+                                        out_vec.data_ptr(), grad_out.data_ptr(), grad.data_ptr(),
+                                        ws.data_ptr(), nbytes, current_stream(ms.device))
+    check(rc, "alan_chain_logmmexp_backward")
+    return grad

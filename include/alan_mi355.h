@@ -16,6 +16,7 @@
  *   alan_reduce(mode = ALAN_MODE_NORMAL)   TorchDimDist.py:127-162 log_prob of a Normal over the K cross-product with
  *                                          the event-dim sum (utils.py:147-152) fused in: the factor PRODUCER
  *   alan_chain_logmmexp                    utils.py:478-510 chain_logmmexp  (+ logpq.py:139 logsumexp(-1))
+ *   alan_chain_logmmexp_backward           autograd through the same
  *
  * Conventions
  *   - Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller.
@@ -106,6 +107,15 @@ int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K,
                         int64_t sT, int64_t sRow, int64_t sCol,
                         void *out_chain, void *out_vec,
                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of out_vec = logsumexp(chain_logmmexp(ms), -1) with respect to ms (what autograd derives from
+ * utils.py:478-510 + logpq.py:139).  out_vec is the forward result [K], grad_out the upstream gradient [K],
+ * grad_ms receives [T, K, K] contiguous.  Two O(T K^2) log-space scans. */
+size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
+int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K,
+                                 int64_t sT, int64_t sRow, int64_t sCol,
+                                 const void *out_vec, const void *grad_out, void *grad_ms,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);

@@ -62,14 +62,24 @@ def oracle_chain(ms, want_chain=False):
     return t.logsumexp(chain, -1), (chain if want_chain else None)
 
 
+def oracle_chain_backward(ms, vec, g):
+    import torch as t
+    from oracle import alan_oracle as orc
+    with t.enable_grad():
+        x = ms.detach().clone().requires_grad_(True)
+        (grad,) = t.autograd.grad(orc.timeseries_plate(x), x, g)
+    return grad
+
+
 @contextlib.contextmanager
 def installed():
     """Temporarily route alan_amd's launch seam to the oracle (CPU tensors accepted)."""
     from alan_amd import engine, native
-    saved = (engine._launch, native.chain_logmmexp, native.require_device)
+    saved = (engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward)
     engine._launch, native.chain_logmmexp = oracle_launch, oracle_chain
+    native.chain_logmmexp_backward = oracle_chain_backward
     native.require_device = lambda x, what="tensor": None
     try:
         yield
     finally:
-        engine._launch, native.chain_logmmexp, native.require_device = saved
+        engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward = saved

@@ -38,5 +38,7 @@ def oracle_backend(monkeypatch):
     from alan_amd import engine, native
     monkeypatch.setattr(engine, "_launch", _oracle_launch)
     monkeypatch.setattr(native, "chain_logmmexp", _oracle_chain)
+    from oracle.backend import oracle_chain_backward
+    monkeypatch.setattr(native, "chain_logmmexp_backward", oracle_chain_backward)
     monkeypatch.setattr(native, "require_device", lambda x, what="tensor": None)
     yield

@@ -255,3 +255,19 @@ def test_fused_and_torch_log_prob_paths_agree():
     assert [str(d) for d in a.dims] == [str(d) for d in b.dims] == ["plate_1", "K_mu", "K_psi", "K_z"]
     t.testing.assert_close(a.x, b.x, rtol=2e-5, atol=2e-4)
     assert a.x.is_contiguous()
+
+
+@pytest.mark.parametrize("case", [c for c in load_golden("chain.pt") if "T" in c],
+                         ids=lambda c: f"T{c['T']}K{c['K']}")
+def test_chain_backward_golden(case):
+    """d/d ms of sum(grad_out * logsumexp(chain_logmmexp(ms), -1)) vs the reference's autograd."""
+    from alan_amd.contract import chain_logmmexp_lse
+    ms = _chain_input(case).to(DEV).requires_grad_(True)
+    out = chain_logmmexp_lse(ms)
+    (grad,) = t.autograd.grad(out, ms, case["grad_out"].to(DEV))
+    if case["grad"] is not None:
+        kw = dict(rtol=1e-4, atol=1e-5) if ms.dtype == t.float32 else dict(rtol=1e-9, atol=1e-10)
+        t.testing.assert_close(grad.cpu(), case["grad"], **kw)
+    s, a = case["grad_checksum"]
+    assert abs(float(grad.double().sum()) - s) <= 2e-4 * max(1.0, a)
+    assert abs(float(grad.double().abs().sum()) - a) <= 2e-4 * max(1.0, a)
