@@ -14,6 +14,7 @@
 //   * the plate sum is accumulated in a register across the chunk; each workgroup writes one partial
 //     per row, and a tiny second stage adds the chunks (deterministic: no float atomics).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "plan.h"
@@ -39,7 +40,11 @@ struct RowsDesc {
     float add_const;
 };
 
-constexpr int ROWS_UNR = 8;  // 16-byte loads in flight per thread (one slab <= 256*8*16 B = 32 KiB)
+#ifndef ROWS_NT
+#define ROWS_NT 1
+#endif
+constexpr int ROWS_UNR = 8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // 16-byte loads in flight per thread (one slab <= 256*8*16 B = 32 KiB)
 
 template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN>
 __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
@@ -79,17 +84,17 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
     const int j0 = ROT ? (r % L) : 0;
 
     // slab of plate index p: 16-byte loads from a 16-byte aligned-down start into registers
-    float4 v[ROWS_UNR];
+    f32x4 v[ROWS_UNR];
     auto slab_fetch = [&](uint32_t p) {
         const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
         const int64_t a0 = e0 & ~(int64_t)3;
         const int n4 = ((int)(e0 - a0) + (int)nrows * L + 3) >> 2;
-        const float4 *src = reinterpret_cast<const float4 *>(d.F + a0);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(d.F + a0);
         if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the last one)
 #pragma unroll
             for (int u = 0; u < ROWS_UNR; ++u) {
                 const int i = u * 256 + t;
-                if (i < n4) v[u] = src[i];
+                if (i < n4) v[u] = ROWS_NT ? __builtin_nontemporal_load(src + i) : src[i];   // read-once stream
             }
         } else {
 #pragma unroll
@@ -107,32 +112,40 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
         }
     };
 
+    // the window-constant small factors of plate index p: thread j < L holds sum_f sh_f[p, j]
+    float gnext = 0.f;
+    auto shared_fetch = [&](uint32_t p) {
+        float g = 0.f;
+        if (d.nshared > 0 && t < L) {
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < d.nshared)
+                    g += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)t * d.sh[f].rs[0]];
+        }
+        gnext = g;
+    };
+
     float acc = 0.f;
     slab_fetch(p0);
+    shared_fetch(p0);
     for (uint32_t p = p0; p < p1; ++p) {
         const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
         const int shift = (int)(e0 & 3);
         const int n4 = (shift + (int)nrows * L + 3) >> 2;
         {
-            float4 *dst = reinterpret_cast<float4 *>(lds);
+            f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
 #pragma unroll
             for (int u = 0; u < ROWS_UNR; ++u) {
                 const int i = u * 256 + t;
                 if (i < n4) dst[i] = v[u];
             }
         }
-        if (d.nshared > 0) {
-            for (int j = t; j < L; j += 256) {
-                float g = 0.f;
-#pragma unroll
-                for (int f = 0; f < MAXF; ++f)
-                    if (f < d.nshared)
-                        g += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)j * d.sh[f].rs[0]];
-                gs[j] = g;
-            }
-        }
+        if (d.nshared > 0 && t < L) gs[t] = gnext;
         __syncthreads();
-        if (p + 1 < p1) slab_fetch(p + 1);  // in flight while this slab is reduced
+        if (p + 1 < p1) {   // in flight while this slab is reduced
+            slab_fetch(p + 1);
+            shared_fetch(p + 1);
+        }
 
         float *row = lds + shift + r * L;
         float val;
@@ -277,10 +290,12 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.NO = (uint32_t)(c.n_out / rp.P);
     rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
     int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
+    if (const char *e = getenv("ALAN_ROWS_RBMAX")) rbmax = std::max(1, std::min(rbmax, atoi(e)));  // tuning knob
     rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
     rp.RB = (int)((rp.NO + rp.n_windows - 1) / rp.n_windows);
     rp.threads = 256;
-    const uint32_t target_blocks = 2048;
+    uint32_t target_blocks = 4096;
+    if (const char *e = getenv("ALAN_ROWS_BLOCKS")) target_blocks = (uint32_t)std::max(1, atoi(e));   // tuning knob
     uint32_t nch = std::max(1u, std::min(rp.P, target_blocks / std::max(1u, rp.n_windows)));
     rp.p_chunk = (rp.P + nch - 1) / nch;
     rp.n_chunks = (rp.P + rp.p_chunk - 1) / rp.p_chunk;
