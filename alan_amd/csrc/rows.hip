@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
                         if (f < d.ngen)
                             x += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
                                                              (int64_t)jj * d.gen[f].rs[0]];
-                    row[jj] = x;
+                    if (has_row) row[jj] = x;   // (threads past the window's last row mirror it: no write)
                     m = fmaxf(m, x);
                 }
             } else if (VEC2) {

@@ -1,0 +1,112 @@
+"""Targeted parity tests of the LDS-staged rows kernel (csrc/rows.hip) against the CPU oracle: every
+template variant (lanes-per-row G, 8-byte vs rotated LDS reads, shared / general small factors),
+fused and unfused plate sum, saved LSE values + backward, SUM mode, unaligned slab starts and the
+16-byte-load tail guard.  Sizes are chosen above the kernel's 16384-element threshold."""
+import math
+
+import pytest
+import torch as t
+
+from oracle import alan_oracle as orc
+from alan_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cmp(out, dims, ref, ref_dims, rtol=3e-5, atol=3e-4):
+    a = orc.align((out.detach().cpu(), tuple(dims)), tuple(ref_dims)) if dims else out.detach().cpu()
+    t.testing.assert_close(a.reshape(ref.shape), ref, rtol=rtol, atol=atol, equal_nan=True)
+
+
+# L -> (G, read path): <=32 G=1, <=64 G=2, <=128 G=4, <=256 G=8; gcd(L,64)>=16 -> rotated b32; even -> b64; odd -> b32
+@pytest.mark.parametrize("L", [8, 9, 16, 30, 31, 32, 33, 48, 50, 64, 100, 127, 128, 200, 256])
+@pytest.mark.parametrize("plate", [False, True])
+def test_lse_over_contiguous_dim(L, plate):
+    g = t.Generator().manual_seed(L * 2 + plate)
+    M, A = 7, max(3, 20000 // (7 * L) + 1)
+    F = t.randn(M, A, L, generator=g) * 4
+    shared = t.randn(M, L, generator=g)            # constant over the window (no inner keep dim)
+    facs = [(F, ("m", "a", "k")), (shared, ("m", "k"))]
+    ref = orc.logsumexp_sum(("k",), *facs)
+    if plate:
+        ref = orc.plate_sum(ref, "m")
+    out, dims = E.reduce_factors([(x.to(DEV), d) for x, d in facs], reduce=("k",), plate=("m",) if plate else ())
+    _cmp(out, dims, ref[0], ref[1])
+
+
+@pytest.mark.parametrize("L", [30, 32, 100])
+def test_general_small_factor_depends_on_inner_keep_dim(L):
+    g = t.Generator().manual_seed(L)
+    M, A = 5, 20000 // (5 * L) + 2
+    F = t.randn(M, A, L, generator=g) * 3
+    gen = t.randn(A, L, generator=g)                # varies with the row inside a window
+    sh = t.randn(L, generator=g)
+    facs = [(F, ("m", "a", "k")), (gen, ("a", "k")), (sh, ("k",))]
+    ref = orc.plate_sum(orc.logsumexp_sum(("k",), *facs), "m")
+    out, dims = E.reduce_factors([(x.to(DEV), d) for x, d in facs], reduce=("k",), plate=("m",))
+    _cmp(out, dims, ref[0], ref[1])
+
+
+@pytest.mark.parametrize("L,off", [(30, 1), (30, 2), (30, 3), (9, 1), (100, 1), (33, 2)])
+def test_unaligned_views_and_tail(L, off):
+    """Factor is a view starting `off` floats into its storage: 16-byte alignment is broken -> the
+    library must fall back (or handle it); the last slab ends exactly at the end of the storage."""
+    g = t.Generator().manual_seed(L + off)
+    M, A = 6, 20000 // (6 * L) + 1
+    store = t.randn(off + M * A * L, generator=g).to(DEV)
+    F = store[off:].view(M, A, L)
+    ref = orc.plate_sum(orc.logsumexp_dims((F.cpu(), ("m", "a", "k")), ("k",)), "m")
+    out, dims = E.reduce_factors([(F, ("m", "a", "k"))], reduce=("k",), plate=("m",))
+    _cmp(out, dims, ref[0], ref[1])
+    # a plate slice (what Split produces): starts at a multiple of the plate stride
+    Fs = F[2:5]
+    ref = orc.plate_sum(orc.logsumexp_dims((Fs.cpu(), ("m", "a", "k")), ("k",)), "m")
+    out, dims = E.reduce_factors([(Fs, ("m", "a", "k"))], reduce=("k",), plate=("m",))
+    _cmp(out, dims, ref[0], ref[1])
+
+
+@pytest.mark.parametrize("L", [30, 64, 150])
+def test_plate_sum_mode_rows(L):
+    """ALAN_MODE_SUM over a contiguous dim (bus_breakdown's sum over plate_ID)."""
+    g = t.Generator().manual_seed(L)
+    A = 20000 // L + 5
+    X = t.randn(A, L, generator=g)
+    y = t.randn(A, generator=g)
+    out, dims = E.reduce_factors([(X.to(DEV), ("a", "i")), (y.to(DEV), ("a",))], plate=("i",))
+    _cmp(out, dims, (X + y[:, None]).sum(1), ("a",), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("L,K2", [(30, 30), (100, 12), (16, 40)])
+def test_saved_lse_and_backward_through_fused_plate(L, K2):
+    g = t.Generator().manual_seed(L + K2)
+    M = 9
+    F = t.randn(M, K2, K2, L, generator=g) * 2
+    gz = t.randn(M, L, generator=g)
+    cpu = [(F, ("m", "a", "b", "z")), (gz, ("m", "z"))]
+    (ref, ref_dims), ref_grads = orc.reduce_Ks_grads(cpu, ("z",), plate="m")
+    dev = [(x.to(DEV).requires_grad_(True), d) for x, d in cpu]
+    out, dims = E.reduce_factors(dev, reduce=("z",), plate=("m",))
+    _cmp(out, dims, ref, ref_dims)
+    w = t.randn(out.shape, generator=g)
+    wref = orc.align((w, tuple(dims)), tuple(ref_dims)).reshape(ref.shape)
+    (_, _), ref_grads = orc.reduce_Ks_grads(cpu, ("z",), plate="m", grad_out=wref)
+    grads = t.autograd.grad(out, [x for x, _ in dev], w.to(DEV))
+    for a, b in zip(grads, ref_grads):
+        t.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5)
+
+
+def test_neg_inf_and_nan_rows():
+    L, A = 30, 800
+    x = t.randn(A, L)
+    x[0, :] = float("-inf")
+    x[1, 5] = float("-inf")
+    x[2, 0] = float("nan")
+    x[3, :] = float("inf")
+    ref, _ = orc.logsumexp_dims((x, ("a", "k")), ("k",))
+    out, dims = E.reduce_factors([(x.to(DEV), ("a", "k"))], reduce=("k",))
+    got = out.cpu()
+    assert t.isnan(got[0]) and t.isnan(ref[0])
+    assert t.isnan(got[2]) and t.isnan(ref[2])
+    assert t.isnan(got[3]) and t.isnan(ref[3])
+    t.testing.assert_close(got[[1] + list(range(4, A))], ref[[1] + list(range(4, A))], rtol=3e-5, atol=3e-5)
