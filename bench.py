@@ -58,6 +58,53 @@ def build_problem(device, M=M_USERS, seed=0):
     return prob.to(device)
 
 
+def build_bus_problem(device, seed=0):
+    """bus_breakdown-shaped model (examples/models/bus_breakdown/bus_breakdown.py:38-100 of the reference):
+    3 nested plates Year=2 / Borough=3 / ID=150, covariates of width 8 and 59, Bernoulli observations."""
+    from alan_amd import Normal, Bernoulli, Plate, BoundPlate, Group, Problem, Data, OptParam
+    g = t.Generator().manual_seed(seed)
+    Y, B, I, nr, nb = 2, 3, 150, 8, 59
+    names = ("plate_Year", "plate_Borough", "plate_ID")
+    inp = {"run_type": (t.rand(Y, B, I, nr, generator=g) < 0.2).float().refine_names(*names, None),
+           "bus_company_name": (t.rand(Y, B, I, nb, generator=g) < 0.05).float().refine_names(*names, None)}
+    obs = (t.rand(Y, B, I, generator=g) < 0.66).float().refine_names(*names)
+    P = Plate(
+        psi=Normal(t.zeros((nr,)), t.ones((nr,))), phi=Normal(t.zeros((nb,)), t.ones((nb,))),
+        sigma_beta=Normal(0, 1), mu_beta=Normal(0, 1),
+        plate_Year=Plate(
+            beta=Normal("mu_beta", lambda sigma_beta: sigma_beta.exp()), sigma_alpha=Normal(0, 1),
+            plate_Borough=Plate(
+                alpha=Normal("beta", lambda sigma_alpha: sigma_alpha.exp()),
+                plate_ID=Plate(obs=Bernoulli(logits=lambda alpha, phi, psi, run_type, bus_company_name:
+                                             (alpha + phi @ bus_company_name + psi @ run_type))))))
+    Q = Plate(
+        global_latents=Group(
+            psi=Normal(OptParam(t.zeros(nr)), OptParam(t.zeros(nr), transformation=t.exp)),
+            phi=Normal(OptParam(t.zeros(nb)), OptParam(t.zeros(nb), transformation=t.exp)),
+            sigma_beta=Normal(OptParam(0.), OptParam(0., transformation=t.exp)),
+            mu_beta=Normal(OptParam(0.), OptParam(0., transformation=t.exp))),
+        plate_Year=Plate(
+            year_latents=Group(beta=Normal(OptParam(0.), OptParam(0., transformation=t.exp)),
+                               sigma_alpha=Normal(OptParam(0.), OptParam(0., transformation=t.exp))),
+            plate_Borough=Plate(alpha=Normal(OptParam(0.), OptParam(0., transformation=t.exp)),
+                                plate_ID=Plate(obs=Data()))))
+    sizes = {"plate_Year": Y, "plate_Borough": B, "plate_ID": I}
+    prob = Problem(BoundPlate(P, sizes, inputs=inp), BoundPlate(Q, sizes, inputs=inp), {"obs": obs})
+    return prob.to(device)
+
+
+def build_timeseries_problem(device, T=1000, seed=0):
+    """Kalman-filter test model of the reference (tests/timeseries.py:5-50) at T=1000."""
+    from alan_amd import Normal, Timeseries, Plate, BoundPlate, Problem, Data
+    g = t.Generator().manual_seed(seed)
+    y = t.randn(T, generator=g).refine_names("T")
+    P = Plate(init=Normal(0, 1.0),
+              T=Plate(ts=Timeseries("init", Normal(lambda prev: 0.9 * prev, 0.1)), obs=Normal("ts", 1.0)))
+    Q = Plate(init=Normal(0, 1), T=Plate(ts=Normal(0, 1), obs=Data()))
+    prob = Problem(BoundPlate(P, {"T": T}), BoundPlate(Q, {"T": T}), {"obs": y})
+    return prob.to(device)
+
+
 def draw(prob, K, seed=1):
     t.manual_seed(seed)
     if t.cuda.is_available():
@@ -125,6 +172,17 @@ def cpu_baseline(K, budget_s=20.0):
             "elbo": float(v)}
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the rows kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, see profiles/r1_rows_kernel_pmc.md).  Counters cannot be read from inside this process;
+    null when the profile does not cover this configuration."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_rows_kernel_pmc.json")))
+        return d[key]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def roofline_scaled(K, scale=64, iters=20):
     """The dominant kernel (S-ML plate step F[M,K,K,K] + g[M,K] -> lse K_z -> sum M) in the bandwidth
     regime: M = 300*scale so that F (2 GB at K=30) is far beyond the 256 MiB Infinity Cache."""
@@ -147,7 +205,8 @@ def roofline_scaled(K, scale=64, iters=20):
     ms = sum(m for _, _, m in res) / len(res)
     gbs = algo / ms / 1e6
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3,
+            "traffic": pmc_traffic("scaled_K30_M19200") if (K, scale) == (30, 64) else None,
+            "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3,
             "algorithmic_bytes": algo, "workload": f"S-ML plate step, K={K}, M={M} (300x{scale})"}
 
 
@@ -222,7 +281,8 @@ def main():
         ms = sum(sel) / len(sel)
         gbs = big / ms / 1e6
         out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                           "frac": gbs / HBM_PEAK_GBS,
+                           "traffic": pmc_traffic("literal_K30_M300") if (K, world) == (30, 1) else None,
                            "kernel": "alan::rows_kernel (plate_1 step: F[M,K,K,K]+g[M,K] -> lse K_z -> sum M)",
                            "us_per_launch": ms * 1e3, "algorithmic_bytes": big, "launches_timed": len(sel),
                            "note": "literal size: 32 MB fits the 256 MiB Infinity Cache and ~1 wave of workgroups; "
@@ -248,6 +308,17 @@ def main():
             del s2
             t.cuda.empty_cache()
         out["sweep"] = sweep
+        import alan_amd as alan
+        others = {}
+        for name, builder in (("bus_breakdown Y=2 B=3 I=150 (3 nested plates), K=30", build_bus_problem),
+                              ("timeseries Kalman T=1000, K=30", build_timeseries_problem)):
+            p2 = builder("cuda")
+            s2 = draw(p2, 30)
+            d_e, v_e = timed_evals(s2, alan.no_checkpoint, 20, 3, world)
+            d_g, v_g = timed_evals(s2, alan.no_checkpoint, 50, 3, world, graph=True)
+            others[name] = {"evals_per_s_eager": 20 / d_e, "evals_per_s_graph": 50 / d_g,
+                            "us_per_eval_graph": d_g / 50 * 1e6, "elbo": v_g}
+        out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
