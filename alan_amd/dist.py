@@ -257,9 +257,11 @@ def _as_dim(v, name, cache):
     if cache is None:
         return v.dim()
     key = (name, id(v))
-    if key not in cache:
-        cache[key] = v.dim()
-    return cache[key]
+    hit = cache.get(key)
+    if hit is None or hit[0] is not v:       # id() can be recycled once a PT dies: check identity
+        hit = (v, v.dim())
+        cache[key] = hit
+    return hit[1]
 
 
 class _DistSpec:

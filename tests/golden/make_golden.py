@@ -327,8 +327,18 @@ def capture_problem(tag, problem, K, strategies, seed, keep_calls=True, record_s
         else:
             e = sample.elbo_nograd(strat)
         rec["elbo"][sname] = e.detach().clone()
+    # gradients of the ELBO (detached sample, i.e. elbo_rws) wrt Q's raw optimisable parameters
+    opt = problem.Q._opt_params
+    if len(opt.keys):
+        for p in opt.parameters():
+            p.grad = None
+        sample.elbo_rws(alan.no_checkpoint).backward()
+        rec["rws_grads"] = {k: getattr(opt, k).grad.detach().clone() for k in opt.keys
+                            if getattr(opt, k).grad is not None}
+        for p in opt.parameters():
+            p.grad = None
     print(f"  {tag} K={K}: " + ", ".join(f"{k}={float(v):.6f}" for k, v in rec["elbo"].items()),
-          f"[{len(calls)} reduce_Ks calls]")
+          f"[{len(calls)} reduce_Ks calls]", f"[{len(rec.get('rws_grads', {}))} param grads]")
     return rec, [dict(model=tag, K=K, call=i, **c) for i, c in enumerate(calls)] if keep_calls else []
 
 

@@ -63,3 +63,37 @@ def test_graph_replay_equals_eager_and_sees_parameter_updates():
     split = alan.Split("plate_1", 38)
     a, b = sample.elbo_nograd(split), sample.elbo_nograd(split, graph=True)
     assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
+
+
+GRAD_CASES = [c for c in CASES if c[1] in ("model1", "movielens", "bus_breakdown")]
+
+
+def _check_rws_grads(fixture, model, split, device):
+    """d ELBO / d (raw Q parameters) through the whole path's backward (Sample.py:124-133 elbo_rws,
+    then .backward() as basic_runner.py:108-110 does) vs the reference's own autograd."""
+    fx = load_golden(fixture)
+    prob = models.BUILDERS[model](fx)
+    prob.to(device)
+    sample = models.sample_from_fixture(prob, fx, device)
+    store = prob.Q._opt_params
+    for strat in (alan.no_checkpoint, alan.checkpoint, split):
+        for p in prob.parameters():
+            p.grad = None
+        sample.elbo_rws(strat).backward()
+        for k, ref in fx["rws_grads"].items():
+            g = getattr(store, f"t_{k}").grad
+            assert g is not None, k
+            scale = float(ref.abs().max()) + 1e-6
+            t.testing.assert_close(g.cpu().double(), ref.double().reshape(g.shape), rtol=2e-3, atol=2e-4 * scale,
+                                   msg=lambda m: f"{k} under {type(strat).__name__}: {m}")
+
+
+@pytest.mark.parametrize("fixture,model,split", GRAD_CASES, ids=[c[0][4:-3] for c in GRAD_CASES])
+def test_rws_gradients_match_reference_host_logic(fixture, model, split, oracle_backend):
+    _check_rws_grads(fixture, model, split, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,model,split", GRAD_CASES, ids=[c[0][4:-3] for c in GRAD_CASES])
+def test_rws_gradients_match_reference_hip(fixture, model, split):
+    _check_rws_grads(fixture, model, split, "cuda")
