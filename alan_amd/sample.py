@@ -35,7 +35,8 @@ class _GraphedELBO:
             t.cuda.current_stream().wait_stream(side)
             t.cuda.synchronize()
             self.graph = t.cuda.CUDAGraph()
-            with t.cuda.graph(self.graph), t.no_grad():
+            # thread_local: a collective's watchdog thread must not invalidate the capture
+            with t.cuda.graph(self.graph, capture_error_mode="thread_local"), t.no_grad():
                 self.out = sample._elbo(sample.detached_sample, None, strategy)
         finally:
             N._TIMER[0] = timer

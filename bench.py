@@ -294,6 +294,18 @@ def main():
         out["producer"] = {"kernel": "alan::reduce_group_kernel<float, NORMAL> (fused Normal log-prob producer of F)",
                            "us_per_launch": sum(sel) / len(sel) * 1e3, "bytes_written": big,
                            "launches_timed": len(sel)}
+    if world > 1 and not args.no_extras:
+        # BASELINE config C4 in the same run: movielens K=100, plate_1 sharded over the ranks
+        s100 = draw(prob, 100)
+        st100 = strategy_for(world, 100)
+        try:
+            d100, v100 = timed_evals(s100, st100, 10, 2, world, graph=use_graph)
+            out["c4_movielens_K100"] = {"evals_per_s": 10 / d100, "ms_per_eval": d100 / 10 * 1e3, "elbo": v100,
+                                        "strategy": f"Split('plate_1', {st100.split_size}, shard=True)",
+                                        "note": "compare with sweep.K100 of the 1-GPU run (Split('plate_1', 38))"}
+        except Exception as e:
+            out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
+        del s100
     if rank == 0 and world == 1 and not args.no_extras:
         out["roofline_scaled"] = roofline_scaled(K)
         out["cpu_baseline"] = cpu_baseline(K)
