@@ -176,9 +176,10 @@ class BoundPlate(nn.Module):
     def _sample(self, K, reparam, sampler, all_platedims):
         assert isinstance(K, int) and isinstance(reparam, bool) and issubclass(sampler, Sampler)
         Kdims = self.plate.groupvarname2Kdim(K)
+        platenames_of = {id(d): n for n, d in all_platedims.items()}
+        ip = pt_tree(self.plate, self.inputs_params_flat_pt(all_platedims), platenames_of)
         with on_device(self.device):
-            tree = self.plate.sample(None, {}, self.inputs_params(all_platedims), [], all_platedims, Kdims,
-                                     sampler, reparam)
+            tree = self.plate.sample(None, {}, ip, [], all_platedims, Kdims, sampler, reparam)
         return tree, Kdims
 
     def sample(self, sample_size=1):
@@ -189,6 +190,7 @@ class BoundPlate(nn.Module):
         out = {}
         N = Dim("N", sample_size)
         for k, v in flatten_tree(tree).items():
+            v = v.dim()
             Ks = [d for d in dims_of(v) if d not in set(platedims)]
             v = v.order(*Ks) if Ks else v
             if sample_size > 1:

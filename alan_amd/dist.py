@@ -74,6 +74,10 @@ class TorchDimDist:
     def sample(self, reparam, sample_dims, sample_shape=()):
         """Sample with exactly the dims ``sample_dims`` (a superset of the parameters' dims) and the
         positional shape [*sample_shape, *batch, *event].  Returns a torchdim tensor."""
+        return self.sample_pt(reparam, sample_dims, sample_shape).dim()
+
+    def sample_pt(self, reparam, sample_dims, sample_shape=()):
+        """As ``sample`` but returns a PT (first-class dims leading: extra dims, then parameter dims)."""
         sample_dims = list(sample_dims)
         ids = [id(d) for d in sample_dims]
         if len(set(ids)) != len(ids):
@@ -87,8 +91,10 @@ class TorchDimDist:
         d = self._build(self.all_arg_ids)
         draw = d.rsample if reparam else d.sample
         x = draw(sample_shape=t.Size([*sample_shape, *[e.size for e in extra]]))
-        idx = (slice(None),) * len(sample_shape) + (*extra, *self.all_arg_dims)
-        return x[idx] if (extra or self.all_arg_dims) else x
+        ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)
+        if ns and nd:      # [sample_shape, dims, batch, event] -> [dims, sample_shape, batch, event]
+            x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
+        return PT(x, (*extra, *self.all_arg_dims))
 
     def log_prob_pt(self, x, dim_order=None):
         """log p(x) as a PT over (x's dims) U (parameter dims); positional sample/batch dims are summed
@@ -243,8 +249,9 @@ class Dist(nn.Module):
             kw[a] = val
         return TorchDimDist(self.dist, **kw)
 
-    def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm=None):
-        return self.tdd(scope).sample(reparam, [*active_platedims, K_dim], self.sample_shape)
+    def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm=None, dimcache=None):
+        """-> PT with dims {active plates, K_dim} (scope values may be PTs or torchdim tensors)."""
+        return self.tdd(scope, dimcache).sample_pt(reparam, [*active_platedims, K_dim], self.sample_shape)
 
     def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None):
         """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""

@@ -132,19 +132,22 @@ class Plate:
 
     # ---- sampling from this plate (as Q) --------------------------------------------------
     def sample(self, name, scope, inputs_params, active_platedims, all_platedims, groupvarname2Kdim,
-               sampler, reparam):
+               sampler, reparam, dimcache=None):
+        """Ancestral sampling of this plate (as Q): a tree of PTs (Plate.py:93-143)."""
         if name is not None:
             active_platedims = [*active_platedims, all_platedims[name]]
         scope = update_scope(scope, inputs_params)
+        dimcache = {} if dimcache is None else dimcache
         out = {}
         for kind, child, v in self.entries():
             if kind == "group":
-                drawn = sample_group(v, scope, active_platedims, groupvarname2Kdim[child], sampler, reparam)
+                drawn = sample_group(v, scope, active_platedims, groupvarname2Kdim[child], sampler, reparam,
+                                     dimcache)
                 out.update(drawn)
                 scope.update(drawn)
             elif kind == "plate":
                 out[child] = v.sample(child, scope, inputs_params.get(child, {}), active_platedims, all_platedims,
-                                      groupvarname2Kdim, sampler, reparam)
+                                      groupvarname2Kdim, sampler, reparam, dimcache)
         return out
 
 
@@ -158,18 +161,22 @@ def update_scope(scope, tree):
     return scope
 
 
-def sample_group(prog, scope, active_platedims, K_dim, sampler, reparam):
+def sample_group(prog, scope, active_platedims, K_dim, sampler, reparam, dimcache=None):
     """Draw every variable of one group with the group's K dim (dist.py:23-72): parents are first
-    re-indexed from their own K dims onto ``K_dim`` by the sampler (permutation / categorical)."""
+    re-indexed from their own K dims onto ``K_dim`` by the sampler (permutation / categorical).
+    scope values and results are PTs."""
+    from .dims import PT
     needed = {a for d in prog.values() for a in d.all_args} - set(prog) - {"prev"}
     for a in needed:
         if a not in scope:
             raise Exception(f"{a} is not in scope")
-    local = sampler.resample_scope({k: v for k, v in scope.items() if k in needed}, active_platedims, K_dim)
-    perm = sampler.perm(dims={K_dim, *active_platedims}, Kdim=K_dim)
+    local = sampler.resample_scope_pt({k: PT.of(v) for k, v in scope.items() if k in needed},
+                                      active_platedims, K_dim)
+    has_ts = any(isinstance(d, Timeseries) for d in prog.values())
+    perm = sampler.perm(dims={K_dim, *active_platedims}, Kdim=K_dim) if has_ts else None
     out = {}
     for var, dist in prog.items():
-        x = dist.sample(local, reparam, active_platedims, K_dim, perm)
+        x = PT.of(dist.sample(local, reparam, active_platedims, K_dim, perm, dimcache))
         local[var] = x
         out[var] = x
     return out

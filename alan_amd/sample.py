@@ -31,13 +31,13 @@ class _GraphedELBO:
             side.wait_stream(t.cuda.current_stream())
             with t.cuda.stream(side), t.no_grad():
                 for _ in range(2):                    # warm allocator / lazy init outside capture
-                    sample._elbo(sample.detached_sample, None, strategy)
+                    sample._elbo(sample._pt_detached, None, strategy)
             t.cuda.current_stream().wait_stream(side)
             t.cuda.synchronize()
             self.graph = t.cuda.CUDAGraph()
             # thread_local: a collective's watchdog thread must not invalidate the capture
             with t.cuda.graph(self.graph, capture_error_mode="thread_local"), t.no_grad():
-                self.out = sample._elbo(sample.detached_sample, None, strategy)
+                self.out = sample._elbo(sample._pt_detached, None, strategy)
         finally:
             N._TIMER[0] = timer
 
@@ -46,25 +46,42 @@ class _GraphedELBO:
         return self.out.clone()
 
 
+def _dim_tree(tree):
+    return {k: (_dim_tree(v) if isinstance(v, dict) else v.dim()) for k, v in tree.items()}
+
+
 class Sample:
+    """``sample`` is a plate-shaped tree whose leaves are torchdim tensors (the reference's format) or
+    PTs (what ``Problem.sample`` produces); internally everything is kept as PTs and the torchdim
+    views ``reparam_sample`` / ``detached_sample`` are built on first access."""
+
     def __init__(self, problem, sample, groupvarname2Kdim, sampler, reparam):
         self.problem = problem
         self.groupvarname2Kdim = groupvarname2Kdim
         self.sampler = sampler
         self.reparam = reparam
-        if reparam:
-            self.reparam_sample = sample
-            self.detached_sample = _detach_tree(sample)
-        else:
-            self.detached_sample = sample
-        self._pt_cache = {}
+        pt = _pt_tree(sample)
+        self._pt_detached = _detach_tree(pt) if reparam else pt
+        self._pt_reparam = pt if reparam else None
+        self._dim_views = {}
+
+    def _view(self, which):
+        if which not in self._dim_views:
+            self._dim_views[which] = _dim_tree(getattr(self, f"_pt_{which}"))
+        return self._dim_views[which]
+
+    @property
+    def detached_sample(self):
+        return self._view("detached")
+
+    @property
+    def reparam_sample(self):
+        if not self.reparam:
+            raise AttributeError("reparam_sample exists only for problem.sample(K, reparam=True)")
+        return self._view("reparam")
 
     def _as_pt(self, tree):
-        """torchdim sample tree -> PT tree, converted once per Sample (the trees are immutable)."""
-        key = id(tree)
-        if key not in self._pt_cache:
-            self._pt_cache[key] = _pt_tree(tree)
-        return self._pt_cache[key]
+        return tree
 
     @property
     def device(self):
@@ -112,11 +129,11 @@ class Sample:
         if not self.reparam:
             raise Exception("To compute the ELBO with the right gradients for VI you must construct a "
                             "reparameterised sample using `problem.sample(K, reparam=True)`")
-        return self._elbo(self.reparam_sample, None, computation_strategy)
+        return self._elbo(self._pt_reparam, None, computation_strategy)
 
     def elbo_rws(self, computation_strategy=checkpoint):
         """ELBO on the detached sample (gradients flow to parameters only, as RWS wants)."""
-        return self._elbo(self.detached_sample, None, computation_strategy)
+        return self._elbo(self._pt_detached, None, computation_strategy)
 
     def elbo_nograd(self, computation_strategy=checkpoint, graph=False):
         """The ELBO with no gradients.  ``graph=True`` (GPU only) captures the whole evaluation -- every
@@ -127,7 +144,7 @@ class Sample:
         if graph and self.device.type == "cuda":
             return self._graphed(computation_strategy)()
         with t.no_grad():
-            return self._elbo(self.detached_sample, None, computation_strategy)
+            return self._elbo(self._pt_detached, None, computation_strategy)
 
     def _graphed(self, computation_strategy):
         key = id(computation_strategy)
@@ -148,6 +165,6 @@ class Sample:
             Js.append(J)
             names.append((g, ds))
         extra = {f"__J_{g}": J[tuple(ds)] for J, (g, ds) in zip(Js, names)}
-        L = self._elbo(self.detached_sample, extra, computation_strategy)
+        L = self._elbo(self._pt_detached, extra, computation_strategy)
         grads = t.autograd.grad(L, Js)
         return {g: gr[tuple(ds)] for gr, (g, ds) in zip(grads, names)}

@@ -10,10 +10,39 @@ import torch as t
 
 from . import engine as E
 from .contract import logmeanexp_dims
-from .dims import PT, Dim, dims_of
+from .dims import PT, Dim, dims_of, pt_align
 
 
 class Sampler:
+    @classmethod
+    def resample_scope_pt(cls, scope, active_platedims, Kdim):
+        """PT version of ``resample_scope``: every parent variable (a PT carrying its own K dim) is
+        re-indexed along that K axis by an index tensor drawn by ``perm_pt`` and relabelled onto ``Kdim``;
+        variables of one Group share one index tensor (Sampler.py:86-115)."""
+        plates = {id(d) for d in active_platedims}
+        by_K, out = {}, {}
+        for name, p in scope.items():
+            Ks = [d for d in p.dims if id(d) not in plates]
+            assert len(Ks) <= 1, f"{name} carries several K dims: {Ks}"
+            if not Ks:
+                out[name] = p
+            else:
+                by_K.setdefault(id(Ks[0]), (Ks[0], {}))[1][name] = p
+        for K_var, group in by_K.values():
+            first = next(iter(group.values()))
+            for p in group.values():
+                assert set(p.ids) == set(first.ids)
+            ax = first.ids.index(id(K_var))
+            shape = list(first.x.shape[: len(first.dims)])
+            idx = cls.perm_pt(shape, ax, first.x.device)          # [*first-class shape], values in [0, K)
+            for name, p in group.items():
+                if p.ids != first.ids:                              # same dims, different storage order
+                    p = PT(pt_align(p, first.ids), first.dims)
+                ix = idx[(...,) + (None,) * p.n_pos].expand(p.x.shape) if p.n_pos else idx
+                x = t.gather(p.x, ax, ix)
+                out[name] = PT(x, (*p.dims[:ax], Kdim, *p.dims[ax + 1:]))
+        return out
+
     @classmethod
     def resample_scope(cls, scope, active_platedims, Kdim):
         by_K = {}
@@ -66,6 +95,10 @@ class PermutationSampler(SamplerMP):
     element of the other dims."""
 
     @staticmethod
+    def perm_pt(shape, axis, device):
+        return t.rand(shape, device=device).argsort(axis)
+
+    @staticmethod
     def perm(dims, Kdim):
         assert isinstance(dims, set) and isinstance(Kdim, Dim)
         others, sizes = _like(dims, Kdim)
@@ -78,6 +111,10 @@ class CategoricalSampler(SamplerMP):
     """Each child picks a parent particle uniformly at random (with replacement)."""
 
     @staticmethod
+    def perm_pt(shape, axis, device):
+        return t.randint(0, shape[axis], shape, device=device)
+
+    @staticmethod
     def perm(dims, Kdim):
         assert isinstance(dims, set) and isinstance(Kdim, Dim)
         others, sizes = _like(dims, Kdim)
@@ -86,6 +123,12 @@ class CategoricalSampler(SamplerMP):
 
 
 class IndependentSampler(Sampler):
+    @staticmethod
+    def perm_pt(shape, axis, device):
+        view = [1] * len(shape)
+        view[axis] = shape[axis]
+        return t.arange(shape[axis], device=device).view(view).expand(shape)
+
     @staticmethod
     def perm(dims, Kdim):
         return t.arange(Kdim.size, device=_device())

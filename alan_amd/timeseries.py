@@ -43,9 +43,11 @@ class Timeseries(nn.Module):
     def _at_time(scope, T_dim, time):
         return {k: (v.order(T_dim)[time] if T_dim in set(dims_of(v)) else v) for k, v in scope.items()}
 
-    def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm):
+    def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm, dimcache=None):
         """Roll the chain forward T steps; between steps the particles are re-paired by
-        ``timeseries_perm`` (one permutation of K per timestep), as Timeseries.py:89-123 does."""
+        ``timeseries_perm`` (one permutation of K per timestep), as Timeseries.py:89-123 does.
+        (Sequential over T on the host, in torchdim: sampling is not on the hot path.)"""
+        scope = {k: (v.dim() if isinstance(v, PT) else v) for k, v in scope.items()}
         *other, T_dim = active_platedims
         prev = scope[self.init]
         if set(dims_of(prev)) != {K_dim, *other}:
@@ -56,7 +58,7 @@ class Timeseries(nn.Module):
         for time in range(T_dim.size):
             local = self._at_time(scope, T_dim, time)
             local["prev"] = prev
-            x = self.trans.sample(local, reparam, other, K_dim, None)
+            x = self.trans.sample(local, reparam, other, K_dim, None).dim()
             steps.append(x.order(*order))
             if timeseries_perm is not None:
                 perm = timeseries_perm.order(T_dim)[time]
