@@ -243,19 +243,63 @@ class Dist(nn.Module):
         for a, name in self._names.items():
             kw[a] = scope[name]
         for a, (fn, argnames) in self._funcs.items():
-            val = fn(*[_as_dim(scope[n], n, dimcache) for n in argnames])
-            if not is_tensor(val):
-                raise Exception("Lambda on a distribution returned a non-Tensor")
-            kw[a] = val
+            kw[a] = call_model_lambda(fn, [(n, scope[n]) for n in argnames], dimcache)
         return TorchDimDist(self.dist, **kw)
 
     def sample(self, scope, reparam, active_platedims, K_dim, timeseries_perm=None, dimcache=None):
-        """-> PT with dims {active plates, K_dim} (scope values may be PTs or torchdim tensors)."""
-        return self.tdd(scope, dimcache).sample_pt(reparam, [*active_platedims, K_dim], self.sample_shape)
+        """-> PT with dims [active plates..., K_dim], stored contiguously in that order (so a Split
+        chunk of the plate is a contiguous slice).  scope values may be PTs or torchdim tensors."""
+        want = [*active_platedims, K_dim]
+        p = self.tdd(scope, dimcache).sample_pt(reparam, want, self.sample_shape)
+        ids = tuple(id(d) for d in want)
+        if p.ids != ids:
+            p = PT(pt_align(p, ids).contiguous(), want)
+        return p
 
     def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None):
         """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""
         return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order), None
+
+
+LAMBDA_BACKEND = "vmap"
+"""How model lambdas (``lambda z, x: z @ x``) see their arguments.
+
+"torchdim": functorch.dim tensors, as in the reference.  "vmap" (default): the same semantics --
+the lambda sees only the POSITIONAL dims of each argument, every first-class dim is mapped over --
+implemented as nested ``torch.vmap`` with an explicit nesting order (dims shared by most arguments
+outermost).  Besides skipping torchdim's Python dispatch, this makes the lowering independent of
+Dim creation order: under a Split, torchdim lowers movielens' ``z @ x`` to 19,000 separate 1x18
+dot products (300 us at K=100), nested vmap to one batched GEMM (10 us)."""
+
+
+def call_model_lambda(fn, named_args, dimcache=None):
+    vals = [v for _, v in named_args]
+    if LAMBDA_BACKEND != "vmap" or not all(isinstance(v, PT) for v in vals):
+        val = fn(*[_as_dim(v, n, dimcache) for n, v in named_args])
+        if not is_tensor(val):
+            raise Exception("Lambda on a distribution returned a non-Tensor")
+        return val
+    seen, count = {}, {}
+    for p in vals:
+        for d, i in zip(p.dims, p.ids):
+            seen.setdefault(i, d)
+            count[i] = count.get(i, 0) + 1
+    order = sorted(seen, key=lambda i: -count[i])                  # stable: ties keep first appearance
+    args = []
+    for p in vals:                                                 # present dims leading, in nesting order
+        pos = {i: k for k, i in enumerate(p.ids)}
+        perm = [pos[i] for i in order if i in pos]
+        x = p.x
+        if perm != list(range(len(perm))):
+            x = x.permute(*perm, *range(len(perm), x.ndim))
+        args.append(x)
+    f = fn
+    for i in reversed(order):
+        f = t.vmap(f, in_dims=tuple(0 if i in p.ids else None for p in vals))
+    val = f(*args)
+    if not isinstance(val, t.Tensor):
+        raise Exception("Lambda on a distribution returned a non-Tensor")
+    return PT(val, [seen[i] for i in order])
 
 
 def _as_dim(v, name, cache):
