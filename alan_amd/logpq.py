@@ -157,16 +157,13 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         total_logQ = lq if total_logQ is None else pt_add(total_logQ, lq)
     lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
     K = total_logQ.size_of(id(Kdim))
-    neg_q = PT(-(lq.x + math.log(K)), lq.dims)              # small: [plates, K]
-    # log P terms that are no bigger than Q's are folded into it; the big ones stay separate factors
-    n_q = neg_q.x.numel()
-    big = []
-    for lp in logPs:
-        if lp.x.numel() <= n_q:
-            neg_q = pt_add(neg_q, lp)
-        else:
-            big.append(lp)
-    factors = [*big, neg_q]
+    # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
+    # factors on the fly, so pre-adding them would only cost extra launches)
+    neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
+    logPs.sort(key=lambda p: -p.x.numel())
+    for lp in logPs[2:]:                       # large Groups: keep the factor count of the step small
+        neg_q = pt_add(neg_q, lp)
+    factors = [*logPs[:2], neg_q]
 
     if Kinits:
         for k in init_Ks:
