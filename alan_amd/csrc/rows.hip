@@ -46,8 +46,12 @@ struct RowsDesc {
 constexpr int ROWS_UNR = 8;
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // 16-byte loads in flight per thread (one slab <= 256*8*16 B = 32 KiB)
 
-template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN>
-__global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
+// PF = prefetch the next slab into registers while the current one is reduced (workgroups that walk a
+// chunk of the plate).  With one slab per workgroup (the literal movielens size: 1200 workgroups) the
+// staging registers are dead during the reduction, the kernel fits 5 workgroups per CU and the whole
+// grid is resident in a single round.
+template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN, bool PF>
+__global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const RowsDesc d) {
     extern __shared__ __align__(16) float lds[];
     constexpr int G = 1 << LOGG;
     const int t = threadIdx.x;
@@ -90,25 +94,33 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
         const int64_t a0 = e0 & ~(int64_t)3;
         const int n4 = ((int)(e0 - a0) + (int)nrows * L + 3) >> 2;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(d.F + a0);
-        if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the last one)
+        if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the very last one)
 #pragma unroll
             for (int u = 0; u < ROWS_UNR; ++u) {
-                const int i = u * 256 + t;
-                if (i < n4) v[u] = ROWS_NT ? __builtin_nontemporal_load(src + i) : src[i];   // read-once stream
+                // clamped, not predicated: straight-line loads with all 8 in flight (threads past the
+                // slab's end re-read its last 16 bytes)
+                const int i = min(u * 256 + t, n4 - 1);
+                v[u] = ROWS_NT ? __builtin_nontemporal_load(src + i) : src[i];   // read-once stream
+            }
+        }
+        // else: the 16-byte loads of the last slab would run past the tensor; slab_store copies it
+        // element-wise straight into LDS instead (no staging registers)
+    };
+    auto slab_store = [&](uint32_t p) {
+        const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
+        const int64_t a0 = e0 & ~(int64_t)3;
+        const int shift = (int)(e0 - a0);
+        const int n4 = (shift + (int)nrows * L + 3) >> 2;
+        if (a0 + 4 * (int64_t)n4 <= d.total) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+#pragma unroll
+            for (int u = 0; u < ROWS_UNR; ++u) {
+                const int i = min(u * 256 + t, n4 - 1);   // duplicates rewrite the same 16 bytes
+                dst[i] = v[u];
             }
         } else {
-#pragma unroll
-            for (int u = 0; u < ROWS_UNR; ++u) {
-                const int i = u * 256 + t;
-                if (i < n4) {
-                    const float *s = d.F + a0 + 4 * (int64_t)i;
-                    const int64_t left = d.total - (a0 + 4 * (int64_t)i);
-                    v[u].x = left > 0 ? s[0] : 0.f;
-                    v[u].y = left > 1 ? s[1] : 0.f;
-                    v[u].z = left > 2 ? s[2] : 0.f;
-                    v[u].w = left > 3 ? s[3] : 0.f;
-                }
-            }
+            const int n = (int)(d.total - a0);
+            for (int i = t; i < n; i += 256) lds[i] = d.F[a0 + i];
         }
     };
 
@@ -126,23 +138,21 @@ __global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
     };
 
     float acc = 0.f;
-    slab_fetch(p0);
-    shared_fetch(p0);
+    if (PF) {
+        slab_fetch(p0);
+        shared_fetch(p0);
+    }
     for (uint32_t p = p0; p < p1; ++p) {
+        if (!PF) {
+            slab_fetch(p);
+            shared_fetch(p);
+        }
         const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
         const int shift = (int)(e0 & 3);
-        const int n4 = (shift + (int)nrows * L + 3) >> 2;
-        {
-            f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
-#pragma unroll
-            for (int u = 0; u < ROWS_UNR; ++u) {
-                const int i = u * 256 + t;
-                if (i < n4) dst[i] = v[u];
-            }
-        }
+        slab_store(p);
         if (d.nshared > 0 && t < L) gs[t] = gnext;
         __syncthreads();
-        if (p + 1 < p1) {   // in flight while this slab is reduced
+        if (PF && p + 1 < p1) {   // in flight while this slab is reduced
             slab_fetch(p + 1);
             shared_fetch(p + 1);
         }
@@ -289,6 +299,7 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.P = nplate ? (uint32_t)c.ksize[0] : 1u;
     rp.NO = (uint32_t)(c.n_out / rp.P);
     rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
+    if (const char *e = getenv("ALAN_ROWS_LOGG")) rp.logG = std::max(rp.logG, std::min(3, atoi(e)));  // tuning knob
     int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
     if (const char *e = getenv("ALAN_ROWS_RBMAX")) rbmax = std::max(1, std::min(rbmax, atoi(e)));  // tuning knob
     rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
@@ -353,8 +364,11 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);
     ev.begin(stream);
-#define ALAN_ROWS4(MODE, G, V, R, GN) \
-    hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN>), grid, block, rp.lds_bytes, stream, d)
+#define ALAN_ROWS4(MODE, G, V, R, GN)                                                                    \
+    if (rp.p_chunk > 1)                                                                                  \
+        hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, true>), grid, block, rp.lds_bytes, stream, d); \
+    else                                                                                                 \
+        hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, false>), grid, block, rp.lds_bytes, stream, d)
 #define ALAN_ROWS3(MODE, G, V, R)                       \
     if (d.ngen > 0) ALAN_ROWS4(MODE, G, false, R, true); \
     else ALAN_ROWS4(MODE, G, V, R, false)

@@ -14,11 +14,13 @@ for M in (300, 300 * 64 if K <= 30 else 600):
     F = -0.5 * t.randn(M, K, K, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
     gz = -0.5 * t.randn(M, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
     cases[M] = [(F, ("m", "a", "b", "z")), (gz, ("m", "z"))]
-for rb in (256, 128, 64):
-    for blocks in (512, 1024, 2048, 4096, 8192):
+grid = [(256, b, 0) for b in (1024, 4096)] + [(128, b, 1) for b in (2048, 8192)] + \
+       [(64, b, 2) for b in (4096, 16384)] + [(32, b, 3) for b in (8192, 32768)]
+for rb, blocks, logg in grid:
         os.environ["ALAN_ROWS_RBMAX"] = str(rb)
         os.environ["ALAN_ROWS_BLOCKS"] = str(blocks)
-        line = f"RBMAX={rb:4d} BLOCKS={blocks:5d}"
+        os.environ["ALAN_ROWS_LOGG"] = str(logg)
+        line = f"RBMAX={rb:4d} BLOCKS={blocks:5d} LOGG={logg}"
         for M, fac in cases.items():
             for _ in range(3):
                 E.reduce_factors(fac, reduce=("z",), plate=("m",))
