@@ -8,10 +8,8 @@ import torch as t
 import torch.nn as nn
 
 from .dims import PT, Dim, dims_of, named_to_dim, dim_to_named
-from .dist import Dist
 from .model import Plate, check_name, flatten_tree, tensordict2tree
-from .samplers import PermutationSampler, Sampler, IndependentSampler, on_device
-from .timeseries import Timeseries
+from .samplers import PermutationSampler, Sampler, on_device
 
 
 class _NamedStore(nn.Module):

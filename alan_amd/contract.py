@@ -18,7 +18,7 @@ import torch as t
 
 from . import engine as E
 from . import native as N
-from .dims import Dim, check_dims, dims_of, is_dimtensor, unwrap, wrap, union_dims
+from .dims import Dim, check_dims, dims_of, unwrap, wrap, union_dims
 
 
 def _factors(lps):

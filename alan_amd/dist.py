@@ -14,7 +14,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, Dim, dims_of, is_dimtensor, is_tensor, pt_align, pt_order, sum_positional, union_dims
+from .dims import PT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 

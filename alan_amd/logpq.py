@@ -19,10 +19,9 @@ import torch as t
 import torch.utils.checkpoint
 
 from . import engine as E
-from . import native as N
-from .dims import PT, Dim, pt_add, pt_align
+from .dims import PT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
-from .split import Split, all_reduce_sum, checkpoint, no_checkpoint
+from .split import all_reduce_sum, no_checkpoint
 from .timeseries import Timeseries
 
 

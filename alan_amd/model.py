@@ -4,11 +4,7 @@ reference), plus sampling of a plate tree from Q.  A Plate is compiled once, at 
 ordered list of *entries* -- ("group", name, {var: Dist}) | ("data", name) | ("plate", name, Plate)
 -- which is what the sampling and log-prob recursions iterate over.
 """
-from typing import Optional
-
-import torch as t
-
-from .dims import Dim, dims_of, is_tensor
+from .dims import Dim, dims_of
 from .dist import Dist, _DistSpec
 from .timeseries import Timeseries
 

@@ -5,10 +5,9 @@
 """
 import torch as t
 
-from .dims import PT, dims_of, is_tensor, sum_positional
+from .dims import PT, sum_positional
 from .logpq import logPQ_plate
-from .model import tensordict2tree
-from .split import Split, checkpoint, no_checkpoint
+from .split import checkpoint
 
 
 def _detach_tree(tree):

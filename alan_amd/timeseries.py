@@ -7,8 +7,8 @@ reference).  Sampling is sequential over T on the host; ``log_prob`` produces th
 import torch as t
 import torch.nn as nn
 
-from .dims import PT, Dim, dims_of, is_tensor
-from .dist import Dist, _DistSpec
+from .dims import PT, Dim, dims_of
+from .dist import _DistSpec
 
 
 class Timeseries(nn.Module):
