@@ -7,7 +7,7 @@ import torch as t
 
 from .dims import PT, sum_positional
 from .logpq import logPQ_plate
-from .split import checkpoint
+from .split import checkpoint, no_checkpoint
 
 
 def _detach_tree(tree):
@@ -152,18 +152,79 @@ class Sample:
             cache[key] = _GraphedELBO(self, computation_strategy)
         return cache[key]
 
-    # ---- the path's backward in production use (Sample.py:208-272): posterior weights over K ----
-    def marginal_weights(self, computation_strategy=checkpoint):
-        """For each latent group, the posterior marginal over its K particles (and active plates):
-        d ELBO / d J for a zero source term J added as an extra log-factor on that group's dims."""
+    # ---- the path's backward in production use (Sample.py:208-346) ---------------------------------
+    def _marginal_idxs(self, joints, computation_strategy):
+        """{frozenset(groupvarnames): posterior weights over their K dims (and active plates)}: the
+        gradient of the ELBO wrt a zero source term J added as an extra log-factor."""
+        for joint in joints:
+            if not isinstance(joint, tuple):
+                raise Exception("Arguments to marginals must be a tuple of groupvarnames, representing joint "
+                                "marginal to evaluate")
+            if len(joint) < 2:
+                raise Exception("Arguments to marginals must be a tuple of groupvarnames of length 2 or above "
+                                "(as we're doing all the univariate marginals anyway")
+            for g in joint:
+                if g not in self.groupvarname2Kdim:
+                    raise Exception("Arguments provided to marginals must be groupvarnames, not varnames.")
+        keys = [frozenset([g]) for g in self.groupvarname2Kdim] + [frozenset(j) for j in joints]
         g2p = self.Q.groupvarname2platenames()
-        Js, names = [], []
-        for g, Kdim in self.groupvarname2Kdim.items():
-            ds = [Kdim, *[self.all_platedims[p] for p in g2p[g]]]
+        Js, dimss, extra = [], [], {}
+        for i, key in enumerate(keys):
+            gs = tuple(key)
+            plates = g2p[gs[0]]
+            for g in gs[1:]:
+                if set(g2p[g]) != set(plates):
+                    raise Exception("Trying to compute marginal for variables at different plates")
+            ds = [*[self.groupvarname2Kdim[g] for g in gs], *[self.all_platedims[p] for p in plates]]
             J = t.zeros([d.size for d in ds], device=self.device, requires_grad=True)
             Js.append(J)
-            names.append((g, ds))
-        extra = {f"__J_{g}": J[tuple(ds)] for J, (g, ds) in zip(Js, names)}
+            dimss.append(ds)
+            extra[f"__J{i}"] = PT(J, ds)
         L = self._elbo(self._pt_detached, extra, computation_strategy)
         grads = t.autograd.grad(L, Js)
-        return {g: gr[tuple(ds)] for gr, (g, ds) in zip(grads, names)}
+        return {key: g[tuple(ds)] for key, g, ds in zip(keys, grads, dimss)}
+
+    def marginal_weights(self, computation_strategy=checkpoint):
+        """Univariate posterior marginals, keyed by group name."""
+        return {next(iter(k)): v for k, v in self._marginal_idxs((), computation_strategy).items()}
+
+    def marginals(self, joints=(), computation_strategy=checkpoint):
+        """A ``Marginals`` object: all univariate marginals plus the requested joints (Sample.py:274-289)."""
+        from .model import flatten_tree
+        from .moments import Marginals
+        weights = self._marginal_idxs(tuple(joints), computation_strategy)
+        return Marginals(flatten_tree(self.detached_sample), weights, self.all_platedims, self._v2g())
+
+    def _moments_uniform_input(self, moms, computation_strategy=no_checkpoint):
+        """E[f(x)] for raw moments, as d ELBO / d J with the extra log-factor f(x) * J (Sample.py:291-346)."""
+        from .model import flatten_tree
+        from .moments import RawMoment
+        from .dims import dims_of
+        flat = flatten_tree(self.detached_sample)
+        plates = set(self.all_platedims.values())
+        Js, dimss, extra = [], [], {}
+        for i, (varnames, m) in enumerate(moms):
+            if not isinstance(m, RawMoment):
+                raise Exception("Moments in sample must be `RawMoment`s (i.e. you must be able to compute them "
+                                "as E[f(x)])")
+            xs = [flat[v] for v in varnames]
+            fx = m.f(*xs).detach()
+            ds = [d for d in dims_of(fx) if d in plates]
+            for x in xs:
+                assert {d for d in dims_of(x) if d in plates} <= set(ds)
+            J = t.zeros([*[d.size for d in ds], *fx.shape], device=self.device, requires_grad=True)
+            Js.append(J)
+            dimss.append(ds)
+            extra[f"__M{i}"] = fx * (J[tuple(ds)] if ds else J)
+        L = self._elbo(self._pt_detached, extra, computation_strategy)
+        grads = t.autograd.grad(L, Js)
+        return [(g[tuple(ds)] if ds else g) for g, ds in zip(grads, dimss)]
+
+    def _moments(self, *args, **kwargs):
+        from .moments import _MomentsAPI
+        return _MomentsAPI._moments(self, *args, **kwargs)
+
+    def moments(self, *args, **kwargs):
+        """``sample.moments('a', mean)`` / ``sample.moments([(('a',), mean), ...])`` -> named tensors."""
+        from .moments import _MomentsAPI
+        return _MomentsAPI.moments(self, *args, **kwargs)
