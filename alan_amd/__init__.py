@@ -15,6 +15,7 @@ from .dist import OptParam, QEMParam, TorchDimDist, new_dist
 from .bound import BoundPlate, Problem
 from .split import Split, no_checkpoint, checkpoint
 from .sample import Sample
+from .posterior import ImportanceSample
 from .moments import Marginals, RawMoment, CompoundMoment, mean, mean2, var, var_from_raw_moment
 from .contract import (reduce_Ks, collect_lps, logsumexp_sum, logsumexp_dims, logmeanexp_dims,
                        chain_logmmexp)

@@ -70,9 +70,12 @@ def _contract(lps, Ks, plate=()):
     return PT(out, dims)
 
 
-def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
-                 all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
-                 prev_lpq, dimcache=None):
+def plate_factors(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
+                  all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
+                  dimcache=None):
+    """All log-prob factors of one plate (lp_getter, logpq.py:257-332): extra factors, every latent group's
+    factors, data likelihoods and the fully-reduced results of the child plates.
+    Returns (platedim, active_platedims, scope, lps, Ks, K_currs, K_inits)."""
     assert isinstance(P, Plate) and isinstance(Q, Plate)
     platedim = None
     if name is not None:
@@ -107,6 +110,15 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
             K_currs.extend(k_ts)
             K_inits.extend(k_init)
     assert len(K_currs) == len(K_inits)
+    return platedim, active_platedims, scope, lps, Ks, K_currs, K_inits
+
+
+def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
+                 all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
+                 prev_lpq, dimcache=None):
+    platedim, active_platedims, scope, lps, Ks, K_currs, K_inits = plate_factors(
+        name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims, all_platedims,
+        groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy, dimcache)
 
     if name is None:
         return _contract(lps, Ks)

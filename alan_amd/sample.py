@@ -220,6 +220,25 @@ class Sample:
         grads = t.autograd.grad(L, Js)
         return [(g[tuple(ds)] if ds else g) for g, ds in zip(grads, dimss)]
 
+    def importance_sample(self, N, computation_strategy=checkpoint):
+        """N joint posterior samples over all combinations of the K particles (Sample.py:150-206).  For
+        moments prefer ``marginals()`` / ``moments()``: this adds sampling noise."""
+        from .dims import Dim
+        from .model import empty_tree
+        from .posterior import ImportanceSample, index_into_sample, logPQ_sample
+        N_dim = Dim("N", N)
+        problem = self.problem
+        with t.no_grad():
+            indices = logPQ_sample(
+                name=None, P=self.P.plate, Q=self.Q.plate, sample=self._pt_detached,
+                inputs_params=problem.inputs_params_pt(), data=problem.data_pt(),
+                extra_log_factors=empty_tree(self.P.plate), scope={}, active_platedims=[],
+                all_platedims=self.all_platedims, groupvarname2Kdim=self.groupvarname2Kdim,
+                varname2groupvarname=self._v2g(), sampler=self.sampler,
+                computation_strategy=computation_strategy, indices={}, N_dim=N_dim, N=N)
+            tree = index_into_sample(self._pt_detached, indices, self.groupvarname2Kdim, self._v2g())
+        return ImportanceSample(problem, tree, N_dim)
+
     def _moments(self, *args, **kwargs):
         from .moments import _MomentsAPI
         return _MomentsAPI._moments(self, *args, **kwargs)

@@ -95,3 +95,44 @@ def test_joint_marginals_and_errors(oracle_backend):
         sample.marginals(joints=[("a", "c")])          # variable name, not group name
     with pytest.raises(Exception):
         sample.moments("a", var)                       # compound moments need Marginals
+
+
+# ---------------------------------------------------------------------------------------------
+# importance_sample: N joint draws over the K particles.  `marginals.moments` is the exact moment under
+# that distribution, so the two must agree within 6 standard errors of the N-sample mean
+# (tests/test_problem_vs_itself.py:90-119 `test_moments_importance_sample`).
+def _importance(model, fixture, K, N, device, builder_fx=True):
+    fx = load_golden(fixture)
+    prob = models.BUILDERS[model](fx).to(device)
+    t.manual_seed(11)
+    sample = prob.sample(K, reparam=False) if model != "model1" else models.sample_from_fixture(prob, fx, device)
+    marg = sample.marginals()
+    isamp = sample.importance_sample(N)
+    names = {"linear_gaussian": ["a"], "linear_gaussian_latents": ["a", "z"], "model1": ["a", "b", "c", "d"]}[model]
+    for vn in names:
+        for m in (mean, mean2):
+            exact = marg._moments(vn, m)
+            est = isamp._moments(vn, m)
+            v = marg._moments(vn, alan.var_from_raw_moment(m))
+            ds = dims_of(exact)
+            if ds:
+                exact, est, v = exact.order(*ds), est.order(*ds), v.order(*ds)
+            bound = 6 * (v / N).sqrt() + 1e-4
+            assert bool(((est - exact).abs() < bound).all()), (vn, est, exact, bound)
+    dumped = isamp.dump()
+    assert all("N" in x.names for x in dumped.values())
+
+
+@pytest.mark.parametrize("model,fixture,K", [("linear_gaussian", "e2e_linear_gaussian.pt", 30),
+                                             ("linear_gaussian_latents", "e2e_linear_gaussian_latents.pt", 10),
+                                             ("model1", "e2e_model1.pt", 3)])
+def test_importance_sample_host_logic(model, fixture, K, oracle_backend):
+    _importance(model, fixture, K, 4000, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,fixture,K", [("linear_gaussian", "e2e_linear_gaussian.pt", 100),
+                                             ("linear_gaussian_latents", "e2e_linear_gaussian_latents.pt", 30),
+                                             ("model1", "e2e_model1.pt", 3)])
+def test_importance_sample_gpu(model, fixture, K):
+    _importance(model, fixture, K, 20000, "cuda")
