@@ -46,6 +46,58 @@ Set ``alan_amd.dist.VALIDATE_ARGS = True`` to get the reference's behaviour (exc
 parameters / samples)."""
 
 
+class _FusedNormalLogProb(t.autograd.Function):
+    """sum_event log N(value; loc, scale) over the cross product of the arguments' first-class dims.
+
+    forward : ONE HIP launch (alan_reduce mode NORMAL) -- the [.., K, K, K, event] broadcast of
+              TorchDimDist.py:127-162 is never materialised.
+    backward: closed-form contractions of the upstream gradient G (shaped like the output) with the
+              small arguments, as ``torch.einsum`` calls -- per-factor log-prob gradients stay on PyTorch,
+              but still without any event-sized broadcast:
+                d value = -(value * <G, w> - <G, loc*w>),  w = 1/scale^2
+                d loc   =  <G, value*w> - loc * <G, w>
+                d scale =  (<G, value^2> - 2 <G, value*loc> + <G, loc^2>) / scale^3 - <G> / scale
+              where <G, a*b> sums over every dim the result lacks."""
+
+    @staticmethod
+    def forward(ctx, spec, value, loc, scale):
+        from . import engine as E
+        vd, ld, sd, od = spec
+        out = E.normal_logprob((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd), od)
+        ctx.spec = spec
+        ctx.save_for_backward(value, loc, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        vd, ld, sd, od = ctx.spec
+        value, loc, scale = ctx.saved_tensors
+        letters = {}
+
+        def sub(dims, event=True):
+            return "".join(letters.setdefault(id(d), chr(ord("a") + len(letters))) for d in dims) + \
+                ("Z" if event else "")
+
+        nev = value.ndim - len(vd)
+        flat = lambda x, d: x.reshape(*x.shape[: len(d)], -1) if nev else x.unsqueeze(-1)
+        v, l, s = flat(value.detach(), vd), flat(loc.detach(), ld), flat(scale.detach(), sd)
+        g, V, L, S = sub(od, False), sub(vd), sub(ld), sub(sd)
+        w = 1.0 / (s * s)
+        es = lambda expr, *ops: t.einsum(expr, *ops)
+        gv = gl = gs = None
+        if ctx.needs_input_grad[1]:
+            gv = -(v * es(f"{g},{S}->{V}", G, w) - es(f"{g},{L},{S}->{V}", G, l, w))
+            gv = gv.reshape(value.shape)
+        if ctx.needs_input_grad[2]:
+            gl = es(f"{g},{V},{S}->{L}", G, v, w) - l * es(f"{g},{S}->{L}", G, w)
+            gl = gl.reshape(loc.shape)
+        if ctx.needs_input_grad[3]:
+            q = es(f"{g},{V}->{S}", G, v * v) - 2 * es(f"{g},{V},{L}->{S}", G, v, l) + es(f"{g},{L}->{S}", G, l * l)
+            gs = q / (s * s * s) - es(f"{g}->{sub(sd, False)}", G).unsqueeze(-1) / s
+            gs = gs.reshape(scale.shape)
+        return None, gv, gl, gs
+
+
 FUSE_NORMAL = True
 """Route gradient-free Normal log-probs on the GPU to the fused HIP producer kernel."""
 
@@ -106,10 +158,9 @@ class TorchDimDist:
         n_sample = x.n_pos - self.sample_batch_ndim - self.sample_event_ndim
         assert n_sample >= 0
         if self._fusable(x):
-            from . import engine as E
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
-            out = E.normal_logprob((x.x, x.dims), (loc.x, loc.dims), (scale.x, scale.dims), dims)
-            return PT(out, dims)
+            spec = (x.dims, loc.dims, scale.dims, tuple(dims))
+            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.x), dims)
         d = self._build(ids, n_sample)
         lp = d.log_prob(pt_align(x, ids))
         if lp.ndim > len(ids):
@@ -129,7 +180,9 @@ class TorchDimDist:
         if not all(v.is_cuda and v.dtype in (t.float32, t.float64) for v in ts):
             return False
         if t.is_grad_enabled() and any(v.requires_grad for v in ts):
-            return False
+            # the backward (einsum contractions) needs one common event shape
+            ev = [tuple(v.shape[len(p.dims):]) for v, p in zip(ts, (x, self.kwargs["loc"], self.kwargs["scale"]))]
+            return ev[0] == ev[1] == ev[2]
         return True
 
 
