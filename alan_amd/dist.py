@@ -141,8 +141,16 @@ class TorchDimDist:
         have = set(self.all_arg_ids)
         extra = [d for d in sample_dims if id(d) not in have]
         d = self._build(self.all_arg_ids)
-        draw = d.rsample if reparam else d.sample
-        x = draw(sample_shape=t.Size([*sample_shape, *[e.size for e in extra]]))
+        shape = t.Size([*sample_shape, *[e.size for e in extra]])
+        if reparam:
+            x = d.rsample(shape)
+        elif self.dist.has_rsample:
+            # same distribution as .sample(), but e.g. Normal.sample() calls torch.normal(mean, std), whose
+            # std >= 0 check synchronises with the device and cannot be captured into a HIP graph
+            with t.no_grad():
+                x = d.rsample(shape)
+        else:
+            x = d.sample(shape)
         ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)
         if ns and nd:      # [sample_shape, dims, batch, event] -> [dims, sample_shape, batch, event]
             x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))

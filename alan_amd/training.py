@@ -1,0 +1,52 @@
+"""
+HIP-graph replay of a whole training iteration -- the loop of examples/basic_runner.py:81-112 of the
+reference (``sample = prob.sample(K)`` -> ``elbo_vi | elbo_rws`` -> ``(-elbo).backward()`` -> ``opt.step()``).
+
+Eagerly an iteration is a few milliseconds of Python driving ~150 small kernels; captured once, every
+later iteration is one graph launch: fresh particles are drawn each replay (PyTorch registers the
+generator's Philox state with the graph), the forward and backward alan_reduce launches, the fused
+producers and the optimizer update all replay on the device.
+"""
+import torch as t
+
+from .split import no_checkpoint
+
+
+class GraphedStep:
+    """``step = GraphedStep(problem, K, optimizer, method="vi"); elbo = step()``.
+
+    The optimizer must be graph-capturable (e.g. ``torch.optim.Adam(..., capturable=True)``); parameters
+    are updated in place, so ``problem`` can be used normally between / after steps.  As in the
+    reference's runner, "rws" expects an optimizer over ``problem.Q.parameters()`` built with
+    ``maximize=True`` (the loss is ``-elbo`` for both methods)."""
+
+    def __init__(self, problem, K, optimizer, method="vi", computation_strategy=no_checkpoint, warmup=3):
+        if method not in ("vi", "rws"):
+            raise Exception("method must be 'vi' or 'rws'")
+        if problem.device.type != "cuda":
+            raise Exception("GraphedStep needs the Problem on the GPU")
+        self.problem, self.K, self.opt, self.method = problem, K, optimizer, method
+        self.strategy = computation_strategy
+        side = t.cuda.Stream()
+        side.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(side):
+            for _ in range(warmup):                    # allocator / lazy-init warm-up outside capture
+                self._iteration()
+        t.cuda.current_stream().wait_stream(side)
+        t.cuda.synchronize()
+        self.graph = t.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with t.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.elbo = self._iteration()
+
+    def _iteration(self):
+        self.opt.zero_grad(set_to_none=True)
+        sample = self.problem.sample(self.K, reparam=(self.method == "vi"))
+        elbo = sample.elbo_vi(self.strategy) if self.method == "vi" else sample.elbo_rws(self.strategy)
+        (-elbo).backward()
+        self.opt.step()
+        return elbo.detach()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.elbo
