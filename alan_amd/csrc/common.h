@@ -1,6 +1,7 @@
 // Shared host/device helpers for libalan_mi355 (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "alan_mi355.h"
 

@@ -164,17 +164,15 @@ int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev
     const size_t lds = ((size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep) * sizeof(float);
     if (lds > 64 * 1024) return ALAN_ERR_UNSUPPORTED;
 
-    ev.begin(stream);
     const dim3 grid(gx, gy), block(256);
     if (d.Ep <= 8)
-        hipLaunchKernelGGL(normal_outer_kernel<8>, grid, block, lds, stream, d);
+        hipExtLaunchKernelGGL(normal_outer_kernel<8>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     else if (d.Ep <= 16)
-        hipLaunchKernelGGL(normal_outer_kernel<16>, grid, block, lds, stream, d);
+        hipExtLaunchKernelGGL(normal_outer_kernel<16>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     else if (d.Ep <= 32)
-        hipLaunchKernelGGL(normal_outer_kernel<32>, grid, block, lds, stream, d);
+        hipExtLaunchKernelGGL(normal_outer_kernel<32>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     else
-        hipLaunchKernelGGL(normal_outer_kernel<64>, grid, block, lds, stream, d);
-    ev.end(stream);
+        hipExtLaunchKernelGGL(normal_outer_kernel<64>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 

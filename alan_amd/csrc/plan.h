@@ -53,9 +53,15 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
                  const alan_tensor_t &out, Canon &c, uint32_t plate_mask = 0,
                  const alan_tensor_t *lse_out = nullptr);
 
+// Optional hipEvent pair (alan_reduce_desc_t.ev_*): handed to hipExtLaunchKernelGGL for the dominant kernel
+// of a call, so the events carry that kernel's own start / stop timestamps (what rocprofv3 reports).
+struct EvPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
 int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl);
 
-int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream);
+int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream,
+                 const EvPair &ev = EvPair());
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
 // fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the
@@ -68,12 +74,6 @@ struct RowsPlan {
     bool rot = false, vec2 = false;
 };
 RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype);
-// Optional hipEvent pair recorded around the dominant kernel of a call (alan_reduce_desc_t.ev_*).
-struct EvPair {
-    hipEvent_t start = nullptr, stop = nullptr;
-    void begin(hipStream_t s) const { if (start) (void)hipEventRecord(start, s); }
-    void end(hipStream_t s) const { if (stop) (void)hipEventRecord(stop, s); }
-};
 int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
                 size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 

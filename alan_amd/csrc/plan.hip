@@ -227,10 +227,7 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     GroupLaunch gl;
     rc = plan_group(c, out.dtype, add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
-    ev.begin(stream);
-    rc = launch_group(gd, gl, mode, compute, stream);
-    ev.end(stream);
-    return rc;
+    return launch_group(gd, gl, mode, compute, stream, ev);
 }
 
 // The fused plan for "log-sum-exp over REDUCE then sum over PLATE", if the rows kernel can take it.

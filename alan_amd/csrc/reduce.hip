@@ -132,23 +132,26 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
 }
 
 template <typename T, int MODE>
-static int launch_group_T(const GroupDesc &gd, const GroupLaunch &gl, hipStream_t stream) {
+static int launch_group_T(const GroupDesc &gd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.block) {
-        hipLaunchKernelGGL((reduce_group_kernel<T, MODE, true>), dim3(gl.grid), dim3(256), 0, stream, gd, 8);
+        hipExtLaunchKernelGGL((reduce_group_kernel<T, MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+                              ev.stop, 0, gd, 8);
     } else {
-        hipLaunchKernelGGL((reduce_group_kernel<T, MODE, false>), dim3(gl.grid), dim3(256), 0, stream, gd, gl.logG);
+        hipExtLaunchKernelGGL((reduce_group_kernel<T, MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+                              ev.stop, 0, gd, gl.logG);
     }
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
-int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream) {
+int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream,
+                 const EvPair &ev) {
     if (gd.n_out == 0) return ALAN_OK;
 #define ALAN_DISPATCH(T)                                                              \
     switch (mode) {                                                                   \
-        case ALAN_MODE_LSE: return launch_group_T<T, ALAN_MODE_LSE>(gd, gl, stream);  \
-        case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream);  \
-        case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream); \
-        case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream); \
+        case ALAN_MODE_LSE: return launch_group_T<T, ALAN_MODE_LSE>(gd, gl, stream, ev);  \
+        case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream, ev);  \
+        case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream, ev); \
+        case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
     }
     if (compute_dtype == ALAN_F32) {
         ALAN_DISPATCH(float)

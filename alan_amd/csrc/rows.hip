@@ -363,12 +363,13 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);
-    ev.begin(stream);
 #define ALAN_ROWS4(MODE, G, V, R, GN)                                                                    \
     if (rp.p_chunk > 1)                                                                                  \
-        hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, true>), grid, block, rp.lds_bytes, stream, d); \
+        hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, true>), grid, block, rp.lds_bytes, stream, ev.start, \
+                              ev.stop, 0, d); \
     else                                                                                                 \
-        hipLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, false>), grid, block, rp.lds_bytes, stream, d)
+        hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, false>), grid, block, rp.lds_bytes, stream, ev.start, \
+                              ev.stop, 0, d)
 #define ALAN_ROWS3(MODE, G, V, R)                       \
     if (d.ngen > 0) ALAN_ROWS4(MODE, G, false, R, true); \
     else ALAN_ROWS4(MODE, G, V, R, false)
@@ -388,7 +389,6 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
         else { ALAN_ROWS2(ALAN_MODE_SUM, false, false) }
     }
 #undef ALAN_ROWS4
-    ev.end(stream);
 #undef ALAN_ROWS2
 #undef ALAN_ROWS3
     if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
