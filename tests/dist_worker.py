@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rank, world, port, fixture, model, platename, split_size, out_path):
+def run(rank, world, port, fixture, model, platename, split_size, out_path, device="cpu"):
     import torch as t
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -20,10 +20,12 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path):
         from oracle import backend
         t.set_num_threads(2)
         fx = load_golden(fixture)
-        prob = models.BUILDERS[model](fx)
-        sample = models.sample_from_fixture(prob, fx, "cpu")
+        prob = models.BUILDERS[model](fx).to(device)
+        sample = models.sample_from_fixture(prob, fx, device)
         strat = alan.Split(platename, split_size, shard=True)
-        with backend.installed():
+        import contextlib
+        # CPU ranks: test-only oracle backend; GPU ranks: the real HIP library (gloo moves the partials)
+        with (backend.installed() if device == "cpu" else contextlib.nullcontext()):
             assert strat.sharded()
             n_chunks = len(alan.split.chunk_sizes(prob.all_platedims[platename].size, split_size))
             mine = list(strat.my_chunks(n_chunks))

@@ -41,3 +41,19 @@ def test_sharded_split_world2(fixture, model, plate, size):
     # the chunks were really partitioned
     all_chunks = sorted(c for r in res for c in r["chunks"])
     assert all_chunks == list(range(len(all_chunks))) and all(len(r["chunks"]) >= 1 for r in res)
+
+
+@pytest.mark.gpu
+def test_sharded_split_world2_on_gpu():
+    """Two ranks sharing cuda:0 (gloo carries the [K,K] partials): the sharded plate runs the real HIP
+    kernels on each rank's chunk; every rank ends with the reference's full-plate ELBO and gradients."""
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res")
+        mp.spawn(dist_worker.run, args=(world, _free_port(), "e2e_movielens_K10.pt", "movielens", "plate_1", 150,
+                                        out, "cuda"), nprocs=world, join=True)
+        res = [t.load(f"{out}.{r}") for r in range(world)]
+    for r in res:
+        assert abs(r["elbo"] - r["ref"]) <= 1e-4 * abs(r["ref"]) + 1e-5, r
+        assert r["grad_err"] < 5e-2, r
+    assert res[0]["elbo"] == res[1]["elbo"]
