@@ -110,3 +110,45 @@ def test_neg_inf_and_nan_rows():
     assert t.isnan(got[2]) and t.isnan(ref[2])
     assert t.isnan(got[3]) and t.isnan(ref[3])
     t.testing.assert_close(got[[1] + list(range(4, A))], ref[[1] + list(range(4, A))], rtol=3e-5, atol=3e-5)
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes
+def _sml(M, K, seed):
+    g = t.Generator().manual_seed(seed)
+    F = -0.5 * t.randn(M, K, K, K, generator=g) ** 2 - 0.9189 - math.log(K)
+    gz = -0.5 * t.randn(M, K, generator=g) ** 2 - 0.9189 - math.log(K)
+    return F, gz
+
+
+@pytest.mark.parametrize("M,K", [(300, 30), (38, 100)], ids=["C2-movielens-K30-M300", "C4-chunk-K100-M38"])
+def test_full_size_against_oracle_and_properties(M, K):
+    """The plate step at the sizes BASELINE.json names (C2: F[300,30,30,30] = 32 MB; one C4 chunk:
+    F[38,100,100,100] = 152 MB): direct comparison with the CPU oracle, plus size-independent
+    properties -- Split chunks sum to the whole plate (logpq.py:151-153), a constant added to a factor
+    shifts the result by M*c, permuting the plate leaves the result unchanged, LSE >= max."""
+    F, gz = _sml(M, K, 7)
+    dims = (("m", "a", "b", "z"), ("m", "z"))
+    ref = orc.plate_sum(orc.logsumexp_sum(("z",), (F, dims[0]), (gz, dims[1])), "m")
+    Fd, gd = F.to(DEV), gz.to(DEV)
+    out, od = E.reduce_factors([(Fd, dims[0]), (gd, dims[1])], reduce=("z",), plate=("m",))
+    _cmp(out, od, ref[0], ref[1], rtol=2e-5, atol=2e-3)
+    # chunks of the plate sum to the whole
+    acc, start = None, 0
+    for n in orc.split_sizes(M, max(2, M // 8 + 1)):
+        part, pd = E.reduce_factors([(Fd[start:start + n], dims[0]), (gd[start:start + n], dims[1])],
+                                    reduce=("z",), plate=("m",))
+        acc = part if acc is None else acc + part
+        start += n
+    t.testing.assert_close(acc, out, rtol=1e-5, atol=2e-3)
+    # shift by a constant
+    shifted, _ = E.reduce_factors([(Fd, dims[0]), (gd + 0.25, dims[1])], reduce=("z",), plate=("m",))
+    t.testing.assert_close(shifted, out + 0.25 * M, rtol=1e-5, atol=2e-3)
+    # plate permutation invariance
+    perm = t.randperm(M, generator=t.Generator().manual_seed(1)).to(DEV)
+    permuted, _ = E.reduce_factors([(Fd[perm].contiguous(), dims[0]), (gd[perm].contiguous(), dims[1])],
+                                   reduce=("z",), plate=("m",))
+    t.testing.assert_close(permuted, out, rtol=1e-5, atol=2e-3)
+    # per-row bound: LSE over z >= max over z  (unfused call)
+    rows, rd = E.reduce_factors([(Fd, dims[0]), (gd, dims[1])], reduce=("z",))
+    mx = (Fd + gd[:, None, None, :]).amax(-1)
+    assert bool((orc.align((rows.cpu(), rd), ("m", "a", "b")) >= mx.cpu() - 1e-5).all())
