@@ -6,7 +6,7 @@ Top-down over the plate tree.  At each plate the factors are gathered exactly as
 plates fully reduced on the HIP engine), indexed with the K indices already drawn higher up, and the
 plate's own K dims are then drawn by walking the elimination steps of ``engine.contract`` BACKWARDS:
 the factors of a step, conditioned on everything sampled so far, are a categorical over the K dims that
-step eliminated.  Timeseries K dims (sample_Ks_timeseries, reduce_Ks.py:85-232) are not implemented.
+step eliminated.  Timeseries K dims are drawn by a filter / sample pass over T (``sample_Ks_timeseries``).
 """
 import torch as t
 
@@ -79,6 +79,39 @@ def sample_Ks(lps, Ks, N_dim, N):
     return indices
 
 
+def sample_Ks_timeseries(lps, Ks, K_currs, K_inits, T_dim, indices, N_dim, N):
+    """Posterior draw of a timeseries variable's K index at every timestep (role of
+    sample_Ks_timeseries, reduce_Ks.py:85-232) by forward-filtering / backward-sampling in the
+    reversed direction: backward messages beta_t[a] = LSE_b(M_{t+1}[a,b] + beta_{t+1}[b]) (one alan_reduce
+    per step), then k_t ~ softmax_b(M_t[k_{t-1}, b] + beta_t[b]) forwards from the already-sampled
+    initial-state index.  O(T K^2) instead of the reference's O(T^2) chain evaluations."""
+    if len(Ks) or len(K_currs) != 1:
+        raise NotImplementedError("alan_amd: a timeseries plate with further latent groups cannot be "
+                                  "posterior-sampled yet")
+    K_cur, K_init = K_currs[0], K_inits[0]
+    assert id(K_init) in indices, "the initial state must have been sampled in the parent plate"
+    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], ())
+    lp = PT(out, dims)
+    want = (id(T_dim), id(K_init), id(K_cur))
+    if set(lp.ids) != set(want):
+        raise NotImplementedError("alan_amd: timeseries plates nested under other K/plate dims are not supported")
+    ms = pt_align(lp, want).contiguous()                         # [T, K_prev, K]
+    T, K = ms.shape[0], ms.shape[2]
+    beta = [None] * (T + 1)
+    beta[T] = t.zeros(K, dtype=ms.dtype, device=ms.device)
+    for step in range(T - 1, 0, -1):
+        beta[step], _ = E.reduce_factors([(ms[step], ("a", "b")), (beta[step + 1], ("b",))], reduce=("b",))
+    prev = pt_align(indices[id(K_init)][1], (id(N_dim),))        # [N] indices of the initial state
+    assert prev.ndim == 1
+    draws = []
+    for step in range(T):
+        logits = ms[step][prev] + beta[step + 1]                 # [N, K]
+        probs = (logits - logits.amax(-1, keepdim=True)).exp()
+        prev = t.multinomial(probs, 1, replacement=True).squeeze(-1)
+        draws.append(prev)
+    return {id(K_cur): (K_cur, PT(t.stack(draws, 1), (N_dim, T_dim)))}
+
+
 def logPQ_sample(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
                  all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
                  indices, N_dim, N):
@@ -86,7 +119,8 @@ def logPQ_sample(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims, all_platedims,
         groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy, {})
     if K_currs:
-        raise NotImplementedError("alan_amd: posterior sampling of Timeseries K dims is not implemented")
+        indices = {**indices, **sample_Ks_timeseries(lps, Ks, K_currs, K_inits, platedim, indices, N_dim, N)}
+        Ks = ()
     lps = _index_all(lps, indices)
     if Ks:
         indices = {**indices, **sample_Ks(lps, Ks, N_dim, N)}

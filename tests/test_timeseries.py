@@ -94,3 +94,46 @@ def test_timeseries_T1000_K30_runs_and_matches_oracle_chain():
     with backend.installed():
         cpu = float(cs.elbo_nograd(alan.no_checkpoint))
     assert abs(gpu - cpu) <= 1e-4 * abs(cpu) + 1e-3, (gpu, cpu)
+
+
+def _ts_posterior_check(device, K, N):
+    """Timeseries posterior: marginals (chain backward) and importance samples (sample_Ks_timeseries) vs
+    each other and vs the closed-form Kalman smoother mean (tests/timeseries.py:52-56 of the reference)."""
+    from alan_amd import mean
+    from alan_amd.dims import dims_of
+    T = 4
+    prob, _ = kalman_problem(T)
+    prob.to(device)
+    y = prob._data.to_dict()["obs"].rename(None).double().cpu()
+    cov = t.zeros(T, T, dtype=t.float64)
+    var = INIT_SCALE ** 2
+    for i in range(T):
+        var = var * A ** 2 + NOISE ** 2
+        fut = var * A ** t.arange(T - i, dtype=t.float64)
+        cov[i, i:] = fut
+        cov[i:, i] = fut
+    post_cov = t.inverse(t.inverse(cov) + t.eye(T, dtype=t.float64) / OBS ** 2)
+    post_mean = post_cov @ (y / OBS ** 2)
+    t.manual_seed(3)
+    sample = prob.sample(K, reparam=False)
+    marg = sample.marginals()
+    m_ts = marg._moments("ts", mean)
+    v_ts = marg._moments("ts", alan.var_from_raw_moment(mean))
+    (Td,) = dims_of(m_ts)
+    m_ts, v_ts = m_ts.order(Td).cpu().double(), v_ts.order(Td).cpu().double()
+    ess = marg.min_ess()
+    assert bool(((m_ts - post_mean).abs() < 7 * (v_ts / ess).sqrt() + 0.05).all()), (m_ts, post_mean, ess)
+    isamp = sample.importance_sample(N)
+    est = isamp._moments("ts", mean).order(Td).cpu().double()
+    assert bool(((est - m_ts).abs() < 6 * (v_ts / N).sqrt() + 1e-3).all()), (est, m_ts)
+    d = isamp.dump()["ts"]
+    assert set(d.names) == {"N", "T"}
+
+
+def test_timeseries_posterior_host_logic(oracle_backend):
+    _ts_posterior_check("cpu", 60, 4000)
+
+
+@pytest.mark.gpu
+def test_timeseries_posterior_gpu():
+    _ts_posterior_check("cuda", 300, 20000)
