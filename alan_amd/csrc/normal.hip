@@ -27,7 +27,6 @@ struct NormalDesc {
     int64_t v_vs[MAXD], v_os[MAXD];   // value / out strides over the value's keep dims
     int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
     int64_t l_os, s_os;               // out strides along the loc / scale dims
-    int32_t dbg;                      // tuning-only: 1 = no stores, 2 = no arithmetic
 };
 
 template <int EMAX>
@@ -41,23 +40,24 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     const uint32_t l0 = blockIdx.y * d.l_chunk;
     const uint32_t l1 = min(d.NL, l0 + d.l_chunk);
 
-    // ---- workgroup-uniform tables (one pass over the scale rows: w = 0.5/sigma^2 and, by LDS float
-    //      atomics, lg[s] = sum_e log sigma + E log sqrt(2 pi))
-    for (uint32_t is = tid; is < d.NS; is += 256) lg[is] = (float)E * 0.91893853320467274178f;
-    for (uint32_t i = tid; i < (l1 - l0) * (uint32_t)Ep; i += 256) {
-        const uint32_t il = i / Ep, e = i - il * Ep;
-        mu[i] = (int)e < E ? d.loc[(int64_t)(l0 + il) * d.l_rs + e] : 0.f;
-    }
-    __syncthreads();
+    // ---- workgroup-uniform tables
     for (uint32_t i = tid; i < d.NS * (uint32_t)Ep; i += 256) {
         const uint32_t is = i / Ep, e = i - is * Ep;
         float v = 0.f;
         if ((int)e < E) {
             const float sc = d.scl[(int64_t)is * d.s_rs + e];
             v = 0.5f / (sc * sc);
-            atomicAdd(&lg[is], __logf(sc));
         }
         w[i] = v;
+    }
+    for (uint32_t is = tid; is < d.NS; is += 256) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s += logf(d.scl[(int64_t)is * d.s_rs + e]);
+        lg[is] = s + (float)E * 0.91893853320467274178f;
+    }
+    for (uint32_t i = tid; i < (l1 - l0) * (uint32_t)Ep; i += 256) {
+        const uint32_t il = i / Ep, e = i - il * Ep;
+        mu[i] = (int)e < E ? d.loc[(int64_t)(l0 + il) * d.l_rs + e] : 0.f;
     }
 
     // ---- this thread's value row
@@ -80,10 +80,6 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     __syncthreads();
 
     for (uint32_t il = l0; il < l1; ++il) {
-        if (d.dbg == 3) {   // tuning-only: prologue cost
-            if (active && v[0] == 12345.678f) d.out[ooff] = v[1];
-            break;
-        }
         const float4 *m4 = reinterpret_cast<const float4 *>(mu + (size_t)(il - l0) * Ep);
         float dd[EMAX];
 #pragma unroll
@@ -102,150 +98,17 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
         for (uint32_t is = 0; is < d.NS; ++is) {
             const float4 *w4 = reinterpret_cast<const float4 *>(w + (size_t)is * Ep);
             float acc = 0.f;
-            if (d.dbg != 2) {
 #pragma unroll
-                for (int q = 0; q < EMAX / 4; ++q) {
-                    if (q * 4 < Ep) {
-                        const float4 ww = w4[q];
-                        acc = fmaf(dd[4 * q], ww.x, acc);
-                        acc = fmaf(dd[4 * q + 1], ww.y, acc);
-                        acc = fmaf(dd[4 * q + 2], ww.z, acc);
-                        acc = fmaf(dd[4 * q + 3], ww.w, acc);
-                    }
+            for (int q = 0; q < EMAX / 4; ++q) {
+                if (q * 4 < Ep) {
+                    const float4 ww = w4[q];
+                    acc = fmaf(dd[4 * q], ww.x, acc);
+                    acc = fmaf(dd[4 * q + 1], ww.y, acc);
+                    acc = fmaf(dd[4 * q + 2], ww.z, acc);
+                    acc = fmaf(dd[4 * q + 3], ww.w, acc);
                 }
             }
-            if (d.dbg == 1) {
-                if (active && acc == 12345.678f) orow[(int64_t)is * d.s_os] = acc;
-            } else if (active) {
-                orow[(int64_t)is * d.s_os] = -acc - lg[is];
-            }
-        }
-    }
-}
-
-// Coalesced-store variant.  The plain kernel's per-thread scalar stores reach HBM as Vi-float (120-byte)
-// pieces and the kernel is store-ISSUE bound (25 us at K=30 for a 32 MB output).  When the scale dim and
-// the value's innermost dim are adjacent in the output (movielens: out[m, k_mu, (k_psi, k_z)] = 900
-// contiguous floats per (m, k_mu)), a workgroup instead takes RB = G*Vi value rows (G whole groups of the
-// innermost value dim), parks its results for one loc row in an LDS tile [NS][RB] and writes each group's
-// NS*Vi-float region with full-width 16-byte stores.
-struct NormalTWDesc {
-    NormalDesc b;
-    int32_t Vi, G, RB, nvo;        // innermost value dim, groups / rows per workgroup, outer value dims
-    FastDiv odiv[MAXD], vidiv;
-    int64_t o_vs[MAXD], o_os[MAXD];
-    int64_t vi_vs;                 // value stride of the innermost value dim
-    uint32_t NG;                   // number of groups = NV / Vi
-};
-
-template <int EMAX>
-__global__ __launch_bounds__(256) void normal_outer_tw_kernel(const NormalTWDesc D) {
-    const NormalDesc &d = D.b;
-    extern __shared__ __align__(16) float lds[];
-    const int E = d.E, Ep = d.Ep;
-    float *w = lds;                         // [NS][Ep]
-    float *lg = w + (size_t)d.NS * Ep;      // [NS]
-    float *mu = lg + ((d.NS + 3) & ~3u);    // [Ep]
-    float *tile = mu + Ep;                  // [NS][RB]
-    const int tid = threadIdx.x;
-    const int RB = D.RB, Vi = D.Vi;
-
-    for (uint32_t is = tid; is < d.NS; is += 256) lg[is] = (float)E * 0.91893853320467274178f;
-    __syncthreads();
-    for (uint32_t i = tid; i < d.NS * (uint32_t)Ep; i += 256) {
-        const uint32_t is = i / Ep, e = i - is * Ep;
-        float v = 0.f;
-        if ((int)e < E) {
-            const float sc = d.scl[(int64_t)is * d.s_rs + e];
-            v = 0.5f / (sc * sc);
-            atomicAdd(&lg[is], __logf(sc));
-        }
-        w[i] = v;
-    }
-
-    const uint32_t g0 = blockIdx.x * (uint32_t)D.G;
-    const uint32_t gl = fd_div((uint32_t)tid, D.vidiv);
-    const int vi = tid - (int)gl * Vi;
-    const bool active = tid < RB && (g0 + gl) < D.NG;
-    int64_t voff = 0;
-    {
-        uint32_t o = active ? g0 + gl : 0u;
-        for (int k = D.nvo - 1; k >= 0; --k) {
-            const uint32_t q = fd_div(o, D.odiv[k]);
-            voff += (int64_t)(o - q * D.odiv[k].d) * D.o_vs[k];
-            o = q;
-        }
-        voff += (int64_t)vi * D.vi_vs;
-    }
-    float v[EMAX];
-#pragma unroll
-    for (int e = 0; e < EMAX; ++e) v[e] = (active && e < E) ? d.val[voff + e] : 0.f;
-
-    const uint32_t l0 = blockIdx.y * d.l_chunk;
-    const uint32_t l1 = min(d.NL, l0 + d.l_chunk);
-    const int region4 = ((int)d.NS * Vi) >> 2;      // 16-byte pieces per (group, loc row)
-    for (uint32_t il = l0; il < l1; ++il) {
-        __syncthreads();                            // tables ready / previous tile drained
-        for (int e = tid; e < Ep; e += 256) mu[e] = e < E ? d.loc[(int64_t)il * d.l_rs + e] : 0.f;
-        __syncthreads();
-        float dd[EMAX];
-        const float4 *m4 = reinterpret_cast<const float4 *>(mu);
-#pragma unroll
-        for (int q = 0; q < EMAX / 4; ++q) {
-            if (q * 4 < Ep) {
-                const float4 m = m4[q];
-                const float a = v[4 * q] - m.x, b = v[4 * q + 1] - m.y, c = v[4 * q + 2] - m.z,
-                            e = v[4 * q + 3] - m.w;
-                dd[4 * q] = a * a;
-                dd[4 * q + 1] = b * b;
-                dd[4 * q + 2] = c * c;
-                dd[4 * q + 3] = e * e;
-            }
-        }
-        if (tid < RB) {
-            for (uint32_t is = 0; is < d.NS; ++is) {
-                const float4 *w4 = reinterpret_cast<const float4 *>(w + (size_t)is * Ep);
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < EMAX / 4; ++q) {
-                    if (q * 4 < Ep) {
-                        const float4 ww = w4[q];
-                        acc = fmaf(dd[4 * q], ww.x, acc);
-                        acc = fmaf(dd[4 * q + 1], ww.y, acc);
-                        acc = fmaf(dd[4 * q + 2], ww.z, acc);
-                        acc = fmaf(dd[4 * q + 3], ww.w, acc);
-                    }
-                }
-                tile[is * RB + tid] = -acc - lg[is];
-            }
-        }
-        __syncthreads();
-        // ---- write-out: group g -> out[group base + il*l_os + (is*Vi + x)], contiguous, 16 bytes per lane
-        for (int g = 0; g < D.G; ++g) {
-            if (g0 + g >= D.NG) break;
-            int64_t obase = (int64_t)il * d.l_os;
-            uint32_t o = g0 + g;
-            for (int k = D.nvo - 1; k >= 0; --k) {
-                const uint32_t q = fd_div(o, D.odiv[k]);
-                obase += (int64_t)(o - q * D.odiv[k].d) * D.o_os[k];
-                o = q;
-            }
-            float4 *dst = reinterpret_cast<float4 *>(d.out + obase);
-            const float *src = tile + g * Vi;
-            for (int f = tid; f < region4; f += 256) {
-                uint32_t is = fd_div((uint32_t)(4 * f), D.vidiv);
-                int x = 4 * f - (int)is * Vi;
-                float r[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    r[u] = src[is * RB + x];
-                    if (++x == Vi) {
-                        x = 0;
-                        ++is;
-                    }
-                }
-                dst[f] = make_float4(r[0], r[1], r[2], r[3]);
-            }
+            if (active) orow[(int64_t)is * d.s_os] = -acc - lg[is];
         }
     }
 }
@@ -293,62 +156,14 @@ int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev
     d.E = (int)E;
     d.Ep = (int)((E + 3) & ~3);
     d.NV = (uint32_t)NV;
-    if (const char *e = getenv("ALAN_NORMAL_DBG")) d.dbg = atoi(e);
-
-    // ---- coalesced-store variant: scale dim and innermost value dim adjacent in the output, every
-    //      (group, loc row) region 16-byte aligned
-    {
-        int vin = -1;
-        for (int j = 0; j < d.nv; ++j)
-            if (d.v_os[j] == 1) vin = j;
-        const int64_t Vi = vin >= 0 ? (int64_t)d.vdiv[vin].d : 0;
-        bool ok = vin >= 0 && nS == 1 && d.s_os == Vi && Vi <= 128 && (NV % Vi) == 0 && ((d.NS * Vi) % 4) == 0 &&
-                  (d.l_os % 4) == 0 && (reinterpret_cast<uintptr_t>(d.out) & 15) == 0;
-        for (int j = 0; j < d.nv && ok; ++j)
-            if (j != vin) ok = (d.v_os[j] % 4) == 0;
-        if (const char *e = getenv("ALAN_NORMAL_TW")) ok = ok && atoi(e) != 0;   // tuning knob
-        if (ok) {
-            NormalTWDesc D;
-            std::memset(&D, 0, sizeof(D));
-            D.b = d;
-            D.Vi = (int)Vi;
-            D.vidiv = make_fastdiv((uint32_t)Vi);
-            D.G = (int)std::max<int64_t>(1, 256 / Vi);
-            D.RB = D.G * D.Vi;
-            D.NG = (uint32_t)(NV / Vi);
-            D.vi_vs = d.v_vs[vin];
-            for (int j = 0; j < d.nv; ++j) {
-                if (j == vin) continue;
-                D.odiv[D.nvo] = d.vdiv[j];
-                D.o_vs[D.nvo] = d.v_vs[j];
-                D.o_os[D.nvo] = d.v_os[j];
-                ++D.nvo;
-            }
-            const uint32_t gx2 = (D.NG + D.G - 1) / D.G;
-            uint32_t gy2 = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 16384 / std::max(1u, gx2)));
-            if (const char *e = getenv("ALAN_NORMAL_GY")) gy2 = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));
-            D.b.l_chunk = (d.NL + gy2 - 1) / gy2;
-            gy2 = (d.NL + D.b.l_chunk - 1) / D.b.l_chunk;
-            const size_t lds2 = ((size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + d.Ep + (size_t)d.NS * D.RB) * sizeof(float);
-            if (lds2 <= 40 * 1024) {   // keep >= 4 workgroups per CU
-                const dim3 grid2(gx2, gy2), block2(256);
-                if (d.Ep <= 8)
-                    hipExtLaunchKernelGGL(normal_outer_tw_kernel<8>, grid2, block2, (uint32_t)lds2, stream, ev.start, ev.stop, 0, D);
-                else if (d.Ep <= 16)
-                    hipExtLaunchKernelGGL(normal_outer_tw_kernel<16>, grid2, block2, (uint32_t)lds2, stream, ev.start, ev.stop, 0, D);
-                else if (d.Ep <= 32)
-                    hipExtLaunchKernelGGL(normal_outer_tw_kernel<32>, grid2, block2, (uint32_t)lds2, stream, ev.start, ev.stop, 0, D);
-                else
-                    hipExtLaunchKernelGGL(normal_outer_tw_kernel<64>, grid2, block2, (uint32_t)lds2, stream, ev.start, ev.stop, 0, D);
-                return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
-            }
-        }
-    }
 
     const uint32_t gx = (uint32_t)((NV + 255) / 256);
     // enough workgroups to fill the chip: split the loc rows over grid.y
-    // one loc row per workgroup is fastest (more waves to hide the read -> FMA chain -> store latency per scale
-    // row; measured 25 us at gy = NL vs 310 us at gy = 1 for K = 30): split the loc rows as far as the grid allows
+    // One loc row per workgroup is fastest: the kernel is issue/latency bound (per scale row: 5 broadcast
+    // ds_read_b128 -> 20 dependent FMAs -> store), so it wants as many waves as the grid allows -- measured
+    // at K=30: 25 us with gy = NL, 310 us with gy = 1; ablation: arithmetic alone 21 us, stores alone 18 us,
+    // per-workgroup prologue 10 us.  (A variant with LDS-transposed, fully coalesced 16-byte stores was
+    // slower: 37 us.)
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 16384 / std::max(1u, gx)));
     if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
     d.l_chunk = (d.NL + gy - 1) / gy;
