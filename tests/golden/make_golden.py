@@ -375,6 +375,37 @@ def gen_models():
     recorded += calls
     save("e2e_model1.pt", rec)
 
+    # ---- the remaining problems of tests/test_problem_vs_itself.py:15-30, with their constants
+    others = {
+        "bernoulli_no_plate": [],
+        "linear_gaussian_two_params": ["prior_mean", "a_scale", "b_scale", "like_scale"],
+        "linear_gaussian_two_params_corr_Q": ["prior_mean", "a_scale", "b_scale", "like_scale"],
+        "linear_gaussian_two_params_corr_Q_reversed": ["prior_mean", "a_scale", "b_scale", "like_scale"],
+        "linear_gaussian_two_params_dangling": ["prior_mean", "prior_scale", "like_scale", "mult"],
+        "linear_gaussian_latents_dangling": ["prior_mean", "prior_scale", "z_scale", "d_scale"],
+        "linear_gaussian_latents_batch": ["prior_mean", "prior_scale", "z_scale", "d_scale"],
+        "linear_multivariate_gaussian": ["prior_mean", "prior_cov", "ap_mean", "ap_cov", "like_cov"],
+        "linear_multivariate_gaussian_batch": ["prior_mean", "prior_cov", "ap_mean", "ap_cov", "like_cov"],
+        "linear_multivariate_gaussian_param": ["prior_mean", "prior_cov", "ap_mean", "ap_cov", "like_cov"],
+    }
+    bundle = {}
+    for i, (name, consts) in enumerate(others.items()):
+        t.manual_seed(40 + i)
+        mod = importlib.import_module(name)
+        strat = {"no_checkpoint": alan.no_checkpoint, "checkpoint": alan.checkpoint}
+        cs = mod.tp.computation_strategy
+        if isinstance(cs, alan.Split):
+            strat["split"] = cs
+        rec, _ = capture_problem(name, mod.tp.problem, 3, strat, 300 + i, keep_calls=False)
+        rec["consts"] = {c: (getattr(mod, c).clone() if isinstance(getattr(mod, c), t.Tensor) else getattr(mod, c))
+                         for c in consts}
+        if isinstance(cs, alan.Split):
+            rec["split"] = (cs.platename, cs.split_size)
+        if hasattr(mod, "known_elbo"):
+            rec["known_elbo"] = mod.known_elbo.clone()
+        bundle[name] = rec
+    save("e2e_small_models.pt", bundle)
+
     # ---- movielens / bus_breakdown from the shipped example data
     for mod, sub, splits in [("movielens", "movielens", ("plate_1", 38)),
                              ("bus_breakdown", "bus_breakdown", ("plate_ID", 40))]:

@@ -167,3 +167,91 @@ def sample_from_fixture(problem, fx, device="cpu"):
 
     return alan.Sample(problem=problem, sample=build(fx["sample"]), groupvarname2Kdim=Kdims,
                        sampler=alan.PermutationSampler, reparam=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# The remaining problems of the reference's tests/test_problem_vs_itself.py:15-30 (constants, data and
+# the sample tree come from tests/golden/e2e_small_models.pt).
+from alan_amd import Beta, MultivariateNormal
+
+
+def _data(fx, k):
+    return {k: _named(fx["data"][k])}
+
+
+def _small(name):
+    def deco(f):
+        SMALL[name] = f
+        return f
+    return deco
+
+
+SMALL = {}
+
+
+@_small("bernoulli_no_plate")
+def _m(fx, c):
+    P = Plate(p=Beta(2, 1), T=Plate(coin=Bernoulli("p")))
+    Q = Plate(p=Beta(1, 1), T=Plate(coin=Data()))
+    return P, Q, _data(fx, "coin")
+
+
+def _two_params(qa, qb, reversed_=False):
+    def build(fx, c):
+        P = Plate(a=Normal(c["prior_mean"], c["a_scale"]), b=Normal("a", c["b_scale"]),
+                  T=Plate(d=Normal("b", c["like_scale"])))
+        Q = (Plate(b=qb(), a=qa(), T=Plate(d=Data())) if reversed_ else
+             Plate(a=qa(), b=qb(), T=Plate(d=Data())))
+        return P, Q, _data(fx, "d")
+    return build
+
+
+SMALL["linear_gaussian_two_params"] = _two_params(lambda: Normal(1, 4), lambda: Normal(1, 4))
+SMALL["linear_gaussian_two_params_corr_Q"] = _two_params(lambda: Normal(1, 4), lambda: Normal("a", 1.2))
+SMALL["linear_gaussian_two_params_corr_Q_reversed"] = _two_params(lambda: Normal("b", 1.2), lambda: Normal(1, 4), True)
+
+
+@_small("linear_gaussian_two_params_dangling")
+def _m(fx, c):
+    mult = c["mult"]
+    P = Plate(a=Normal(c["prior_mean"], c["prior_scale"]), b=Normal("a", 1.3),
+              T=Plate(d=Normal(lambda a: mult * a, c["like_scale"])))
+    Q = Plate(a=Normal(1, 4), b=Normal(lambda a: 1.2 * a, 1.2), T=Plate(d=Data()))
+    return P, Q, _data(fx, "d")
+
+
+@_small("linear_gaussian_latents_dangling")
+def _m(fx, c):
+    P = Plate(a=Normal(c["prior_mean"], c["prior_scale"]),
+              T=Plate(z=Normal("a", c["z_scale"]), zp=Normal("a", 1.), d=Normal("z", c["d_scale"])))
+    Q = Plate(a=Normal(1, 4),
+              T=Plate(z=Normal(lambda a: 1.5 * a, 3.5), zp=Normal(lambda a: 1.5 * a, 3.5), d=Data()))
+    return P, Q, _data(fx, "d")
+
+
+@_small("linear_gaussian_latents_batch")
+def _m(fx, c):
+    P = Plate(a=Normal(c["prior_mean"], c["prior_scale"]),
+              T=Plate(z=Normal("a", c["z_scale"]), d=Normal("z", c["d_scale"])))
+    Q = Plate(a=Normal(t.zeros(2), 4), T=Plate(z=Normal(lambda a: 0.5 * a, 6), d=Data()))
+    return P, Q, _data(fx, "d")
+
+
+def _mvn(plated):
+    def build(fx, c):
+        like = MultivariateNormal("a", c["like_cov"])
+        P = Plate(a=MultivariateNormal(c["prior_mean"], c["prior_cov"]), **({"T": Plate(d=like)} if plated else {"d": like}))
+        Q = Plate(a=MultivariateNormal(c["ap_mean"], c["ap_cov"]), **({"T": Plate(d=Data())} if plated else {"d": Data()}))
+        return P, Q, _data(fx, "d")
+    return build
+
+
+SMALL["linear_multivariate_gaussian"] = _mvn(False)
+SMALL["linear_multivariate_gaussian_batch"] = _mvn(False)
+SMALL["linear_multivariate_gaussian_param"] = _mvn(True)
+
+
+def small_model(name, fx):
+    P, Q, data = SMALL[name](fx, fx["consts"])
+    sizes = fx["platesizes"]
+    return Problem(BoundPlate(P, sizes), BoundPlate(Q, sizes), data)

@@ -121,3 +121,32 @@ def test_graphed_training_step_improves_the_elbo(method):
     known = float(fx["known_elbo"])
     assert last > first + 1.0, (first, last)
     assert last < known + 0.5, (last, known)
+
+
+# ---------------------------------------------------------------------------------------------
+# every other problem of the reference's own suite (tests/test_problem_vs_itself.py:15-30): Beta/Bernoulli,
+# correlated and reversed Q (reduce_logQ), dangling variables, unnamed batch dims, MultivariateNormal
+SMALL = sorted(load_golden("e2e_small_models.pt"))
+
+
+def _check_small(name, device):
+    fx = load_golden("e2e_small_models.pt")[name]
+    prob = models.small_model(name, fx).to(device)
+    sample = models.sample_from_fixture(prob, fx, device)
+    strategies = {"no_checkpoint": alan.no_checkpoint, "checkpoint": alan.checkpoint}
+    if "split" in fx["elbo"]:
+        strategies["split"] = alan.Split(*fx["split"])
+    for sname, strat in strategies.items():
+        got, ref = float(sample.elbo_nograd(strat)), float(fx["elbo"][sname])
+        assert abs(got - ref) <= 1e-4 * abs(ref) + 1e-5, (name, sname, got, ref)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_reference_suite_models_host_logic(name, oracle_backend):
+    _check_small(name, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SMALL)
+def test_reference_suite_models_hip(name):
+    _check_small(name, "cuda")
