@@ -38,6 +38,7 @@ struct RowsDesc {
     float *lse;             // optional per-row log-sum-exp values
     int64_t lks[MAXD], l_ps;
     float add_const;
+    int32_t dbg;            // ablation knob (ALAN_ROWS_ABLATE): 1 = no reduction, 2 = no global loads
 };
 
 #ifndef ROWS_NT
@@ -50,12 +51,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // 16-byte loads in fl
 // chunk of the plate).  With one slab per workgroup (the literal movielens size: 1200 workgroups) the
 // staging registers are dead during the reduction, the kernel fits 5 workgroups per CU and the whole
 // grid is resident in a single round.
-template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN, bool PF>
+template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN, bool PF, bool SHORT>
 __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const RowsDesc d) {
     extern __shared__ __align__(16) float lds[];
     constexpr int G = 1 << LOGG;
+    constexpr int NS = SHORT ? 8 : 16;   // float2 slots per lane: a lane holds <= 32 (SHORT: 16) row elements
     const int t = threadIdx.x;
     const int L = d.L;
+    if (d.dbg == 4) return;
     const uint32_t o0 = blockIdx.x * (uint32_t)d.RB;
     const uint32_t nrows = min((uint32_t)d.RB, d.NO - o0);
     const uint32_t p0 = blockIdx.y * d.p_chunk;
@@ -85,7 +88,6 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             lb += idx * d.lks[k];
         }
     }
-    const int j0 = ROT ? (r % L) : 0;
 
     // slab of plate index p: 16-byte loads from a 16-byte aligned-down start into registers
     f32x4 v[ROWS_UNR];
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
         const int64_t a0 = e0 & ~(int64_t)3;
         const int n4 = ((int)(e0 - a0) + (int)nrows * L + 3) >> 2;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(d.F + a0);
+        if (d.dbg >= 2) return;
         if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the very last one)
 #pragma unroll
             for (int u = 0; u < ROWS_UNR; ++u) {
@@ -157,99 +160,104 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             shared_fetch(p + 1);
         }
 
-        float *row = lds + shift + r * L;
-        float val;
-        if (MODE == ALAN_MODE_LSE) {
-            float m = -__builtin_huge_valf();
+        const float *row = lds + shift + r * L;
+        // ---- the row (+ small factors) into registers, ONE pass over LDS: lane gl of the row's G lanes takes
+        // elements gl, gl+G, ... (<= 32 of them); slots past the row's end are masked, not skipped, so the
+        // reads are straight-line with compile-time offsets and all in flight together
+        float x[2 * NS];
+        constexpr float NEG = -__builtin_huge_valf();
+        constexpr float PAD = MODE == ALAN_MODE_LSE ? NEG : 0.f;
+        if (VEC2) {
+            const float2 *r2 = reinterpret_cast<const float2 *>(row) + gl;
+            const float2 *g2 = reinterpret_cast<const float2 *>(gs) + gl;
+            const int nq = (L >> 1) - gl;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                float2 a = r2[u * G];            // (reads past the row stay inside the LDS allocation)
+                if (d.nshared > 0) {
+                    const float2 g = g2[u * G];
+                    a.x += g.x;
+                    a.y += g.y;
+                }
+                const bool ok = u * G < nq;
+                x[2 * u] = ok ? a.x : PAD;
+                x[2 * u + 1] = ok ? a.y : PAD;
+            }
+        } else {
             if (GEN) {
-                // pass 1: x = F + small factors, written back in place; exact row max
+                // general small factors (they vary over the window's rows): folded into this lane's own
+                // elements of the LDS row first, with a rolled loop (global loads, L1/L2-resident)
+                float *wrow = lds + shift + r * L;
+#pragma unroll 2
                 for (int j = gl; j < L; j += G) {
-                    int jj = j + j0;
-                    if (ROT && jj >= L) jj -= L;
-                    float x = row[jj];
-                    if (d.nshared > 0) x += gs[jj];
+                    float a = wrow[j];
 #pragma unroll
                     for (int f = 0; f < MAXF; ++f)
                         if (f < d.ngen)
-                            x += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
-                                                             (int64_t)jj * d.gen[f].rs[0]];
-                    if (has_row) row[jj] = x;   // (threads past the window's last row mirror it: no write)
-                    m = fmaxf(m, x);
-                }
-            } else if (VEC2) {
-                const float2 *r2 = reinterpret_cast<const float2 *>(row);
-                const float2 *g2 = reinterpret_cast<const float2 *>(gs);
-                if (d.nshared > 0) {
-                    for (int q = gl; q < (L >> 1); q += G) {
-                        const float2 x = r2[q], g = g2[q];
-                        m = fmaxf(m, fmaxf(x.x + g.x, x.y + g.y));
-                    }
-                } else {
-                    for (int q = gl; q < (L >> 1); q += G) {
-                        const float2 x = r2[q];
-                        m = fmaxf(m, fmaxf(x.x, x.y));
-                    }
-                }
-            } else {
-                for (int j = gl; j < L; j += G) {
-                    int jj = j + j0;
-                    if (ROT && jj >= L) jj -= L;
-                    float x = row[jj];
-                    if (d.nshared > 0) x += gs[jj];
-                    m = fmaxf(m, x);
+                            a += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
+                                                             (int64_t)j * d.gen[f].rs[0]];
+                    if (has_row) wrow[j] = a;   // (threads past the window's last row mirror it: no write)
                 }
             }
+            if (ROT) {
+                // row stride = 0 (mod 16 words): every lane would start on the same bank.  Rows are then
+                // 16-byte aligned, so read float4 quads, each row starting at a different (rotated) quad
+                const int NQ = L >> 2;
+                const float4 *r4 = reinterpret_cast<const float4 *>(row);
+                const float4 *g4 = reinterpret_cast<const float4 *>(gs);
+                int qq = (gl + r) % NQ;
+#pragma unroll
+                for (int u = 0; u < NS / 2; ++u) {
+                    float4 a = r4[qq];
+                    if (d.nshared > 0) {
+                        const float4 g = g4[qq];
+                        a.x += g.x, a.y += g.y, a.z += g.z, a.w += g.w;
+                    }
+                    const bool ok = gl + u * G < NQ;
+                    x[4 * u] = ok ? a.x : PAD;
+                    x[4 * u + 1] = ok ? a.y : PAD;
+                    x[4 * u + 2] = ok ? a.z : PAD;
+                    x[4 * u + 3] = ok ? a.w : PAD;
+                    qq += G;
+                    if (qq >= NQ) qq -= NQ;
+                }
+            } else {
+                const float *r1 = row + gl, *g1 = gs + gl;
+#pragma unroll
+                for (int u = 0; u < 2 * NS; ++u) {
+                    float a = r1[u * G];
+                    if (d.nshared > 0) a += g1[u * G];
+                    x[u] = gl + u * G < L ? a : PAD;
+                }
+            }
+        }
+        float val;
+        if (d.dbg == 1 || d.dbg == 3) {
+            val = x[0];
+        } else if (MODE == ALAN_MODE_LSE) {
+            float m = NEG;   // exact row max, then sum exp(x - max): the reference's two-pass arithmetic
+#pragma unroll
+            for (int u = 0; u < 2 * NS; ++u) m = fmaxf(m, x[u]);
 #pragma unroll
             for (int ofs = G >> 1; ofs > 0; ofs >>= 1) m = fmaxf(m, __shfl_xor(m, ofs));
-            // pass 2: sum exp(x - max)   (utils.py:219)
-            float s = 0.f;
-            const bool add_g = d.nshared > 0 && !GEN;
-            if (VEC2) {
-                const float2 *r2 = reinterpret_cast<const float2 *>(row);
-                const float2 *g2 = reinterpret_cast<const float2 *>(gs);
-                float s1 = 0.f;
-                if (add_g) {
-                    for (int q = gl; q < (L >> 1); q += G) {
-                        const float2 x = r2[q], g = g2[q];
-                        s += __expf(x.x + g.x - m);
-                        s1 += __expf(x.y + g.y - m);
-                    }
-                } else {
-                    for (int q = gl; q < (L >> 1); q += G) {
-                        const float2 x = r2[q];
-                        s += __expf(x.x - m);
-                        s1 += __expf(x.y - m);
-                    }
-                }
-                s += s1;
-            } else {
-                for (int j = gl; j < L; j += G) {
-                    int jj = j + j0;
-                    if (ROT && jj >= L) jj -= L;
-                    float x = row[jj];
-                    if (add_g) x += gs[jj];
-                    s += __expf(x - m);
-                }
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < NS; ++u) {
+                s0 += __expf(x[2 * u] - m);     // utils.py:219   (masked slots: exp(-inf) = 0)
+                s1 += __expf(x[2 * u + 1] - m);
             }
+            float s = s0 + s1;
 #pragma unroll
             for (int ofs = G >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
             val = logf(s + Num<float>::eps) + m;  // utils.py:220
         } else {  // ALAN_MODE_SUM
-            float s = 0.f;
-            for (int j = gl; j < L; j += G) {
-                int jj = j + j0;
-                if (ROT && jj >= L) jj -= L;
-                float x = row[jj];
-                if (d.nshared > 0) x += gs[jj];
-                if (GEN) {
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                    for (int f = 0; f < MAXF; ++f)
-                        if (f < d.ngen)
-                            x += ((const float *)d.gen[f].p)[sb[f] + (int64_t)p * d.gen_ps[f] +
-                                                             (int64_t)jj * d.gen[f].rs[0]];
-                }
-                s += x;
+            for (int u = 0; u < NS; ++u) {
+                s0 += x[2 * u];
+                s1 += x[2 * u + 1];
             }
+            float s = s0 + s1;
 #pragma unroll
             for (int ofs = G >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
             val = s;
@@ -300,6 +308,8 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.NO = (uint32_t)(c.n_out / rp.P);
     rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
     if (const char *e = getenv("ALAN_ROWS_LOGG")) rp.logG = std::max(rp.logG, std::min(3, atoi(e)));  // tuning knob
+    rp.rot = gcd_i((int)L, 64) >= 16;
+    if (rp.rot) while ((1 << rp.logG) > L / 4) --rp.logG;   // (the quad rotation wraps once per step)
     int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
     if (const char *e = getenv("ALAN_ROWS_RBMAX")) rbmax = std::max(1, std::min(rbmax, atoi(e)));  // tuning knob
     rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
@@ -311,9 +321,9 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.p_chunk = (rp.P + nch - 1) / nch;
     rp.n_chunks = (rp.P + rp.p_chunk - 1) / rp.p_chunk;
     rp.gs_off = (int)((((int64_t)rp.RB * L + 3 + 3) / 4) * 4);
-    rp.lds_bytes = (size_t)(rp.gs_off + ((L + 3) / 4) * 4) * 4;
+    // + slack: the unrolled row reads run up to 32*G floats past a row's start (masked, never used)
+    rp.lds_bytes = (size_t)(rp.gs_off + ((L + 3) / 4) * 4 + 32 * (1 << rp.logG) + 8) * 4;
     rp.partial_bytes = (nplate && rp.n_chunks > 1) ? (size_t)rp.n_chunks * rp.NO * 4 : 0;
-    rp.rot = gcd_i((int)L, 64) >= 16;
     rp.vec2 = !rp.rot && (L % 2 == 0);
     rp.ok = true;
     return rp;
@@ -360,19 +370,24 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     for (int j = 0; j < d.nki; ++j) d.lks[j] = c.l.ks[k0 + j];
     d.l_ps = k0 ? c.l.ks[0] : 0;
     d.add_const = two_stage ? 0.f : (float)add_const;
+    if (const char *e = getenv("ALAN_ROWS_ABLATE")) d.dbg = atoi(e);
 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);
-#define ALAN_ROWS4(MODE, G, V, R, GN)                                                                    \
-    if (rp.p_chunk > 1)                                                                                  \
-        hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, true>), grid, block, rp.lds_bytes, stream, ev.start, \
-                              ev.stop, 0, d); \
-    else                                                                                                 \
-        hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, false>), grid, block, rp.lds_bytes, stream, ev.start, \
-                              ev.stop, 0, d)
-#define ALAN_ROWS3(MODE, G, V, R)                       \
-    if (d.ngen > 0) ALAN_ROWS4(MODE, G, false, R, true); \
-    else ALAN_ROWS4(MODE, G, V, R, false)
+#define ALAN_ROWS5(MODE, G, V, R, GN, PFV, SH)                                                                  \
+    hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, PFV, SH>), grid, block, rp.lds_bytes, stream, ev.start, \
+                          ev.stop, 0, d)
+#define ALAN_ROWS4(MODE, G, V, R, GN)                    \
+    if (rp.p_chunk > 1) {                                \
+        if (G == 0 && rp.L <= 16) ALAN_ROWS5(MODE, G, V, R, GN, true, (G == 0));  \
+        else ALAN_ROWS5(MODE, G, V, R, GN, true, false);  \
+    } else {                                             \
+        if (G == 0 && rp.L <= 16) ALAN_ROWS5(MODE, G, V, R, GN, false, (G == 0)); \
+        else ALAN_ROWS5(MODE, G, V, R, GN, false, false); \
+    }
+#define ALAN_ROWS3(MODE, G, V, R)                         \
+    if (d.ngen > 0) { ALAN_ROWS4(MODE, G, false, R, true) } \
+    else { ALAN_ROWS4(MODE, G, V, R, false) }
 #define ALAN_ROWS2(MODE, V, R)                        \
     switch (rp.logG) {                                \
         case 0: ALAN_ROWS3(MODE, 0, V, R); break;     \
@@ -386,8 +401,10 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
         else { ALAN_ROWS2(ALAN_MODE_LSE, false, false) }
     } else {
         if (rp.rot) { ALAN_ROWS2(ALAN_MODE_SUM, false, true) }
+        else if (rp.vec2) { ALAN_ROWS2(ALAN_MODE_SUM, true, false) }
         else { ALAN_ROWS2(ALAN_MODE_SUM, false, false) }
     }
+#undef ALAN_ROWS5
 #undef ALAN_ROWS4
 #undef ALAN_ROWS2
 #undef ALAN_ROWS3
