@@ -37,6 +37,8 @@ struct Num<float> {
     static constexpr float eps = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
     __device__ static __forceinline__ float exp(float x) { return __expf(x); }
     __device__ static __forceinline__ float log(float x) { return logf(x); }
+    __device__ static __forceinline__ float exp_acc(float x) { return expf(x); }
+    __device__ static __forceinline__ float log1p(float x) { return log1pf(x); }
     __device__ static __forceinline__ float ninf() { return -__builtin_huge_valf(); }
     __device__ static __forceinline__ float nan() { return __builtin_nanf(""); }
 };
@@ -45,6 +47,8 @@ struct Num<double> {
     static constexpr double eps = 2.220446049250313e-16;  // torch.finfo(float64).eps
     __device__ static __forceinline__ double exp(double x) { return ::exp(x); }
     __device__ static __forceinline__ double log(double x) { return ::log(x); }
+    __device__ static __forceinline__ double exp_acc(double x) { return ::exp(x); }
+    __device__ static __forceinline__ double log1p(double x) { return ::log1p(x); }
     __device__ static __forceinline__ double ninf() { return -__builtin_huge_val(); }
     __device__ static __forceinline__ double nan() { return __builtin_nan(""); }
 };

@@ -80,6 +80,15 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
             s += -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
             continue;
         }
+        if (MODE == ALAN_MODE_BERNOULLI) {
+            // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
+            // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+            const T y = load_as<T>(d.f[0].p, d.f[0].dtype, off[0]);
+            const T xl = load_as<T>(d.f[1].p, d.f[1].dtype, off[1]);
+            const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
+            s += ls - (T(1) - y) * xl;
+            continue;
+        }
         T x = T(0);
 #pragma unroll
         for (int f = 0; f < MAXF; ++f)
@@ -152,6 +161,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream, ev);  \
         case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
+        case ALAN_MODE_BERNOULLI: return launch_group_T<T, ALAN_MODE_BERNOULLI>(gd, gl, stream, ev); \
     }
     if (compute_dtype == ALAN_F32) {
         ALAN_DISPATCH(float)

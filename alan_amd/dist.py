@@ -98,8 +98,48 @@ class _FusedNormalLogProb(t.autograd.Function):
         return None, gv, gl, gs
 
 
+class _FusedBernoulliLogProb(t.autograd.Function):
+    """sum log Bernoulli(value; logits) over the event dims and every first-class dim missing from the
+    output (ONE HIP launch, alan_reduce mode BERNOULLI).  backward: d logits = G * (value - sigmoid(logits))
+    summed over the dims logits lacks (plain torch ops on the broadcast, which is only data-sized)."""
+
+    @staticmethod
+    def forward(ctx, spec, value, logits):
+        from . import engine as E
+        vd, ld, od = spec
+        out = E.bernoulli_logprob((value.detach(), vd), (logits.detach(), ld), od)
+        ctx.spec = spec
+        ctx.save_for_backward(value, logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        vd, ld, od = ctx.spec
+        value, logits = ctx.saved_tensors
+        if not ctx.needs_input_grad[2]:
+            return None, None, None
+        dims, ids = pt_order((PT(value, vd), PT(logits, ld)))
+        nv, nl = value.ndim - len(vd), logits.ndim - len(ld)
+        nev = max(nv, nl)
+        v = pt_align(PT(value.detach(), vd), ids, nev - nv)
+        l = pt_align(PT(logits.detach(), ld), ids, nev - nl)
+        g = pt_align(PT(G, od), ids)[(...,) + (None,) * nev]
+        full = g * (v - t.sigmoid(l))
+        full = full.expand([max(a, b) for a, b in zip(full.shape, l.shape)])
+        red = [k for k, (a, b) in enumerate(zip(full.shape, l.shape)) if b == 1 and a != 1]
+        gl = full.sum(red, keepdim=True) if red else full           # aligned like l
+        ld_ids = {id(d) for d in ld}
+        drop = [k for k, i in enumerate(ids) if i not in ld_ids] + list(range(len(ids), len(ids) + nev - nl))
+        if drop:
+            gl = gl.squeeze(drop)
+        cur = {i: k for k, i in enumerate(i for i in ids if i in ld_ids)}
+        perm = [cur[id(d)] for d in ld]
+        gl = gl.permute(*perm, *range(len(ld), gl.ndim))
+        return None, None, gl.reshape(logits.shape).to(logits.dtype)
+
+
 FUSE_NORMAL = True
-"""Route gradient-free Normal log-probs on the GPU to the fused HIP producer kernel."""
+"""Route Normal / Bernoulli(logits) log-probs on the GPU to the fused HIP producer kernels."""
 
 
 class TorchDimDist:
@@ -156,42 +196,59 @@ class TorchDimDist:
             x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
         return PT(x, (*extra, *self.all_arg_dims))
 
-    def log_prob_pt(self, x, dim_order=None):
+    def log_prob_pt(self, x, dim_order=None, sum_dims=()):
         """log p(x) as a PT over (x's dims) U (parameter dims); positional sample/batch dims are summed
         out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of the result:
-        ``lead`` dims outermost, ``last`` dims innermost, any others in between."""
+        ``lead`` dims outermost, ``last`` dims innermost, any others in between.  ``sum_dims``: first-class
+        dims to sum out as well (a data-only plate's sum, logpq.py:149, fused into the producer)."""
         x = PT.of(x)
         lead, last = dim_order if dim_order is not None else ((), ())
         dims, ids = pt_order((x, *self.kwargs.values()), lead, last)
+        drop = {id(d) for d in sum_dims}
+        if not drop <= set(ids):
+            raise Exception("log_prob: a dim to sum out is on neither the value nor the parameters")
+        out_dims = tuple(d for d in dims if id(d) not in drop)
         n_sample = x.n_pos - self.sample_batch_ndim - self.sample_event_ndim
         assert n_sample >= 0
-        if self._fusable(x):
+        kind = self._fusable(x)
+        if kind == "normal":
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
-            spec = (x.dims, loc.dims, scale.dims, tuple(dims))
-            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.x), dims)
+            spec = (x.dims, loc.dims, scale.dims, out_dims)
+            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.x), out_dims)
+        if kind == "bernoulli":
+            logits = self.kwargs["logits"]
+            spec = (x.dims, logits.dims, out_dims)
+            return PT(_FusedBernoulliLogProb.apply(spec, x.x, logits.x), out_dims)
         d = self._build(ids, n_sample)
         lp = d.log_prob(pt_align(x, ids))
-        if lp.ndim > len(ids):
-            lp = lp.sum(tuple(range(len(ids), lp.ndim)))
-        return PT(lp, dims)
+        axes = [i for i, d_ in enumerate(dims) if id(d_) in drop] + list(range(len(ids), lp.ndim))
+        if axes:
+            lp = lp.sum(tuple(axes))
+        return PT(lp, out_dims)
 
     def log_prob(self, x, dim_order=None):
         assert is_tensor(x)
         return self.log_prob_pt(x, dim_order).dim()
 
     def _fusable(self, x):
-        """Normal log-probs on the GPU with no gradient to record go to the fused HIP producer
-        (alan_reduce mode NORMAL); everything else stays on torch.distributions."""
-        if not FUSE_NORMAL or self.dist is not td.Normal or set(self.kwargs) != {"loc", "scale"}:
-            return False
-        ts = [x.x, self.kwargs["loc"].x, self.kwargs["scale"].x]
+        """Normal and Bernoulli(logits) log-probs on the GPU go to the fused HIP producers (alan_reduce
+        modes NORMAL / BERNOULLI); everything else stays on torch.distributions.  -> "normal" | "bernoulli" | None"""
+        if not FUSE_NORMAL:
+            return None
+        if self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"}:
+            kind, args = "normal", (x, self.kwargs["loc"], self.kwargs["scale"])
+        elif self.dist is td.Bernoulli and set(self.kwargs) == {"logits"}:
+            kind, args = "bernoulli", (x, self.kwargs["logits"])
+        else:
+            return None
+        ts = [p.x for p in args]
         if not all(v.is_cuda and v.dtype in (t.float32, t.float64) for v in ts):
-            return False
-        if t.is_grad_enabled() and any(v.requires_grad for v in ts):
+            return None
+        if kind == "normal" and t.is_grad_enabled() and any(v.requires_grad for v in ts):
             # the backward (einsum contractions) needs one common event shape
-            ev = [tuple(v.shape[len(p.dims):]) for v, p in zip(ts, (x, self.kwargs["loc"], self.kwargs["scale"]))]
-            return ev[0] == ev[1] == ev[2]
-        return True
+            ev = [tuple(v.shape[len(p.dims):]) for v, p in zip(ts, args)]
+            return kind if ev[0] == ev[1] == ev[2] else None
+        return kind
 
 
 # --------------------------------------------------------------------------------------------
@@ -317,9 +374,9 @@ class Dist(nn.Module):
             p = PT(pt_align(p, ids).contiguous(), want)
         return p
 
-    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None):
+    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=()):
         """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""
-        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order), None
+        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order, sum_dims=sum_dims), None
 
 
 LAMBDA_BACKEND = "vmap"

@@ -204,15 +204,13 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
 
 
 # --------------------------------------------------------------------------- fused factor producer
-def normal_logprob(value, loc, scale, out_dims):
-    """log N(value; loc, scale) summed over every positional (sample/batch/event) dim, as ONE launch
-    (alan_reduce mode NORMAL): the [.., K, K, K, d] broadcast the reference materialises
-    (TorchDimDist.py:127-162) never exists.  Each argument is (tensor, leading first-class dims);
-    trailing positional dims are right-aligned.  Returns a tensor laid out as ``out_dims``."""
+def _produce(mode, args, out_dims):
+    """One producer launch: ``args`` are (tensor, leading first-class dims) pairs whose trailing positional
+    dims are right-aligned; every dim not in ``out_dims`` is summed out."""
     tok = _Tokens()
-    npos = max(x.ndim - len(d) for x, d in (value, loc, scale))
+    npos = max(x.ndim - len(d) for x, d in args)
     factors = []
-    for x, d in (value, loc, scale):
+    for x, d in args:
         k = x.ndim - len(d)
         keys = tok.many(d) + tuple(tok(("_e", npos - k + j)) for j in range(k))
         factors.append((x.detach(), keys))
@@ -220,9 +218,23 @@ def normal_logprob(value, loc, scale, out_dims):
     odims = tok.many(out_dims)
     roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
     dtype = _result_dtype([x for x, _ in factors])
-    out = t.empty([sizes[d] for d in odims], dtype=dtype, device=value[0].device)
-    _launch(N.MODE_NORMAL, factors, sizes, roles, out, odims)
+    out = t.empty([sizes[d] for d in odims], dtype=dtype, device=args[0][0].device)
+    _launch(mode, factors, sizes, roles, out, odims)
     return out
+
+
+def normal_logprob(value, loc, scale, out_dims):
+    """log N(value; loc, scale) summed over every positional (sample/batch/event) dim -- and over any
+    first-class dim missing from ``out_dims`` (a data-only plate's sum, logpq.py:149) -- as ONE launch
+    (alan_reduce mode NORMAL): the [.., K, K, K, d] broadcast the reference materialises
+    (TorchDimDist.py:127-162) never exists.  Each argument is (tensor, leading first-class dims);
+    trailing positional dims are right-aligned.  Returns a tensor laid out as ``out_dims``."""
+    return _produce(N.MODE_NORMAL, (value, loc, scale), out_dims)
+
+
+def bernoulli_logprob(value, logits, out_dims):
+    """log Bernoulli(value; logits=logits), summed like ``normal_logprob`` (alan_reduce mode BERNOULLI)."""
+    return _produce(N.MODE_BERNOULLI, (value, logits), out_dims)
 
 
 # --------------------------------------------------------------------------- elimination planner

@@ -116,6 +116,22 @@ def plate_factors(name, P, Q, sample, inputs_params, data, extra_log_factors, sc
 def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
                  all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
                  prev_lpq, dimcache=None):
+    if name is not None and not tree_tensors(extra_log_factors) and \
+            all(kind == "data" for kind, _, _ in Q.entries()) and len(Q.grouped_prog):
+        # a plate of observations only (movielens plate_2, bus_breakdown's ID plate): no K of its own, so
+        # sum_plate commutes with everything and each likelihood's producer sums the plate out itself
+        platedim = all_platedims[name]
+        inner = update_scope(update_scope(scope, inputs_params), sample)
+        lp = None
+        for _, child, _ in Q.entries():
+            f, _ = P.flat_prog[child].log_prob(data[child], inner, dim_order=(active_platedims, ()),
+                                               dimcache=dimcache, sum_dims=(platedim,))
+            lp = f if lp is None else pt_add(lp, f)
+        if prev_lpq is not None:
+            assert set(lp.ids) == set(prev_lpq.ids)
+            lp = pt_add(prev_lpq, lp)
+        return lp
+
     platedim, active_platedims, scope, lps, Ks, K_currs, K_inits = plate_factors(
         name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims, all_platedims,
         groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy, dimcache)

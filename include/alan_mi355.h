@@ -60,10 +60,15 @@ typedef enum {
     ALAN_MODE_LSE = 0,     /* out = log(sum_R exp(x - max_R x) + eps(dtype)) + max_R x,  x = sum_f scale_f * factor_f */
     ALAN_MODE_SUM = 1,     /* out = sum_R x */
     ALAN_MODE_WEXPSUM = 2, /* out = sum_R weight * exp(x) */
-    ALAN_MODE_NORMAL = 3   /* fused factor PRODUCER (TorchDimDist.py:127-162 + utils.py:147-152 for td.Normal):
+    ALAN_MODE_NORMAL = 3,  /* fused factor PRODUCER (TorchDimDist.py:127-162 + utils.py:147-152 for td.Normal):
                               exactly 3 factors (value, loc, scale);
                               out = sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
                               R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised */
+    ALAN_MODE_BERNOULLI = 4 /* fused factor PRODUCER for td.Bernoulli(logits=...) (same reference lines):
+                              exactly 2 factors (value, logits);
+                              out = sum_R [ logsigmoid(logits) - (1 - value) * logits ]
+                              (= -binary_cross_entropy_with_logits, what torch's Bernoulli.log_prob evaluates);
+                              R = event/batch dims and, for a data-only plate, the plate dims (logpq.py:149) */
 } alan_mode_t;
 
 typedef struct {

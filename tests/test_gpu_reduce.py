@@ -307,3 +307,77 @@ def test_fused_normal_backward_matches_torch_autograd(shapes):
     t.testing.assert_close(lp_f.x, lp_t.x, rtol=2e-5, atol=2e-4)
     for a, b in zip(gf, gt):
         t.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
+
+
+# ------------------------------------------------------------------ fused Bernoulli(logits) producer
+@pytest.mark.parametrize("vdtype,ldtype", [(t.float32, t.float32), (t.float64, t.float32), (t.float64, t.float64)])
+@pytest.mark.parametrize("plate_sum", [False, True])
+def test_bernoulli_producer_matches_torch_distributions(vdtype, ldtype, plate_sum):
+    """alan_reduce(mode BERNOULLI) == td.Bernoulli(logits=l).log_prob(y) over the broadcast of value [m, n] and
+    logits [m, n, kz], optionally with the data plate n summed by the same launch (logpq.py:149).  Large |logits|
+    exercise both branches of logsigmoid."""
+    g = t.Generator().manual_seed(11)
+    M, Nf, K = 37, 5, 30
+    y = (t.rand(M, Nf, generator=g) < 0.4).to(vdtype)
+    l = (6 * t.randn(M, Nf, K, generator=g)).to(ldtype)
+    l[0, 0, :4] = t.tensor([-90.0, 90.0, 0.0, -1e-8]).to(ldtype)
+    ref = t.distributions.Bernoulli(logits=l).log_prob(y[:, :, None].to(t.promote_types(vdtype, ldtype)))
+    out_dims = ("m", "kz") if plate_sum else ("m", "n", "kz")
+    if plate_sum:
+        ref = ref.sum(1)
+    out = E_.bernoulli_logprob((y.to(DEV), ("m", "n")), (l.to(DEV), ("m", "n", "kz")), out_dims)
+    assert out.dtype == ref.dtype
+    # (mixed dtypes: torch evaluates logsigmoid in the logits' fp32 and only then promotes)
+    kw = dict(rtol=2e-5, atol=2e-5) if t.float32 in (vdtype, ldtype) else dict(rtol=1e-12, atol=1e-10)
+    t.testing.assert_close(out.cpu(), ref, **kw)
+
+
+@pytest.mark.parametrize("with_event", [False, True])
+def test_fused_bernoulli_forward_and_backward_match_torch_path(with_event):
+    import alan_amd.dist as D
+    from alan_amd.dims import Dim, PT
+    g = t.Generator().manual_seed(5)
+    M, Nf, K, Ev = 6, 4, 5, 3
+    dm, dn, dz = Dim("plate_1", M), Dim("plate_2", Nf), Dim("K_z", K)
+    ev = (Ev,) if with_event else ()
+    y = PT((t.rand(M, Nf, *ev, generator=g) < 0.5).float().to(DEV), (dm, dn))
+    raw = t.randn(M, K, Nf, *ev, generator=g)               # logits stored [plate_1, K_z, plate_2, event]
+
+    def run(fuse, sum_dims):
+        D.FUSE_NORMAL = fuse
+        try:
+            leaf = raw.clone().to(DEV).requires_grad_(True)
+            dist = D.TorchDimDist(t.distributions.Bernoulli, logits=PT(leaf, (dm, dz, dn)))
+            lp = dist.log_prob_pt(y, ([dm], []), sum_dims=sum_dims)
+            wgt = t.randn(lp.x.shape, generator=t.Generator().manual_seed(1)).to(DEV)
+            (grad,) = t.autograd.grad((lp.x * wgt).sum(), [leaf])
+            return lp, grad
+        finally:
+            D.FUSE_NORMAL = True
+
+    for sum_dims in ((), (dn,)):
+        (lp_f, gf), (lp_t, gt) = run(True, sum_dims), run(False, sum_dims)
+        assert [str(d) for d in lp_f.dims] == [str(d) for d in lp_t.dims]
+        assert ("plate_2" in [str(d) for d in lp_f.dims]) == (not sum_dims)
+        t.testing.assert_close(lp_f.x, lp_t.x, rtol=2e-5, atol=2e-5)
+        t.testing.assert_close(gf, gt, rtol=1e-4, atol=1e-5)
+
+
+def test_normal_producer_sums_a_data_plate():
+    """A Normal likelihood in a data-only plate: the plate sum rides in the producer launch."""
+    import alan_amd.dist as D
+    from alan_amd.dims import Dim, PT
+    g = t.Generator().manual_seed(9)
+    M, Nf, K = 8, 6, 4
+    dm, dn, dz = Dim("plate_1", M), Dim("plate_2", Nf), Dim("K_z", K)
+    y = PT(t.randn(M, Nf, generator=g).to(DEV), (dm, dn))
+    loc = PT(t.randn(M, K, generator=g).to(DEV), (dm, dz))
+    sc = PT((t.rand(Nf, generator=g) + 0.5).to(DEV), (dn,))
+    dist = D.TorchDimDist(t.distributions.Normal, loc=loc, scale=sc)
+    full = dist.log_prob_pt(y, ([dm, dn], []))
+    summed = dist.log_prob_pt(y, ([dm], []), sum_dims=(dn,))
+    assert [str(d) for d in summed.dims] == ["plate_1", "K_z"]
+    pos = [str(d) for d in full.dims].index("plate_2")
+    t.testing.assert_close(summed.x, full.x.sum(pos), rtol=2e-5, atol=2e-5)
+    with pytest.raises(Exception, match="neither the value nor the parameters"):
+        dist.log_prob_pt(y, ([dm], []), sum_dims=(Dim("plate_9", 3),))
