@@ -7,7 +7,7 @@ log-probs work) but the QEM optimiser itself is out of scope of this build.
 import torch as t
 import torch.nn as nn
 
-from .dims import PT, Dim, dims_of, named_to_dim, dim_to_named
+from .dims import PT, ExpPT, Dim, dims_of, named_to_dim, dim_to_named
 from .model import Plate, check_name, flatten_tree, tensordict2tree
 from .samplers import PermutationSampler, Sampler, on_device
 
@@ -160,6 +160,10 @@ class BoundPlate(nn.Module):
                              (self._qem_params, None)):
             for k in store._keys:
                 raw = getattr(store, f"t_{k}")
+                if trans is not None and trans[k] is t.exp:
+                    p = named_to_pt(store._names[k], raw, all_platedims)
+                    out[k] = ExpPT(p.x, p.dims)            # exp() applied lazily (or inside the producer)
+                    continue
                 if trans is not None:
                     raw = trans[k](raw)
                 out[k] = named_to_pt(store._names[k], raw, all_platedims)

@@ -27,6 +27,8 @@ struct NormalDesc {
     int64_t v_vs[MAXD], v_os[MAXD];   // value / out strides over the value's keep dims
     int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
     int64_t l_os, s_os;               // out strides along the loc / scale dims
+    int32_t log_scale;                // scl holds log(scale)
+    float out_scale, add_const;       // out = out_scale * log_prob + add_const
 };
 
 template <int EMAX>
@@ -46,13 +48,16 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
         float v = 0.f;
         if ((int)e < E) {
             const float sc = d.scl[(int64_t)is * d.s_rs + e];
-            v = 0.5f / (sc * sc);
+            v = d.log_scale ? 0.5f * expf(-2.f * sc) : 0.5f / (sc * sc);
         }
         w[i] = v;
     }
     for (uint32_t is = tid; is < d.NS; is += 256) {
         float s = 0.f;
-        for (int e = 0; e < E; ++e) s += logf(d.scl[(int64_t)is * d.s_rs + e]);
+        for (int e = 0; e < E; ++e) {
+            const float sc = d.scl[(int64_t)is * d.s_rs + e];
+            s += d.log_scale ? sc : logf(sc);
+        }
         lg[is] = s + (float)E * 0.91893853320467274178f;
     }
     for (uint32_t i = tid; i < (l1 - l0) * (uint32_t)Ep; i += 256) {
@@ -108,13 +113,14 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
                     acc = fmaf(dd[4 * q + 3], ww.w, acc);
                 }
             }
-            if (active) orow[(int64_t)is * d.s_os] = -acc - lg[is];
+            if (active) orow[(int64_t)is * d.s_os] = (-acc - lg[is]) * d.out_scale + d.add_const;
         }
     }
 }
 
 // Returns ALAN_ERR_UNSUPPORTED when the canonical problem is not an outer-product Normal.
-int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev) {
+int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
+                            const EvPair &ev) {
     if (c.nf != 3 || c.nr != 1) return ALAN_ERR_UNSUPPORTED;
     for (int f = 0; f < 3; ++f)
         if (c.f[f].dtype != ALAN_F32 || c.f[f].rs[0] != 1) return ALAN_ERR_UNSUPPORTED;
@@ -156,6 +162,9 @@ int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev
     d.E = (int)E;
     d.Ep = (int)((E + 3) & ~3);
     d.NV = (uint32_t)NV;
+    d.log_scale = log_scale ? 1 : 0;
+    d.out_scale = out_scale;
+    d.add_const = (float)add_const;
 
     const uint32_t gx = (uint32_t)((NV + 255) / 256);
     // enough workgroups to fill the chip: split the loc rows over grid.y

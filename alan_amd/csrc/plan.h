@@ -23,6 +23,7 @@ struct GroupDesc {
     void *out;
     int64_t oks[MAXD];
     double add_const;
+    float out_scale;   // producer modes: out = out_scale * sum + add_const
 };
 
 struct GroupLaunch {
@@ -58,7 +59,8 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
 struct EvPair {
     hipEvent_t start = nullptr, stop = nullptr;
 };
-int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl);
+int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl,
+               float out_scale = 1.f);
 
 int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream,
                  const EvPair &ev = EvPair());
@@ -78,6 +80,7 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
                 size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 
 // normal.hip: register-blocked Normal producer (value / loc / scale on disjoint dims).
-int try_launch_normal_outer(const Canon &c, hipStream_t stream, const EvPair &ev);
+int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
+                            const EvPair &ev);
 
 }  // namespace alan

@@ -141,7 +141,7 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
     return ALAN_OK;
 }
 
-int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl) {
+int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl, float out_scale) {
     std::memset(&gd, 0, sizeof(gd));
     gd.nf = c.nf;
     gd.nk = c.nk;
@@ -156,6 +156,7 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
     gd.out = const_cast<void *>(c.o.p);
     for (int j = 0; j < c.nk; ++j) gd.oks[j] = c.o.ks[j];
     gd.add_const = add_const;
+    gd.out_scale = out_scale;
     if (gd.nr == 0) {  // the kernel's single-dim fast path reads rs[0]
         gd.nr = 1;
         gd.rdiv[0] = make_fastdiv(1);
@@ -217,15 +218,17 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     int rc = canonicalise(d, keep_mask, red_mask, out, c);
     if (rc != ALAN_OK) return rc;
     const int compute = out.dtype;
-    if (mode == ALAN_MODE_NORMAL) {
-        rc = try_launch_normal_outer(c, stream, ev);
+    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI;
+    const float out_scale = producer ? out.scale : 1.f;
+    if (mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE) {
+        rc = try_launch_normal_outer(c, mode == ALAN_MODE_NORMAL_LOGSCALE, out_scale, add_const, stream, ev);
         if (rc != ALAN_ERR_UNSUPPORTED) return rc;
     }
     const RowsPlan rp = plan_rows(c, mode, compute);
     if (rp.ok) return launch_rows(c, rp, mode, add_const, nullptr, 0, stream, ev);
     GroupDesc gd;
     GroupLaunch gl;
-    rc = plan_group(c, out.dtype, add_const, gd, gl);
+    rc = plan_group(c, out.dtype, add_const, gd, gl, out_scale);
     if (rc != ALAN_OK) return rc;
     return launch_group(gd, gl, mode, compute, stream, ev);
 }
@@ -251,9 +254,10 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
     }
     if (plate && d.mode != ALAN_MODE_LSE) return ALAN_ERR_BAD_DESC;
     if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM && d.mode != ALAN_MODE_WEXPSUM &&
-        d.mode != ALAN_MODE_NORMAL && d.mode != ALAN_MODE_BERNOULLI)
+        d.mode != ALAN_MODE_NORMAL && d.mode != ALAN_MODE_BERNOULLI && d.mode != ALAN_MODE_NORMAL_LOGSCALE)
         return ALAN_ERR_BAD_DESC;
-    if (d.mode == ALAN_MODE_NORMAL && d.n_factors != 3) return ALAN_ERR_BAD_DESC;
+    if ((d.mode == ALAN_MODE_NORMAL || d.mode == ALAN_MODE_NORMAL_LOGSCALE) && d.n_factors != 3)
+        return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_BERNOULLI && d.n_factors != 2) return ALAN_ERR_BAD_DESC;
     return ALAN_OK;
 }

@@ -71,13 +71,16 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
                 if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.w.rs[k];
             }
         }
-        if (MODE == ALAN_MODE_NORMAL) {
+        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
             // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))
             const T v = load_as<T>(d.f[0].p, d.f[0].dtype, off[0]);
             const T loc = load_as<T>(d.f[1].p, d.f[1].dtype, off[1]);
             const T sc = load_as<T>(d.f[2].p, d.f[2].dtype, off[2]);
             const T z = v - loc;
-            s += -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+            if (MODE == ALAN_MODE_NORMAL)
+                s += -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+            else  // sc = log(scale)
+                s += -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178);
             continue;
         }
         if (MODE == ALAN_MODE_BERNOULLI) {
@@ -135,6 +138,8 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
     }
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
+        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI)
+            v *= (T)d.out_scale;
         v += (T)d.add_const;
         store_as<T>(d.out, d.out_dtype, obase, v);
     }
@@ -162,6 +167,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
         case ALAN_MODE_BERNOULLI: return launch_group_T<T, ALAN_MODE_BERNOULLI>(gd, gl, stream, ev); \
+        case ALAN_MODE_NORMAL_LOGSCALE: return launch_group_T<T, ALAN_MODE_NORMAL_LOGSCALE>(gd, gl, stream, ev); \
     }
     if (compute_dtype == ALAN_F32) {
         ALAN_DISPATCH(float)

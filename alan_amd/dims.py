@@ -146,6 +146,39 @@ class PT:
         return PT(self.x.detach(), self.dims)
 
 
+class ExpPT(PT):
+    """A parameter declared as OptParam(..., transformation=torch.exp): behaves as PT(exp(raw)) -- ``.x``
+    materialises the transform on first use -- but keeps ``raw`` so the fused Normal producer can take the
+    log-scale directly (alan_reduce mode NORMAL_LOGSCALE) and skip the exp launch."""
+    __slots__ = ("raw", "_val")
+
+    def __init__(self, raw, dims=()):
+        self.raw = raw
+        self._val = None
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @property
+    def x(self):
+        if self._val is None:
+            self._val = self.raw.exp()
+        return self._val
+
+    @property
+    def materialised(self):
+        return self._val is not None
+
+    @property
+    def n_pos(self):
+        return self.raw.ndim - len(self.dims)
+
+    def size_of(self, dim_id):
+        return self.raw.shape[self.ids.index(dim_id)]
+
+    def detach(self):
+        return ExpPT(self.raw.detach(), self.dims)
+
+
 def pt_order(pts, lead=(), last=()):
     """Ordered union of the dims of several PTs: ``lead`` dims first, ``last`` dims last, others between.
     Returns (dims, ids)."""

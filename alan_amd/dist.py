@@ -14,7 +14,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -61,17 +61,25 @@ class _FusedNormalLogProb(t.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, value, loc, scale):
+        """spec = (value dims, loc dims, scale dims, out dims, log_scale, (a, b)): with ``log_scale`` the third
+        tensor is log(scale) (and its gradient is returned wrt that); the result is a * log_prob + b."""
         from . import engine as E
-        vd, ld, sd, od = spec
-        out = E.normal_logprob((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd), od)
+        vd, ld, sd, od, log_scale, affine = spec
+        out = E.normal_logprob((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd), od,
+                               log_scale=log_scale, affine=affine)
         ctx.spec = spec
         ctx.save_for_backward(value, loc, scale)
         return out
 
     @staticmethod
     def backward(ctx, G):
-        vd, ld, sd, od = ctx.spec
+        vd, ld, sd, od, log_scale, affine = ctx.spec
         value, loc, scale = ctx.saved_tensors
+        if affine[0] != 1.0:
+            G = G * affine[0]
+        raw_scale = scale
+        if log_scale:
+            scale = scale.detach().exp()
         letters = {}
 
         def sub(dims, event=True):
@@ -94,7 +102,9 @@ class _FusedNormalLogProb(t.autograd.Function):
         if ctx.needs_input_grad[3]:
             q = es(f"{g},{V}->{S}", G, v * v) - 2 * es(f"{g},{V},{L}->{S}", G, v, l) + es(f"{g},{L}->{S}", G, l * l)
             gs = q / (s * s * s) - es(f"{g}->{sub(sd, False)}", G).unsqueeze(-1) / s
-            gs = gs.reshape(scale.shape)
+            if log_scale:
+                gs = gs * s                                  # d/d log(scale)
+            gs = gs.reshape(raw_scale.shape)
         return None, gv, gl, gs
 
 
@@ -106,18 +116,20 @@ class _FusedBernoulliLogProb(t.autograd.Function):
     @staticmethod
     def forward(ctx, spec, value, logits):
         from . import engine as E
-        vd, ld, od = spec
-        out = E.bernoulli_logprob((value.detach(), vd), (logits.detach(), ld), od)
+        vd, ld, od, affine = spec
+        out = E.bernoulli_logprob((value.detach(), vd), (logits.detach(), ld), od, affine)
         ctx.spec = spec
         ctx.save_for_backward(value, logits)
         return out
 
     @staticmethod
     def backward(ctx, G):
-        vd, ld, od = ctx.spec
+        vd, ld, od, affine = ctx.spec
         value, logits = ctx.saved_tensors
         if not ctx.needs_input_grad[2]:
             return None, None, None
+        if affine[0] != 1.0:
+            G = G * affine[0]
         dims, ids = pt_order((PT(value, vd), PT(logits, ld)))
         nv, nl = value.ndim - len(vd), logits.ndim - len(ld)
         nev = max(nv, nl)
@@ -196,11 +208,13 @@ class TorchDimDist:
             x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
         return PT(x, (*extra, *self.all_arg_dims))
 
-    def log_prob_pt(self, x, dim_order=None, sum_dims=()):
+    def log_prob_pt(self, x, dim_order=None, sum_dims=(), affine=None):
         """log p(x) as a PT over (x's dims) U (parameter dims); positional sample/batch dims are summed
         out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of the result:
         ``lead`` dims outermost, ``last`` dims innermost, any others in between.  ``sum_dims``: first-class
-        dims to sum out as well (a data-only plate's sum, logpq.py:149, fused into the producer)."""
+        dims to sum out as well (a data-only plate's sum, logpq.py:149, fused into the producer).
+        ``affine = (a, b, allowed ids)``: if every dim of the result is in ``allowed`` the result is
+        a * log_prob + b instead (the caller re-checks the same condition on the returned dims)."""
         x = PT.of(x)
         lead, last = dim_order if dim_order is not None else ((), ())
         dims, ids = pt_order((x, *self.kwargs.values()), lead, last)
@@ -210,20 +224,26 @@ class TorchDimDist:
         out_dims = tuple(d for d in dims if id(d) not in drop)
         n_sample = x.n_pos - self.sample_batch_ndim - self.sample_event_ndim
         assert n_sample >= 0
+        ab = (1.0, 0.0)
+        if affine is not None and {id(d) for d in out_dims} <= set(affine[2]):
+            ab = (float(affine[0]), float(affine[1]))
         kind = self._fusable(x)
         if kind == "normal":
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
-            spec = (x.dims, loc.dims, scale.dims, out_dims)
-            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.x), out_dims)
+            lazy = isinstance(scale, ExpPT) and not scale.materialised
+            spec = (x.dims, loc.dims, scale.dims, out_dims, lazy, ab)
+            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.raw if lazy else scale.x), out_dims)
         if kind == "bernoulli":
             logits = self.kwargs["logits"]
-            spec = (x.dims, logits.dims, out_dims)
+            spec = (x.dims, logits.dims, out_dims, ab)
             return PT(_FusedBernoulliLogProb.apply(spec, x.x, logits.x), out_dims)
         d = self._build(ids, n_sample)
         lp = d.log_prob(pt_align(x, ids))
         axes = [i for i, d_ in enumerate(dims) if id(d_) in drop] + list(range(len(ids), lp.ndim))
         if axes:
             lp = lp.sum(tuple(axes))
+        if ab != (1.0, 0.0):
+            lp = t.add(ab[1], lp, alpha=ab[0])
         return PT(lp, out_dims)
 
     def log_prob(self, x, dim_order=None):
@@ -237,6 +257,9 @@ class TorchDimDist:
             return None
         if self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"}:
             kind, args = "normal", (x, self.kwargs["loc"], self.kwargs["scale"])
+            sc = args[2]
+            if isinstance(sc, ExpPT) and not sc.materialised:        # look at the raw parameter instead
+                args = (x, args[1], PT(sc.raw, sc.dims))
         elif self.dist is td.Bernoulli and set(self.kwargs) == {"logits"}:
             kind, args = "bernoulli", (x, self.kwargs["logits"])
         else:
@@ -374,9 +397,9 @@ class Dist(nn.Module):
             p = PT(pt_align(p, ids).contiguous(), want)
         return p
 
-    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=()):
+    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=(), affine=None):
         """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""
-        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order, sum_dims=sum_dims), None
+        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order, sum_dims=sum_dims, affine=affine), None
 
 
 LAMBDA_BACKEND = "vmap"

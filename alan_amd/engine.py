@@ -45,7 +45,7 @@ def _out_order(factors, keep, sizes):
 
 
 def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=None, add_const=0.0,
-            scales=None):
+            scales=None, out_scale=1.0):
     space = list(sizes)
     if len(space) > N.MAX_DIMS:
         raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
@@ -66,7 +66,7 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
         N.fill_tensor(desc.factor[i], x, _strides(x, list(dims), space), 1.0 if scales is None else scales[i])
     if weight is not None:
         N.fill_tensor(desc.weight, weight[0], _strides(weight[0], list(weight[1]), space))
-    N.fill_tensor(desc.out, out, _strides(out, list(out_dims), space))
+    N.fill_tensor(desc.out, out, _strides(out, list(out_dims), space), out_scale)
     if lse_out is not None:
         N.fill_tensor(desc.lse_out, lse_out[0], _strides(lse_out[0], list(lse_out[1]), space))
     desc.add_const = add_const
@@ -204,9 +204,9 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
 
 
 # --------------------------------------------------------------------------- fused factor producer
-def _produce(mode, args, out_dims):
+def _produce(mode, args, out_dims, affine=(1.0, 0.0)):
     """One producer launch: ``args`` are (tensor, leading first-class dims) pairs whose trailing positional
-    dims are right-aligned; every dim not in ``out_dims`` is summed out."""
+    dims are right-aligned; every dim not in ``out_dims`` is summed out; out = affine[0] * sum + affine[1]."""
     tok = _Tokens()
     npos = max(x.ndim - len(d) for x, d in args)
     factors = []
@@ -219,22 +219,25 @@ def _produce(mode, args, out_dims):
     roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
     dtype = _result_dtype([x for x, _ in factors])
     out = t.empty([sizes[d] for d in odims], dtype=dtype, device=args[0][0].device)
-    _launch(mode, factors, sizes, roles, out, odims)
+    _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]))
     return out
 
 
-def normal_logprob(value, loc, scale, out_dims):
+def normal_logprob(value, loc, scale, out_dims, log_scale=False, affine=(1.0, 0.0)):
     """log N(value; loc, scale) summed over every positional (sample/batch/event) dim -- and over any
     first-class dim missing from ``out_dims`` (a data-only plate's sum, logpq.py:149) -- as ONE launch
     (alan_reduce mode NORMAL): the [.., K, K, K, d] broadcast the reference materialises
     (TorchDimDist.py:127-162) never exists.  Each argument is (tensor, leading first-class dims);
-    trailing positional dims are right-aligned.  Returns a tensor laid out as ``out_dims``."""
-    return _produce(N.MODE_NORMAL, (value, loc, scale), out_dims)
+    trailing positional dims are right-aligned.  Returns a tensor laid out as ``out_dims``.
+    ``log_scale``: the third argument holds log(scale) (a learned scale's raw parameter, Param.py:18-25);
+    ``affine = (a, b)``: the launch writes a * log_prob + b (the -(log Q + log K) of logpq.py:234-235)."""
+    mode = N.MODE_NORMAL_LOGSCALE if log_scale else N.MODE_NORMAL
+    return _produce(mode, (value, loc, scale), out_dims, affine)
 
 
-def bernoulli_logprob(value, logits, out_dims):
+def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):
     """log Bernoulli(value; logits=logits), summed like ``normal_logprob`` (alan_reduce mode BERNOULLI)."""
-    return _produce(N.MODE_BERNOULLI, (value, logits), out_dims)
+    return _produce(N.MODE_BERNOULLI, (value, logits), out_dims, affine)
 
 
 # --------------------------------------------------------------------------- elimination planner

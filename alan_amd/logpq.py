@@ -19,7 +19,7 @@ import torch as t
 import torch.utils.checkpoint
 
 from . import engine as E
-from .dims import PT, pt_add, pt_align
+from .dims import PT, ExpPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
 from .timeseries import Timeseries
@@ -53,7 +53,14 @@ def _logPQ_plate_checkpointed(**kwargs):
         return _logPQ_plate(**kwargs)
     dims = []
 
+    def fresh(tree):
+        # lazily-transformed parameters cache their value on first use: give the forward run and the
+        # recomputation identical (un-materialised) starting points
+        return {k: (fresh(v) if isinstance(v, dict) else ExpPT(v.raw, v.dims) if isinstance(v, ExpPT) else v)
+                for k, v in tree.items()}
+
     def body(kw):
+        kw = {**kw, "inputs_params": fresh(kw["inputs_params"]), "scope": fresh(kw["scope"])}
         out = _logPQ_plate(**kw)
         dims.append(out.dims)
         return out.x
@@ -169,24 +176,33 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
 
     logPs, total_logQ, Kinits = [], None, []
     init_Ks = [groupvarname2Kdim[varname2groupvarname[d.init]] for d in prog_P.values() if isinstance(d, Timeseries)]
+    # A one-variable group whose log Q carries no parent K (a factorised Q: reduce_logQ is then the
+    # identity) has its -(log Q + log K) written by the log-prob producer itself.
+    own = {id(Kdim), *(id(d) for d in active_platedims)}
+    K = Kdim.size
+    single = len(prog_P) == 1 and not any(isinstance(d, Timeseries) for d in (*prog_P.values(), *prog_Q.values()))
+    extra = {"affine": (-1.0, -math.log(K), own)} if single else {}
     for var in prog_P:
         x = sample[var]
         assert isinstance(x, PT)
         lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
                                            dimcache=dimcache)
         lq, Kinit_q = prog_Q[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
-                                           dimcache=dimcache)
+                                           dimcache=dimcache, **extra)
         if Kinit_q is not None:
             assert Kinit_p is Kinit_q
         if Kinit_p is not None:
             Kinits.append(Kinit_p)
         logPs.append(lp)
         total_logQ = lq if total_logQ is None else pt_add(total_logQ, lq)
-    lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
-    K = total_logQ.size_of(id(Kdim))
-    # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
-    # factors on the fly, so pre-adding them would only cost extra launches)
-    neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
+    assert K == total_logQ.size_of(id(Kdim))
+    if single and set(total_logQ.ids) <= own:
+        neg_q = total_logQ                           # already -(log Q + log K)
+    else:
+        lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
+        # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
+        # factors on the fly, so pre-adding them would only cost extra launches)
+        neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
     logPs.sort(key=lambda p: -p.x.numel())
     for lp in logPs[2:]:                       # large Groups: keep the factor count of the step small
         neg_q = pt_add(neg_q, lp)

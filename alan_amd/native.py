@@ -14,7 +14,7 @@ MAX_FACTORS = 6
 
 F32, F64 = 0, 1
 KEEP, REDUCE, PLATE = 0, 1, 2
-MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI = 0, 1, 2, 3, 4
+MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSCALE = 0, 1, 2, 3, 4, 5
 
 _STATUS = {
     -1: "bad descriptor",

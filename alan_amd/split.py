@@ -14,7 +14,7 @@ import warnings
 import torch as t
 import torch.distributed as dist
 
-from .dims import PT, Dim, dims_of, is_tensor
+from .dims import PT, ExpPT, Dim, dims_of, is_tensor
 
 
 class NoSplit:
@@ -82,8 +82,9 @@ class Split:
                 elif isinstance(v, PT):
                     assert v.has(orig), f"{k} lacks the plate dim {orig} being split"
                     ax = v.ids.index(id(orig))
-                    for o, piece, nd in zip(outs, v.x.split(sizes, ax), new_dims):
-                        o[k] = PT(piece, (*v.dims[:ax], nd, *v.dims[ax + 1:]))
+                    lazy = isinstance(v, ExpPT) and not v.materialised
+                    for o, piece, nd in zip(outs, (v.raw if lazy else v.x).split(sizes, ax), new_dims):
+                        o[k] = (ExpPT if lazy else PT)(piece, (*v.dims[:ax], nd, *v.dims[ax + 1:]))
                 else:
                     assert is_tensor(v)
                     assert orig in set(dims_of(v)), f"{k} lacks the plate dim {orig} being split"

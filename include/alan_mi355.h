@@ -64,12 +64,16 @@ typedef enum {
                               exactly 3 factors (value, loc, scale);
                               out = sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
                               R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised */
-    ALAN_MODE_BERNOULLI = 4 /* fused factor PRODUCER for td.Bernoulli(logits=...) (same reference lines):
+    ALAN_MODE_BERNOULLI = 4, /* fused factor PRODUCER for td.Bernoulli(logits=...) (same reference lines):
                               exactly 2 factors (value, logits);
                               out = sum_R [ logsigmoid(logits) - (1 - value) * logits ]
                               (= -binary_cross_entropy_with_logits, what torch's Bernoulli.log_prob evaluates);
                               R = event/batch dims and, for a data-only plate, the plate dims (logpq.py:149) */
+    ALAN_MODE_NORMAL_LOGSCALE = 5 /* ALAN_MODE_NORMAL whose third factor is log(scale): the exp() transform of a
+                              learned scale parameter (Param.py:18-25, transformation=t.exp) folded into the producer */
 } alan_mode_t;
+/* Producer modes (NORMAL, NORMAL_LOGSCALE, BERNOULLI) write  out = out.scale * sum_R(log-prob) + add_const, so the
+ * "-(log Q + log K)" of logpq.py:234-235 costs no extra pass; out.scale must be 1 in the other modes. */
 
 typedef struct {
     const void *data;                 /* device pointer to element 0 */

@@ -381,3 +381,51 @@ def test_normal_producer_sums_a_data_plate():
     t.testing.assert_close(summed.x, full.x.sum(pos), rtol=2e-5, atol=2e-5)
     with pytest.raises(Exception, match="neither the value nor the parameters"):
         dist.log_prob_pt(y, ([dm], []), sum_dims=(Dim("plate_9", 3),))
+
+
+@pytest.mark.parametrize("shapes", ["movielens", "mean_field_q"])
+def test_fused_normal_log_scale_and_affine(shapes):
+    """Normal(loc, exp(raw)) with the exp folded into the producer (mode NORMAL_LOGSCALE) and the
+    -(log Q + log K) epilogue (out.scale / add_const): values and gradients wrt (value, loc, RAW scale) against
+    the unfused path (exp kernel + torch.distributions + t.add)."""
+    import math
+    import alan_amd.dist as D
+    from alan_amd.dims import Dim, PT, ExpPT
+    g = t.Generator().manual_seed(4)
+    M, K, Ev = 9, 5, 18
+    dm, dz, dmu, dpsi = Dim("plate_1", M), Dim("K_z", K), Dim("K_mu", K), Dim("K_psi", K)
+    if shapes == "movielens":
+        spec = [((M, K, Ev), (dm, dz)), ((K, Ev), (dmu,)), ((K, Ev), (dpsi,))]
+    else:                                # q(z) = N(loc[m], exp(raw[m])): the shape the affine epilogue applies to
+        spec = [((M, K, Ev), (dm, dz)), ((M, Ev), (dm,)), ((M, Ev), (dm,))]
+    raw = [t.randn(s, generator=g) for s, _ in spec]
+    raw[2] = 0.4 * raw[2]
+    own = {id(dm), id(dz)}
+    aff = (-1.0, -math.log(K), own)
+
+    def run(fuse):
+        D.FUSE_NORMAL = fuse
+        try:
+            leaves = [r.clone().to(DEV).requires_grad_(True) for r in raw]
+            x, loc = PT(leaves[0], spec[0][1]), PT(leaves[1], spec[1][1])
+            sc = ExpPT(leaves[2], spec[2][1])
+            lp = D.TorchDimDist(t.distributions.Normal, loc=loc, scale=sc).log_prob_pt(x, ([dm], [dz]), affine=aff)
+            assert sc.materialised == (not fuse)
+            wgt = t.randn(lp.x.shape, generator=t.Generator().manual_seed(1)).to(DEV)
+            grads = t.autograd.grad((lp.x * wgt).sum(), leaves)
+            return lp, grads
+        finally:
+            D.FUSE_NORMAL = True
+
+    (lp_f, gf), (lp_t, gt) = run(True), run(False)
+    assert [str(d) for d in lp_f.dims] == [str(d) for d in lp_t.dims]
+    t.testing.assert_close(lp_f.x, lp_t.x, rtol=2e-5, atol=2e-4)
+    plain = D.TorchDimDist(t.distributions.Normal, loc=PT(raw[1].to(DEV), spec[1][1]),
+                           scale=PT(raw[2].to(DEV).exp(), spec[2][1])).log_prob_pt(PT(raw[0].to(DEV), spec[0][1]),
+                                                                                  ([dm], [dz]))
+    applied = {id(d) for d in plain.dims} <= own
+    assert applied == (shapes == "mean_field_q")
+    want = (-plain.x - math.log(K)) if applied else plain.x
+    t.testing.assert_close(lp_f.x, want, rtol=2e-5, atol=2e-4)
+    for a, b in zip(gf, gt):
+        t.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
