@@ -8,7 +8,9 @@
 // (same arithmetic as torch.distributions.Normal.log_prob: no expanded square, so no cancellation.)
 // A thread owns one value row in registers and walks the (loc row, scale row) cross product; loc/scale
 // rows are workgroup-uniform, so they come from LDS as broadcast reads: ~1.4 issue slots per (output, e).
-// The kernel is bound by the store of F (HBM write), not by arithmetic.
+// The event length is a template parameter (tables zero-padded to it): the LDS reads of a scale row are then
+// straight-line and issue back to back -- with run-time bounds every 16-byte read sat in its own basic block
+// behind an s_waitcnt, and the kernel ran at LDS latency (26 us at K=30 instead of 17).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -29,36 +31,37 @@ struct NormalDesc {
     int64_t l_os, s_os;               // out strides along the loc / scale dims
     int32_t log_scale;                // scl holds log(scale)
     float out_scale, add_const;       // out = out_scale * log_prob + add_const
+    int32_t dbg;                      // ablation knob (ALAN_NORMAL_ABLATE): 1 prologue only, 2 no stores, 3 one scale row
+    int32_t rows_contig;              // value rows of a workgroup are one contiguous, 16-byte aligned block
+    int32_t vstage_off;               // LDS offset (floats) of the value staging area
 };
 
 template <int EMAX>
 __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     extern __shared__ __align__(16) float lds[];
-    const int E = d.E, Ep = d.Ep;
+    const int E = d.E;
+    constexpr int Ep = EMAX;              // table row stride: the event length padded to the template's
     float *w = lds;                       // [NS][Ep], zero padded
     float *lg = w + (size_t)d.NS * Ep;    // [NS]
     float *mu = lg + ((d.NS + 3) & ~3u);  // [l_chunk][Ep]
+    float *lgs = mu + (size_t)d.l_chunk * Ep;   // [NS][Ep] log(scale), zero padded (prologue only)
     const int tid = threadIdx.x;
     const uint32_t l0 = blockIdx.y * d.l_chunk;
     const uint32_t l1 = min(d.NL, l0 + d.l_chunk);
 
-    // ---- workgroup-uniform tables
+    // ---- workgroup-uniform tables: every scale element is loaded once, by its own thread (all loads in
+    // flight together); the per-row log-normaliser is then summed from LDS
+#pragma unroll 4
     for (uint32_t i = tid; i < d.NS * (uint32_t)Ep; i += 256) {
         const uint32_t is = i / Ep, e = i - is * Ep;
-        float v = 0.f;
+        float v = 0.f, lgv = 0.f;
         if ((int)e < E) {
             const float sc = d.scl[(int64_t)is * d.s_rs + e];
             v = d.log_scale ? 0.5f * expf(-2.f * sc) : 0.5f / (sc * sc);
+            lgv = d.log_scale ? sc : logf(sc);
         }
         w[i] = v;
-    }
-    for (uint32_t is = tid; is < d.NS; is += 256) {
-        float s = 0.f;
-        for (int e = 0; e < E; ++e) {
-            const float sc = d.scl[(int64_t)is * d.s_rs + e];
-            s += d.log_scale ? sc : logf(sc);
-        }
-        lg[is] = s + (float)E * 0.91893853320467274178f;
+        lgs[i] = lgv;
     }
     for (uint32_t i = tid; i < (l1 - l0) * (uint32_t)Ep; i += 256) {
         const uint32_t il = i / Ep, e = i - il * Ep;
@@ -80,40 +83,80 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
         }
     }
     float v[EMAX];
+    if (d.rows_contig) {
+        // the workgroup's 256 value rows are one contiguous block: stream it into LDS with 16-byte loads
+        // (each thread reading its own row from global memory costs one cache line per lane per load: the
+        // texture addresser, not HBM, then bounds the prologue)
+        float *vs = lds + d.vstage_off;
+        const uint32_t r0 = blockIdx.x * 256u;
+        const uint32_t nrow = min(256u, d.NV - r0);
+        const int n4 = (int)((nrow * (uint32_t)E + 3u) >> 2);
+        const float4 *src = reinterpret_cast<const float4 *>(d.val + (int64_t)r0 * E);
+        float4 *dst = reinterpret_cast<float4 *>(vs);
+        const int64_t lim4 = ((int64_t)d.NV * E + 3) >> 2;          // 16-byte units in the whole value tensor
+        const int64_t base4 = ((int64_t)r0 * E) >> 2;
+        for (int i = tid; i < n4; i += 256)
+            if (base4 + i < lim4) dst[i] = src[i];                   // (the allocation is padded to 16 bytes by torch)
+        __syncthreads();
+        const float *row = vs + (size_t)min((uint32_t)tid, nrow - 1u) * E;
 #pragma unroll
-    for (int e = 0; e < EMAX; ++e) v[e] = (e < E) ? d.val[voff + e] : 0.f;
+        for (int e = 0; e < EMAX; ++e) {
+            const float x = row[min(e, E - 1)];
+            v[e] = e < E ? x : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const float x = d.val[voff + min(e, E - 1)];   // branch-free: every load is issued, pad slots zeroed
+            v[e] = e < E ? x : 0.f;
+        }
+    }
+    __syncthreads();
+    for (uint32_t is = tid; is < d.NS; is += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) s += lgs[(size_t)is * Ep + e];   // (pad slots hold 0)
+        lg[is] = s + (float)E * 0.91893853320467274178f;
+    }
     __syncthreads();
 
+    if (d.dbg == 1) {
+        float q = lg[tid % d.NS];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) q += v[e];
+        if (active) d.out[ooff + (int64_t)l0 * d.l_os] = q;
+        return;
+    }
+    const uint32_t ns_run = d.dbg == 3 ? 1u : d.NS;
+    const bool do_store = active && d.dbg != 2;
     for (uint32_t il = l0; il < l1; ++il) {
         const float4 *m4 = reinterpret_cast<const float4 *>(mu + (size_t)(il - l0) * Ep);
         float dd[EMAX];
 #pragma unroll
         for (int q = 0; q < EMAX / 4; ++q) {
-            if (q * 4 < Ep) {
-                const float4 m = m4[q];
-                const float a = v[4 * q] - m.x, b = v[4 * q + 1] - m.y, c = v[4 * q + 2] - m.z,
-                            e = v[4 * q + 3] - m.w;
-                dd[4 * q] = a * a;
-                dd[4 * q + 1] = b * b;
-                dd[4 * q + 2] = c * c;
-                dd[4 * q + 3] = e * e;
-            }
+            const float4 m = m4[q];
+            const float a = v[4 * q] - m.x, b = v[4 * q + 1] - m.y, c = v[4 * q + 2] - m.z, e = v[4 * q + 3] - m.w;
+            dd[4 * q] = a * a;
+            dd[4 * q + 1] = b * b;
+            dd[4 * q + 2] = c * c;
+            dd[4 * q + 3] = e * e;
         }
         float *orow = d.out + ooff + (int64_t)il * d.l_os;
-        for (uint32_t is = 0; is < d.NS; ++is) {
+        for (uint32_t is = 0; is < ns_run; ++is) {
             const float4 *w4 = reinterpret_cast<const float4 *>(w + (size_t)is * Ep);
+            float4 ww[EMAX / 4];
+#pragma unroll
+            for (int q = 0; q < EMAX / 4; ++q) ww[q] = w4[q];      // straight-line: all reads issue together
             float acc = 0.f;
 #pragma unroll
             for (int q = 0; q < EMAX / 4; ++q) {
-                if (q * 4 < Ep) {
-                    const float4 ww = w4[q];
-                    acc = fmaf(dd[4 * q], ww.x, acc);
-                    acc = fmaf(dd[4 * q + 1], ww.y, acc);
-                    acc = fmaf(dd[4 * q + 2], ww.z, acc);
-                    acc = fmaf(dd[4 * q + 3], ww.w, acc);
-                }
+                acc = fmaf(dd[4 * q], ww[q].x, acc);
+                acc = fmaf(dd[4 * q + 1], ww[q].y, acc);
+                acc = fmaf(dd[4 * q + 2], ww[q].z, acc);
+                acc = fmaf(dd[4 * q + 3], ww[q].w, acc);
             }
-            if (active) orow[(int64_t)is * d.s_os] = (-acc - lg[is]) * d.out_scale + d.add_const;
+            const float res = (-acc - lg[is]) * d.out_scale + d.add_const;
+            if (do_store || res == 12345.678f) orow[(int64_t)is * d.s_os] = res;
         }
     }
 }
@@ -160,11 +203,28 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
     d.scl = (const float *)c.f[2].p;
     d.out = (float *)const_cast<void *>(c.o.p);
     d.E = (int)E;
-    d.Ep = (int)((E + 3) & ~3);
+    static const int kEmax[] = {4, 8, 12, 16, 20, 24, 28, 32, 48, 64};
+    d.Ep = 64;
+    for (int em : kEmax)
+        if (E <= em) {
+            d.Ep = em;      // = the kernel's template parameter: table row stride
+            break;
+        }
     d.NV = (uint32_t)NV;
     d.log_scale = log_scale ? 1 : 0;
     d.out_scale = out_scale;
     d.add_const = (float)add_const;
+    if (const char *e = getenv("ALAN_NORMAL_ABLATE")) d.dbg = atoi(e);
+    {   // value rows contiguous in row-index order?  (voff(r) = r * E)
+        bool contig = reinterpret_cast<uintptr_t>(d.val) % 16 == 0;   // (a workgroup's block starts 1 KiB-aligned)
+        int64_t run = E;
+        for (int k = d.nv - 1; k >= 0; --k) {
+            contig = contig && d.v_vs[k] == run;
+            run *= d.vdiv[k].d;
+        }
+        if (const char *e = getenv("ALAN_NORMAL_STAGE")) contig = contig && atoi(e) != 0;   // tuning knob
+        d.rows_contig = contig ? 1 : 0;
+    }
 
     const uint32_t gx = (uint32_t)((NV + 255) / 256);
     // enough workgroups to fill the chip: split the loc rows over grid.y
@@ -177,18 +237,30 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
     if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
     d.l_chunk = (d.NL + gy - 1) / gy;
     gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
-    const size_t lds = ((size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep) * sizeof(float);
+    size_t lds_f = 2 * (size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep;
+    if (d.rows_contig) {
+        d.vstage_off = (int)((lds_f + 3) & ~(size_t)3);
+        lds_f = d.vstage_off + 256 * (size_t)d.E + 4;
+    }
+    const size_t lds = lds_f * sizeof(float);
     if (lds > 64 * 1024) return ALAN_ERR_UNSUPPORTED;
 
     const dim3 grid(gx, gy), block(256);
-    if (d.Ep <= 8)
-        hipExtLaunchKernelGGL(normal_outer_kernel<8>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
-    else if (d.Ep <= 16)
-        hipExtLaunchKernelGGL(normal_outer_kernel<16>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
-    else if (d.Ep <= 32)
-        hipExtLaunchKernelGGL(normal_outer_kernel<32>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
-    else
-        hipExtLaunchKernelGGL(normal_outer_kernel<64>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
+#define ALAN_NORMAL_CASE(EM) \
+    case EM: hipExtLaunchKernelGGL(normal_outer_kernel<EM>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d); break
+    switch (d.Ep) {
+        ALAN_NORMAL_CASE(4);
+        ALAN_NORMAL_CASE(8);
+        ALAN_NORMAL_CASE(12);
+        ALAN_NORMAL_CASE(16);
+        ALAN_NORMAL_CASE(20);
+        ALAN_NORMAL_CASE(24);
+        ALAN_NORMAL_CASE(28);
+        ALAN_NORMAL_CASE(32);
+        ALAN_NORMAL_CASE(48);
+        default: hipExtLaunchKernelGGL(normal_outer_kernel<64>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
+    }
+#undef ALAN_NORMAL_CASE
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 

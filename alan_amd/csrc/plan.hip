@@ -169,7 +169,8 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
         if (c.red_contig) {
             while (logG < 6 && (c.n_red >> logG) > 4) ++logG;  // ~4 elements per lane
         }
-        while (logG < 6 && (c.n_out << logG) < want_threads && (c.n_red >> logG) >= 2) ++logG;
+        // small launches are latency chains: widen the group until a lane sees one element
+        while (logG < 6 && (c.n_out << logG) < want_threads && (1ll << logG) < c.n_red) ++logG;
     }
     gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 512);
     gl.logG = logG;

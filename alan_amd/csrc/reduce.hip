@@ -48,61 +48,77 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
         obase += idx * d.oks[k];
     }
 
-    // ---- stream over the reduce index
+    // ---- stream over the reduce index, UNR elements per step: their loads are all issued before the
+    // first is consumed (small problems are pure latency chains; big ones want the loads in flight)
+    constexpr int UNR = 4;
+    constexpr bool PRODUCER = MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE ||
+                              MODE == ALAN_MODE_BERNOULLI;
     T m = Num<T>::ninf(), s = T(0);
-    for (uint32_t r = gl; r < d.n_red; r += G) {
-        int64_t off[MAXF];
-        int64_t woff = wbase;
-        if (d.nr == 1) {
+    for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
+        T val[UNR][MAXF];
+        T wv[UNR];
 #pragma unroll
-            for (int f = 0; f < MAXF; ++f) off[f] = base[f] + (int64_t)r * d.f[f < d.nf ? f : 0].rs[0];
-            if (MODE == ALAN_MODE_WEXPSUM) woff += (int64_t)r * d.w.rs[0];
-        } else {
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t ru = r0 + (uint32_t)u * G;
+            const uint32_t r = ru < d.n_red ? ru : r0;   // clamped: the slot is masked below
+            int64_t off[MAXF];
+            int64_t woff = wbase;
+            if (d.nr == 1) {
 #pragma unroll
-            for (int f = 0; f < MAXF; ++f) off[f] = base[f];
-            uint32_t rr = r;
-            for (int k = d.nr - 1; k >= 0; --k) {
-                const uint32_t q = fd_div(rr, d.rdiv[k]);
-                const int64_t idx = (int64_t)(rr - q * d.rdiv[k].d);
-                rr = q;
+                for (int f = 0; f < MAXF; ++f) off[f] = base[f] + (int64_t)r * d.f[f < d.nf ? f : 0].rs[0];
+                if (MODE == ALAN_MODE_WEXPSUM) woff += (int64_t)r * d.w.rs[0];
+            } else {
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) off[f] = base[f];
+                uint32_t rr = r;
+                for (int k = d.nr - 1; k >= 0; --k) {
+                    const uint32_t q = fd_div(rr, d.rdiv[k]);
+                    const int64_t idx = (int64_t)(rr - q * d.rdiv[k].d);
+                    rr = q;
+#pragma unroll
+                    for (int f = 0; f < MAXF; ++f)
+                        if (f < d.nf) off[f] += idx * d.f[f].rs[k];
+                    if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.w.rs[k];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f)
+                if (f < (PRODUCER ? (MODE == ALAN_MODE_BERNOULLI ? 2 : 3) : d.nf))
+                    val[u][f] = load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
+            if (MODE == ALAN_MODE_WEXPSUM) wv[u] = load_as<T>(d.w.p, d.w.dtype, woff);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool ok = r0 + (uint32_t)u * G < d.n_red;
+            if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
+                // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))
+                const T z = val[u][0] - val[u][1];
+                const T sc = val[u][2];
+                T lp;
+                if (MODE == ALAN_MODE_NORMAL)
+                    lp = -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+                else  // sc = log(scale)
+                    lp = -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178);
+                s += ok ? lp : T(0);
+            } else if (MODE == ALAN_MODE_BERNOULLI) {
+                // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
+                // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+                const T y = val[u][0], xl = val[u][1];
+                const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
+                s += ok ? ls - (T(1) - y) * xl : T(0);
+            } else {
+                T x = T(0);
 #pragma unroll
                 for (int f = 0; f < MAXF; ++f)
-                    if (f < d.nf) off[f] += idx * d.f[f].rs[k];
-                if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.w.rs[k];
+                    if (f < d.nf) x += (T)d.f[f].scale * val[u][f];
+                if (MODE == ALAN_MODE_LSE) {
+                    if (ok) lse_push(m, s, x);
+                } else if (MODE == ALAN_MODE_SUM) {
+                    s += ok ? x : T(0);
+                } else {
+                    s += ok ? wv[u] * Num<T>::exp(x) : T(0);
+                }
             }
-        }
-        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
-            // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))
-            const T v = load_as<T>(d.f[0].p, d.f[0].dtype, off[0]);
-            const T loc = load_as<T>(d.f[1].p, d.f[1].dtype, off[1]);
-            const T sc = load_as<T>(d.f[2].p, d.f[2].dtype, off[2]);
-            const T z = v - loc;
-            if (MODE == ALAN_MODE_NORMAL)
-                s += -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
-            else  // sc = log(scale)
-                s += -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178);
-            continue;
-        }
-        if (MODE == ALAN_MODE_BERNOULLI) {
-            // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
-            // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
-            const T y = load_as<T>(d.f[0].p, d.f[0].dtype, off[0]);
-            const T xl = load_as<T>(d.f[1].p, d.f[1].dtype, off[1]);
-            const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
-            s += ls - (T(1) - y) * xl;
-            continue;
-        }
-        T x = T(0);
-#pragma unroll
-        for (int f = 0; f < MAXF; ++f)
-            if (f < d.nf) x += (T)d.f[f].scale * load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
-        if (MODE == ALAN_MODE_LSE) {
-            lse_push(m, s, x);
-        } else if (MODE == ALAN_MODE_SUM) {
-            s += x;
-        } else {
-            const T w = load_as<T>(d.w.p, d.w.dtype, woff);
-            s += w * Num<T>::exp(x);
         }
     }
 
