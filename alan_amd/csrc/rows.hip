@@ -171,17 +171,31 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             const float2 *r2 = reinterpret_cast<const float2 *>(row) + gl;
             const float2 *g2 = reinterpret_cast<const float2 *>(gs) + gl;
             const int nq = (L >> 1) - gl;
+            // straight-line batches of 8 slots (row values, then the small factors): every read of a batch is
+            // in flight before the first use -- with the add inside one loop each pair of reads sat behind
+            // its own s_waitcnt and the pass ran at LDS latency
+            constexpr int HB = 8;
 #pragma unroll
-            for (int u = 0; u < NS; ++u) {
-                float2 a = r2[u * G];            // (reads past the row stay inside the LDS allocation)
+            for (int h = 0; h < NS / HB; ++h) {
+                float2 a[HB];
+#pragma unroll
+                for (int u = 0; u < HB; ++u) a[u] = r2[(h * HB + u) * G];   // (reads past the row stay inside the allocation)
                 if (d.nshared > 0) {
-                    const float2 g = g2[u * G];
-                    a.x += g.x;
-                    a.y += g.y;
+                    float2 g[HB];
+#pragma unroll
+                    for (int u = 0; u < HB; ++u) g[u] = g2[(h * HB + u) * G];
+#pragma unroll
+                    for (int u = 0; u < HB; ++u) {
+                        a[u].x += g[u].x;
+                        a[u].y += g[u].y;
+                    }
                 }
-                const bool ok = u * G < nq;
-                x[2 * u] = ok ? a.x : PAD;
-                x[2 * u + 1] = ok ? a.y : PAD;
+#pragma unroll
+                for (int u = 0; u < HB; ++u) {
+                    const bool ok = (h * HB + u) * G < nq;
+                    x[2 * (h * HB + u)] = ok ? a[u].x : PAD;
+                    x[2 * (h * HB + u) + 1] = ok ? a[u].y : PAD;
+                }
             }
         } else {
             if (GEN) {
