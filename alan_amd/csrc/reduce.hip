@@ -51,8 +51,6 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
     // ---- stream over the reduce index, UNR elements per step: their loads are all issued before the
     // first is consumed (small problems are pure latency chains; big ones want the loads in flight)
     constexpr int UNR = 4;
-    constexpr bool PRODUCER = MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE ||
-                              MODE == ALAN_MODE_BERNOULLI;
     T m = Num<T>::ninf(), s = T(0);
     for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
         T val[UNR][MAXF];
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
             }
 #pragma unroll
             for (int f = 0; f < MAXF; ++f)
-                if (f < (PRODUCER ? (MODE == ALAN_MODE_BERNOULLI ? 2 : 3) : d.nf))
+                if (f < (MODE == ALAN_MODE_BERNOULLI ? 2 : d.nf))
                     val[u][f] = load_as<T>(d.f[f].p, d.f[f].dtype, off[f]);
             if (MODE == ALAN_MODE_WEXPSUM) wv[u] = load_as<T>(d.w.p, d.w.dtype, woff);
         }
@@ -91,14 +89,21 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
         for (int u = 0; u < UNR; ++u) {
             const bool ok = r0 + (uint32_t)u * G < d.n_red;
             if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
-                // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi))
-                const T z = val[u][0] - val[u][1];
-                const T sc = val[u][2];
-                T lp;
-                if (MODE == ALAN_MODE_NORMAL)
-                    lp = -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
-                else  // sc = log(scale)
-                    lp = -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178);
+                // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi));
+                // one term per (value, loc, scale) triple, weighted by the value factor's scale field
+                T lp = T(0);
+#pragma unroll
+                for (int tm = 0; tm < MAXF / 3; ++tm) {
+                    if (3 * tm < d.nf) {
+                        const T z = val[u][3 * tm] - val[u][3 * tm + 1];
+                        const T sc = val[u][3 * tm + 2];
+                        const bool logsc = MODE == ALAN_MODE_NORMAL_LOGSCALE || d.f[3 * tm + 2].scale == 2.f;
+                        const T one = logsc
+                            ? -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178)
+                            : -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+                        lp += (T)d.f[3 * tm].scale * one;
+                    }
+                }
                 s += ok ? lp : T(0);
             } else if (MODE == ALAN_MODE_BERNOULLI) {
                 // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,

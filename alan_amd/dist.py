@@ -250,6 +250,35 @@ class TorchDimDist:
         assert is_tensor(x)
         return self.log_prob_pt(x, dim_order).dim()
 
+    def _normal_args(self):
+        loc, scale = self.kwargs["loc"], self.kwargs["scale"]
+        lazy = isinstance(scale, ExpPT) and not scale.materialised
+        return loc, scale, lazy
+
+    @staticmethod
+    def log_p_minus_q(P, Q, x, dim_order, allowed, logK):
+        """log P(x) - log Q(x) - log K as ONE launch, or None when that does not apply: both must be fusable
+        Normals, nothing may need a gradient, and the result may only carry dims in ``allowed`` (the
+        group's own K and the active plates -- then reduce_logQ is the identity, Sampler.py:118-134)."""
+        x = PT.of(x)
+        if P._fusable(x) != "normal" or Q._fusable(x) != "normal":
+            return None
+        args = [x, *[a for D in (P, Q) for a in D._normal_args()[:2]]]
+        if t.is_grad_enabled() and any((a.raw if isinstance(a, ExpPT) and not a.materialised else a.x).requires_grad
+                                       for a in args):
+            return None
+        lead, last = dim_order
+        dims, ids = pt_order(args, lead, last)
+        if not set(ids) <= set(allowed):
+            return None
+        from . import engine as E
+        terms = []
+        for D in (P, Q):
+            loc, scale, lazy = D._normal_args()
+            terms.append(((loc.x, loc.dims), ((scale.raw if lazy else scale.x), scale.dims), lazy))
+        out = E.normal_logprob_pq((x.x, x.dims), terms[0], terms[1], tuple(dims), affine=(1.0, -logK))
+        return PT(out, dims)
+
     def _fusable(self, x):
         """Normal and Bernoulli(logits) log-probs on the GPU go to the fused HIP producers (alan_reduce
         modes NORMAL / BERNOULLI); everything else stays on torch.distributions.  -> "normal" | "bernoulli" | None"""

@@ -204,7 +204,7 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
 
 
 # --------------------------------------------------------------------------- fused factor producer
-def _produce(mode, args, out_dims, affine=(1.0, 0.0)):
+def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None):
     """One producer launch: ``args`` are (tensor, leading first-class dims) pairs whose trailing positional
     dims are right-aligned; every dim not in ``out_dims`` is summed out; out = affine[0] * sum + affine[1]."""
     tok = _Tokens()
@@ -219,7 +219,8 @@ def _produce(mode, args, out_dims, affine=(1.0, 0.0)):
     roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
     dtype = _result_dtype([x for x, _ in factors])
     out = t.empty([sizes[d] for d in odims], dtype=dtype, device=args[0][0].device)
-    _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]))
+    _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]),
+            scales=scales)
     return out
 
 
@@ -233,6 +234,15 @@ def normal_logprob(value, loc, scale, out_dims, log_scale=False, affine=(1.0, 0.
     ``affine = (a, b)``: the launch writes a * log_prob + b (the -(log Q + log K) of logpq.py:234-235)."""
     mode = N.MODE_NORMAL_LOGSCALE if log_scale else N.MODE_NORMAL
     return _produce(mode, (value, loc, scale), out_dims, affine)
+
+
+def normal_logprob_pq(value, p, q, out_dims, affine=(1.0, 0.0)):
+    """affine[0] * (log N(value; p) - log N(value; q)) + affine[1] in ONE launch: the "log P - log Q - log K"
+    of a latent whose prior and approximate posterior are both Normal and carry the same dims
+    (logpq.py:221-235).  p, q = (loc, scale, scale_is_log) with loc / scale as (tensor, dims) pairs."""
+    (pl, ps, plog), (ql, qs, qlog) = p, q
+    scales = [1.0, 1.0, 2.0 if plog else 1.0, -1.0, 1.0, 2.0 if qlog else 1.0]
+    return _produce(N.MODE_NORMAL, (value, pl, ps, value, ql, qs), out_dims, affine, scales)
 
 
 def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):

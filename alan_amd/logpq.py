@@ -22,6 +22,7 @@ from . import engine as E
 from .dims import PT, ExpPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
+from .dist import TorchDimDist
 from .timeseries import Timeseries
 
 
@@ -177,18 +178,30 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
     logPs, total_logQ, Kinits = [], None, []
     init_Ks = [groupvarname2Kdim[varname2groupvarname[d.init]] for d in prog_P.values() if isinstance(d, Timeseries)]
     # A one-variable group whose log Q carries no parent K (a factorised Q: reduce_logQ is then the
-    # identity) has its -(log Q + log K) written by the log-prob producer itself.
+    # identity) has its -(log Q + log K) written by the log-prob producer itself -- together with log P
+    # when that is a Normal on the same dims (a prior with constant / plate-level parameters).
     own = {id(Kdim), *(id(d) for d in active_platedims)}
     K = Kdim.size
     single = len(prog_P) == 1 and not any(isinstance(d, Timeseries) for d in (*prog_P.values(), *prog_Q.values()))
-    extra = {"affine": (-1.0, -math.log(K), own)} if single else {}
+    if single:
+        (var,) = prog_P
+        tP, tQ = prog_P[var].tdd(scope, dimcache), prog_Q[var].tdd(scope, dimcache)
+        pq = TorchDimDist.log_p_minus_q(tP, tQ, sample[var], order, own, math.log(K))
+        if pq is not None:                      # log P - log Q - log K in one launch
+            return [pq], (Kdim,), (), ()
+        lp = tP.log_prob_pt(sample[var], dim_order=order)
+        neg_q = tQ.log_prob_pt(sample[var], dim_order=order, affine=(-1.0, -math.log(K), own))
+        if not set(neg_q.ids) <= own:           # log Q carries a parent K: reduce it first (Sampler.py:118-134)
+            lq = sampler.reduce_logQ(neg_q, active_platedims, Kdim)
+            neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
+        return [lp, neg_q], (Kdim,), (), ()
     for var in prog_P:
         x = sample[var]
         assert isinstance(x, PT)
         lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
                                            dimcache=dimcache)
         lq, Kinit_q = prog_Q[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
-                                           dimcache=dimcache, **extra)
+                                           dimcache=dimcache)
         if Kinit_q is not None:
             assert Kinit_p is Kinit_q
         if Kinit_p is not None:
@@ -196,13 +209,10 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         logPs.append(lp)
         total_logQ = lq if total_logQ is None else pt_add(total_logQ, lq)
     assert K == total_logQ.size_of(id(Kdim))
-    if single and set(total_logQ.ids) <= own:
-        neg_q = total_logQ                           # already -(log Q + log K)
-    else:
-        lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
-        # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
-        # factors on the fly, so pre-adding them would only cost extra launches)
-        neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
+    lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
+    # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
+    # factors on the fly, so pre-adding them would only cost extra launches)
+    neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
     logPs.sort(key=lambda p: -p.x.numel())
     for lp in logPs[2:]:                       # large Groups: keep the factor count of the step small
         neg_q = pt_add(neg_q, lp)

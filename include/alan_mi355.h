@@ -61,9 +61,10 @@ typedef enum {
     ALAN_MODE_SUM = 1,     /* out = sum_R x */
     ALAN_MODE_WEXPSUM = 2, /* out = sum_R weight * exp(x) */
     ALAN_MODE_NORMAL = 3,  /* fused factor PRODUCER (TorchDimDist.py:127-162 + utils.py:147-152 for td.Normal):
-                              exactly 3 factors (value, loc, scale);
-                              out = sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
-                              R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised */
+                              3 factors (value, loc, scale), or 6 = two such terms (log P and log Q of one variable);
+                              out = sum_t value_t.scale * sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
+                              R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised.
+                              A scale factor whose own .scale field is 2 holds log(scale) (see NORMAL_LOGSCALE). */
     ALAN_MODE_BERNOULLI = 4, /* fused factor PRODUCER for td.Bernoulli(logits=...) (same reference lines):
                               exactly 2 factors (value, logits);
                               out = sum_R [ logsigmoid(logits) - (1 - value) * logits ]

@@ -429,3 +429,38 @@ def test_fused_normal_log_scale_and_affine(shapes):
     t.testing.assert_close(lp_f.x, want, rtol=2e-5, atol=2e-4)
     for a, b in zip(gf, gt):
         t.testing.assert_close(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("q_log_scale", [False, True])
+def test_normal_p_minus_q_single_launch(q_log_scale):
+    """log P - log Q - log K of a latent with Normal prior and Normal approximate posterior on the same dims
+    (logpq.py:221-235) as ONE alan_reduce(mode NORMAL, 6 factors) launch vs the two separate log-probs."""
+    import math
+    import alan_amd.dist as D
+    from alan_amd.dims import Dim, PT, ExpPT
+    g = t.Generator().manual_seed(8)
+    M, K, Ev = 7, 6, 18
+    dm, dz = Dim("plate_1", M), Dim("K_z", K)
+    x = PT(t.randn(M, K, Ev, generator=g).to(DEV), (dm, dz))
+    P = D.TorchDimDist(t.distributions.Normal, loc=PT(t.tensor(0.3, device=DEV), ()),
+                       scale=PT(t.tensor(1.7, device=DEV), ()))
+    qraw = 0.3 * t.randn(M, Ev, generator=g).to(DEV)
+    qscale = ExpPT(qraw, (dm,)) if q_log_scale else PT(qraw.exp(), (dm,))
+    Q = D.TorchDimDist(t.distributions.Normal, loc=PT(t.randn(M, Ev, generator=g).to(DEV), (dm,)), scale=qscale)
+    own = {id(dm), id(dz)}
+    with t.no_grad():
+        pq = D.TorchDimDist.log_p_minus_q(P, Q, x, ([dm], [dz]), own, math.log(K))
+    assert pq is not None and [str(d) for d in pq.dims] == ["plate_1", "K_z"]
+    if q_log_scale:
+        assert not qscale.materialised
+    want = P.log_prob_pt(x, ([dm], [dz])).x - Q.log_prob_pt(x, ([dm], [dz])).x - math.log(K)
+    t.testing.assert_close(pq.x, want, rtol=2e-5, atol=2e-4)
+    # does not apply: a prior carrying a parent K, or a gradient to record
+    dmu = Dim("K_mu", K)
+    P2 = D.TorchDimDist(t.distributions.Normal, loc=PT(t.randn(K, Ev, generator=g).to(DEV), (dmu,)),
+                        scale=PT(t.tensor(1.0, device=DEV), ()))
+    with t.no_grad():
+        assert D.TorchDimDist.log_p_minus_q(P2, Q, x, ([dm], [dz]), own, math.log(K)) is None
+    Q3 = D.TorchDimDist(t.distributions.Normal, loc=PT(t.randn(M, Ev, generator=g).to(DEV).requires_grad_(True), (dm,)),
+                        scale=PT(qraw.exp(), (dm,)))
+    assert D.TorchDimDist.log_p_minus_q(P, Q3, x, ([dm], [dz]), own, math.log(K)) is None
