@@ -36,7 +36,10 @@ struct NormalDesc {
     int32_t vstage_off;               // LDS offset (floats) of the value staging area
 };
 
-template <int EMAX>
+// R = value rows per thread (rows t, t+256, ... of the workgroup's block of 256*R): every 16-byte read of a
+// scale row from LDS then feeds 4*R FMAs.  At R = 1 the LDS return path (5 broadcast ds_read_b128 per 20
+// FMAs) is what bounds the main loop, not the FMAs.
+template <int EMAX, int R>
 __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     extern __shared__ __align__(16) float lds[];
     const int E = d.E;
@@ -68,47 +71,55 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
         mu[i] = (int)e < E ? d.loc[(int64_t)(l0 + il) * d.l_rs + e] : 0.f;
     }
 
-    // ---- this thread's value row
-    const uint32_t r = blockIdx.x * 256u + tid;
-    const bool active = r < d.NV;
-    int64_t voff = 0, ooff = 0;
-    {
-        uint32_t o = active ? r : d.NV - 1u;
+    // ---- this thread's value rows
+    bool active[R];
+    int64_t ooff[R];
+    float v[R][EMAX];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t r0 = (blockIdx.x * R + j) * 256u;          // first row of sub-block j
+        const uint32_t r = r0 + tid;
+        active[j] = r < d.NV;
+        int64_t voff = 0;
+        ooff[j] = 0;
+        uint32_t o = active[j] ? r : d.NV - 1u;
         for (int k = d.nv - 1; k >= 0; --k) {
             const uint32_t q = fd_div(o, d.vdiv[k]);
             const int64_t idx = (int64_t)(o - q * d.vdiv[k].d);
             o = q;
             voff += idx * d.v_vs[k];
-            ooff += idx * d.v_os[k];
+            ooff[j] += idx * d.v_os[k];
         }
-    }
-    float v[EMAX];
-    if (d.rows_contig) {
-        // the workgroup's 256 value rows are one contiguous block: stream it into LDS with 16-byte loads
-        // (each thread reading its own row from global memory costs one cache line per lane per load: the
-        // texture addresser, not HBM, then bounds the prologue)
-        float *vs = lds + d.vstage_off;
-        const uint32_t r0 = blockIdx.x * 256u;
-        const uint32_t nrow = min(256u, d.NV - r0);
-        const int n4 = (int)((nrow * (uint32_t)E + 3u) >> 2);
-        const float4 *src = reinterpret_cast<const float4 *>(d.val + (int64_t)r0 * E);
-        float4 *dst = reinterpret_cast<float4 *>(vs);
-        const int64_t lim4 = ((int64_t)d.NV * E + 3) >> 2;          // 16-byte units in the whole value tensor
-        const int64_t base4 = ((int64_t)r0 * E) >> 2;
-        for (int i = tid; i < n4; i += 256)
-            if (base4 + i < lim4) dst[i] = src[i];                   // (the allocation is padded to 16 bytes by torch)
-        __syncthreads();
-        const float *row = vs + (size_t)min((uint32_t)tid, nrow - 1u) * E;
+        if (d.rows_contig) {
+            // the sub-block's 256 rows are one contiguous run: stream it into LDS with 16-byte loads (each
+            // thread reading its own row from global memory costs one cache line per lane per load: the
+            // texture addresser, not HBM, then bounds the prologue)
+            float *vs = lds + d.vstage_off;
+            if (j > 0) __syncthreads();                           // the previous sub-block has been read
+            if (r0 < d.NV) {
+                const uint32_t nrow = min(256u, d.NV - r0);
+                const int n4 = (int)((nrow * (uint32_t)E + 3u) >> 2);
+                const float4 *src = reinterpret_cast<const float4 *>(d.val + (int64_t)r0 * E);
+                float4 *dst = reinterpret_cast<float4 *>(vs);
+                const int64_t lim4 = ((int64_t)d.NV * E + 3) >> 2;    // 16-byte units in the whole value tensor
+                const int64_t base4 = ((int64_t)r0 * E) >> 2;
+                for (int i = tid; i < n4; i += 256)
+                    if (base4 + i < lim4) dst[i] = src[i];         // (torch pads allocations beyond 16 bytes)
+            }
+            __syncthreads();
+            const uint32_t last = r0 < d.NV ? min(256u, d.NV - r0) - 1u : 0u;
+            const float *row = vs + (size_t)min((uint32_t)tid, last) * E;
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const float x = row[min(e, E - 1)];
-            v[e] = e < E ? x : 0.f;
-        }
-    } else {
+            for (int e = 0; e < EMAX; ++e) {
+                const float x = row[min(e, E - 1)];
+                v[j][e] = e < E ? x : 0.f;
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) {
-            const float x = d.val[voff + min(e, E - 1)];   // branch-free: every load is issued, pad slots zeroed
-            v[e] = e < E ? x : 0.f;
+            for (int e = 0; e < EMAX; ++e) {
+                const float x = d.val[voff + min(e, E - 1)];   // branch-free: every load is issued, pad slots zeroed
+                v[j][e] = e < E ? x : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -120,43 +131,55 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     }
     __syncthreads();
 
-    if (d.dbg == 1) {
+    if (d.dbg == 1) {   // ablation: prologue only
         float q = lg[tid % d.NS];
 #pragma unroll
-        for (int e = 0; e < EMAX; ++e) q += v[e];
-        if (active) d.out[ooff + (int64_t)l0 * d.l_os] = q;
+        for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) q += v[j][e];
+        if (active[0]) d.out[ooff[0] + (int64_t)l0 * d.l_os] = q;
         return;
     }
     const uint32_t ns_run = d.dbg == 3 ? 1u : d.NS;
-    const bool do_store = active && d.dbg != 2;
+    bool do_store[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) do_store[j] = active[j] && d.dbg != 2;
     for (uint32_t il = l0; il < l1; ++il) {
         const float4 *m4 = reinterpret_cast<const float4 *>(mu + (size_t)(il - l0) * Ep);
-        float dd[EMAX];
+        float dd[R][EMAX];
 #pragma unroll
         for (int q = 0; q < EMAX / 4; ++q) {
             const float4 m = m4[q];
-            const float a = v[4 * q] - m.x, b = v[4 * q + 1] - m.y, c = v[4 * q + 2] - m.z, e = v[4 * q + 3] - m.w;
-            dd[4 * q] = a * a;
-            dd[4 * q + 1] = b * b;
-            dd[4 * q + 2] = c * c;
-            dd[4 * q + 3] = e * e;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const float a = v[j][4 * q] - m.x, b = v[j][4 * q + 1] - m.y, c = v[j][4 * q + 2] - m.z,
+                            e = v[j][4 * q + 3] - m.w;
+                dd[j][4 * q] = a * a;
+                dd[j][4 * q + 1] = b * b;
+                dd[j][4 * q + 2] = c * c;
+                dd[j][4 * q + 3] = e * e;
+            }
         }
-        float *orow = d.out + ooff + (int64_t)il * d.l_os;
         for (uint32_t is = 0; is < ns_run; ++is) {
             const float4 *w4 = reinterpret_cast<const float4 *>(w + (size_t)is * Ep);
             float4 ww[EMAX / 4];
 #pragma unroll
             for (int q = 0; q < EMAX / 4; ++q) ww[q] = w4[q];      // straight-line: all reads issue together
-            float acc = 0.f;
+            const float lgi = lg[is];
 #pragma unroll
-            for (int q = 0; q < EMAX / 4; ++q) {
-                acc = fmaf(dd[4 * q], ww[q].x, acc);
-                acc = fmaf(dd[4 * q + 1], ww[q].y, acc);
-                acc = fmaf(dd[4 * q + 2], ww[q].z, acc);
-                acc = fmaf(dd[4 * q + 3], ww[q].w, acc);
+            for (int j = 0; j < R; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < EMAX / 4; ++q) {
+                    acc = fmaf(dd[j][4 * q], ww[q].x, acc);
+                    acc = fmaf(dd[j][4 * q + 1], ww[q].y, acc);
+                    acc = fmaf(dd[j][4 * q + 2], ww[q].z, acc);
+                    acc = fmaf(dd[j][4 * q + 3], ww[q].w, acc);
+                }
+                const float res = (-acc - lgi) * d.out_scale + d.add_const;
+                if (do_store[j] || res == 12345.678f)
+                    d.out[ooff[j] + (int64_t)il * d.l_os + (int64_t)is * d.s_os] = res;
             }
-            const float res = (-acc - lg[is]) * d.out_scale + d.add_const;
-            if (do_store || res == 12345.678f) orow[(int64_t)is * d.s_os] = res;
         }
     }
 }
@@ -227,13 +250,13 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
         d.rows_contig = contig ? 1 : 0;
     }
 
-    const uint32_t gx = (uint32_t)((NV + 255) / 256);
-    // enough workgroups to fill the chip: split the loc rows over grid.y
-    // One loc row per workgroup is fastest: the kernel is issue/latency bound (per scale row: 5 broadcast
-    // ds_read_b128 -> 20 dependent FMAs -> store), so it wants as many waves as the grid allows -- measured
-    // at K=30: 25 us with gy = NL, 310 us with gy = 1; ablation: arithmetic alone 21 us, stores alone 18 us,
-    // per-workgroup prologue 10 us.  (A variant with LDS-transposed, fully coalesced 16-byte stores was
-    // slower: 37 us.)
+    // two value rows per thread once that still leaves >= 512 workgroups
+    int R = (NV * (int64_t)d.NL >= 512ll * 512) ? 2 : 1;
+    if (const char *e = getenv("ALAN_NORMAL_R")) R = atoi(e) == 2 ? 2 : 1;   // tuning knob
+    const uint32_t gx = (uint32_t)((NV + 256 * R - 1) / (256 * R));
+    // enough workgroups to fill the chip: split the loc rows over grid.y, one loc row per workgroup when the
+    // grid allows (K=30: 25 us with gy = NL, 310 us with gy = 1).  Measured budget at K=30, R=2 (HIP events,
+    // 4.7 us of which is the event floor): tables + value staging 3.6 us, FMAs/LDS 4-6 us, stores of F 6 us.
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 16384 / std::max(1u, gx)));
     if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
     d.l_chunk = (d.NL + gy - 1) / gy;
@@ -247,8 +270,15 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
     if (lds > 64 * 1024) return ALAN_ERR_UNSUPPORTED;
 
     const dim3 grid(gx, gy), block(256);
-#define ALAN_NORMAL_CASE(EM) \
-    case EM: hipExtLaunchKernelGGL(normal_outer_kernel<EM>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d); break
+#define ALAN_NORMAL_CASE(EM)                                                                                     \
+    case EM:                                                                                                     \
+        if (R == 2)                                                                                              \
+            hipExtLaunchKernelGGL((normal_outer_kernel<EM, 2>), grid, block, (uint32_t)lds, stream, ev.start,     \
+                                  ev.stop, 0, d);                                                                \
+        else                                                                                                     \
+            hipExtLaunchKernelGGL((normal_outer_kernel<EM, 1>), grid, block, (uint32_t)lds, stream, ev.start,     \
+                                  ev.stop, 0, d);                                                                \
+        break
     switch (d.Ep) {
         ALAN_NORMAL_CASE(4);
         ALAN_NORMAL_CASE(8);
@@ -259,7 +289,7 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
         ALAN_NORMAL_CASE(28);
         ALAN_NORMAL_CASE(32);
         ALAN_NORMAL_CASE(48);
-        default: hipExtLaunchKernelGGL(normal_outer_kernel<64>, grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
+        default: hipExtLaunchKernelGGL((normal_outer_kernel<64, 1>), grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     }
 #undef ALAN_NORMAL_CASE
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
