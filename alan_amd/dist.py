@@ -449,6 +449,16 @@ def call_model_lambda(fn, named_args, dimcache=None):
         if not is_tensor(val):
             raise Exception("Lambda on a distribution returned a non-Tensor")
         return val
+    # Within ONE evaluation the same lambda on the same argument objects (a parent-level variable seen again by
+    # every chunk of a Split) is evaluated once.  Only without autograd: under torch.utils.checkpoint the
+    # forward and the recomputation must build identical graphs.
+    memo = key = None
+    if dimcache is not None and not t.is_grad_enabled():
+        memo = dimcache.setdefault("__lambda__", {})
+        key = (id(fn), *[id(v) for v in vals])
+        hit = memo.get(key)
+        if hit is not None and hit[0] is fn and all(a is b for a, b in zip(hit[1], vals)):
+            return hit[2]
     seen, count = {}, {}
     for p in vals:
         for d, i in zip(p.dims, p.ids):
@@ -469,7 +479,10 @@ def call_model_lambda(fn, named_args, dimcache=None):
     val = f(*args)
     if not isinstance(val, t.Tensor):
         raise Exception("Lambda on a distribution returned a non-Tensor")
-    return PT(val, [seen[i] for i in order])
+    out = PT(val, [seen[i] for i in order])
+    if memo is not None:
+        memo[key] = (fn, vals, out)
+    return out
 
 
 def _as_dim(v, name, cache):

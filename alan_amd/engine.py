@@ -259,6 +259,7 @@ def plan_elimination(dimsets, sizes, Ks):
     pairwise steps (reduce_Ks.py:270-281)."""
     Ks = [k for k in Ks]
     live = {i: set(ds) for i, ds in enumerate(dimsets)}
+    stored = {i: tuple(ds) for i, ds in enumerate(dimsets)}      # storage order of the input factors
     steps = []
     nxt = len(dimsets)
     remaining = [k for k in Ks if any(k in ds for ds in live.values())]
@@ -294,6 +295,16 @@ def plan_elimination(dimsets, sizes, Ks):
             continue
         others = set().union(*[ds for i, ds in live.items() if i not in grp]) if len(live) > len(grp) else set()
         now = tuple(kk for kk in remaining if kk in union and kk not in others)
+        if len(now) > 1:
+            # several Ks at once with (almost) nothing kept is one long serial reduction in a single
+            # workgroup (K=100: 10^4 elements, 38 us): peel off one K per step instead -- the innermost
+            # one of the largest factor, so that step streams it with coalesced loads
+            red = math.prod(sizes[kk] for kk in now)
+            kept = math.prod(sizes[dd] for dd in union if dd not in now)
+            if red > 2048 and kept < 256:
+                big = max(grp, key=lambda i: math.prod(sizes[dd] for dd in live[i]))
+                pos = {dd: j for j, dd in enumerate(stored.get(big, ()))}
+                now = (max(now, key=lambda kk: pos.get(kk, -1)),)
         steps.append((tuple(grp), now))
         live[nxt] = {d for d in union if d not in now}
         for i in grp:

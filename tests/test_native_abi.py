@@ -86,6 +86,15 @@ def test_planner_single_launch_for_movielens_shapes():
     assert len(steps) == 1 and set(steps[0][1]) == {"Ka", "Kb"} and set(steps[0][0]) == {0, 1, 2}
 
 
+def test_planner_peels_one_K_when_the_joint_reduction_would_be_one_long_chain():
+    """movielens top level at K=100: a[Ka] + b[Kb] + T[Ka,Kb] over both Ks is 10^4 elements into ONE output --
+    a single workgroup.  The planner eliminates the innermost K of T first (all three factors in that launch:
+    a is constant over Kb), then the other."""
+    sizes = {"Ka": 100, "Kb": 100}
+    steps = E.plan_elimination([("Ka",), ("Kb",), ("Ka", "Kb")], sizes, ["Ka", "Kb"])
+    assert steps == [((0, 1, 2), ("Kb",)), ((3,), ("Ka",))]
+
+
 def test_planner_chain_is_pairwise_not_joint():
     sizes = {"K1": 30, "K2": 30, "K3": 30, "K4": 30}
     steps = E.plan_elimination([("K1", "K2"), ("K2", "K3"), ("K3", "K4")], sizes, ["K1", "K2", "K3", "K4"])
