@@ -68,26 +68,34 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
     const int r = has_row ? (t >> LOGG) : (int)nrows - 1;
     float *gs = lds + d.gs_off;
 
-    // ---- this thread's row: offsets of the general secondary factors / outputs (fixed across the plate)
+    // ---- this thread's row: offsets of the general secondary factors (fixed across the plate).  The output /
+    // lse offsets are recomputed where they are used (a few multiply-highs) rather than held in registers
+    // through the reduction: the one-slab variant runs at a 96-VGPR cap and used to spill ~20 dwords per
+    // thread -- 24 MB of scratch writes per launch at the literal movielens size.
     int64_t sb[GEN ? MAXF : 1];
 #pragma unroll
     for (int f = 0; f < (GEN ? MAXF : 1); ++f) sb[f] = 0;
-    int64_t ob = 0, lb = 0;
-    {
+    if (GEN) {
         uint32_t o = o0 + (uint32_t)r;
         for (int k = d.nki - 1; k >= 0; --k) {
             const uint32_t q = fd_div(o, d.kdiv[k]);
             const int64_t idx = (int64_t)(o - q * d.kdiv[k].d);
             o = q;
-            if (GEN) {
 #pragma unroll
-                for (int f = 0; f < MAXF; ++f)
-                    if (f < d.ngen) sb[f] += idx * d.gen[f].ks[k];
-            }
-            ob += idx * d.oks[k];
-            lb += idx * d.lks[k];
+            for (int f = 0; f < MAXF; ++f)
+                if (f < d.ngen) sb[f] += idx * d.gen[f].ks[k];
         }
     }
+    auto row_offset = [&](const int64_t *strides) {
+        int64_t off = 0;
+        uint32_t o = o0 + (uint32_t)r;
+        for (int k = d.nki - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(o, d.kdiv[k]);
+            off += (int64_t)(o - q * d.kdiv[k].d) * strides[k];
+            o = q;
+        }
+        return off;
+    };
 
     // slab of plate index p: 16-byte loads from a 16-byte aligned-down start into registers
     f32x4 v[ROWS_UNR];
@@ -128,16 +136,20 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
     };
 
     // the window-constant small factors of plate index p: thread j < L holds sum_f sh_f[p, j]
-    float gnext = 0.f;
+    // The first two stay PENDING loads until the next slab is staged (adding them here would put an
+    // s_waitcnt vmcnt(0) right behind the slab prefetch and serialise it with the reduction); further ones
+    // (rare) are added at once, in a rolled loop -- unrolled over MAXF the compiler hoists six 64-bit base
+    // addresses into the prologue and spills them.
+    float gn0 = 0.f, gn1 = 0.f, gn_rest = 0.f;
     auto shared_fetch = [&](uint32_t p) {
-        float g = 0.f;
+        gn0 = gn1 = gn_rest = 0.f;
         if (d.nshared > 0 && t < L) {
-#pragma unroll
-            for (int f = 0; f < MAXF; ++f)
-                if (f < d.nshared)
-                    g += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)t * d.sh[f].rs[0]];
+            gn0 = ((const float *)d.sh[0].p)[(int64_t)p * d.sh_ps[0] + (int64_t)t * d.sh[0].rs[0]];
+            if (d.nshared > 1) gn1 = ((const float *)d.sh[1].p)[(int64_t)p * d.sh_ps[1] + (int64_t)t * d.sh[1].rs[0]];
+#pragma unroll 1
+            for (int f = 2; f < d.nshared; ++f)
+                gn_rest += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)t * d.sh[f].rs[0]];
         }
-        gnext = g;
     };
 
     float acc = 0.f;
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
         const int64_t e0 = ((int64_t)p * d.NO + o0) * L;
         const int shift = (int)(e0 & 3);
         slab_store(p);
-        if (d.nshared > 0 && t < L) gs[t] = gnext;
+        if (d.nshared > 0 && t < L) gs[t] = (gn0 + gn1) + gn_rest;
         __syncthreads();
         if (PF && p + 1 < p1) {   // in flight while this slab is reduced
             slab_fetch(p + 1);
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             // straight-line batches of 8 slots (row values, then the small factors): every read of a batch is
             // in flight before the first use -- with the add inside one loop each pair of reads sat behind
             // its own s_waitcnt and the pass ran at LDS latency
-            constexpr int HB = 8;
+            constexpr int HB = PF ? 8 : 4;   // (the one-slab variant has fewer registers to spare)
 #pragma unroll
             for (int h = 0; h < NS / HB; ++h) {
                 float2 a[HB];
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             val = s;
         }
         if (has_row && gl == 0) {
-            if (d.lse) d.lse[lb + (int64_t)p * d.l_ps] = val;
+            if (d.lse) d.lse[row_offset(d.lks) + (int64_t)p * d.l_ps] = val;
             acc += val;
         }
         __syncthreads();
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
         if (d.partial)
             d.partial[(int64_t)blockIdx.y * d.NO + o0 + r] = acc;
         else
-            d.out[ob] = acc + d.add_const;
+            d.out[row_offset(d.oks)] = acc + d.add_const;
     }
 }
 

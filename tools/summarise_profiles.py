@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/profiles_raw/ (written on the GPU box by tools/collect_profiles.sh) into the tracked
+summaries under profiles/:  r1_bench.json (the bench line), r1_bench_default_kernel_stats.{csv,md}
+(rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extras`), r1_rows_kernel_pmc.{json,md}
+(FETCH_SIZE / WRITE_SIZE passes over tools/profile_rows.py, corrected as MI355X_MICROARCH.md prescribes)."""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "profiles_raw")
+OUT = os.path.join(ROOT, "profiles")
+csv.field_size_limit(1 << 30)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(RAW, pattern), recursive=True)
+    assert len(hits) == 1, (pattern, hits)
+    return hits[0]
+
+
+def short(name, n=96):
+    return name if len(name) <= n else name[:n]
+
+
+# ---- bench line
+bench = json.load(open(os.path.join(RAW, "bench_full.json")))
+json.dump(bench, open(os.path.join(OUT, "r1_bench.json"), "w"), indent=1)
+
+# ---- kernel stats
+src = one("stats/**/*kernel_stats.csv")
+shutil.copy(src, os.path.join(OUT, "r1_bench_default_kernel_stats.csv"))
+rows = list(csv.DictReader(open(src)))
+evals = max(int(r["Calls"]) for r in rows if "rows_kernel" in r["Name"])
+with open(os.path.join(OUT, "r1_bench_default_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extras` (round 1)\n\n"
+            "Full CSV: `r1_bench_default_kernel_stats.csv`.  Kernel names truncated.  The run evaluates the movielens K=30 "
+            f"ELBO {evals} times (2 warm + 1 captured + 5 + 50 graph replays, then 50 eager for the per-kernel HIP events).\n\n"
+            "| kernel | calls | per eval | avg us | % |\n|---|---|---|---|---|\n")
+    for r in rows:
+        calls = int(r["Calls"])
+        if calls < evals // 4:
+            continue
+        f.write(f"| `{short(r['Name'])}` | {calls} | {calls / evals:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |\n")
+    rk = [r for r in rows if "rows_kernel" in r["Name"]][0]
+    f.write(f"\n`alan::rows_kernel` (the dominant reduce_Ks kernel, S-ML plate step at the literal movielens size: 32.5 MB) "
+            f"averages {float(rk['AverageNs']) / 1e3:.1f} us here; bench.py's live HIP-event measurement of the same launches "
+            f"in the bench run committed beside this file (`r1_bench.json`, a separate process on the same box) gives "
+            f"{bench['roofline']['us_per_launch']:.1f} us (hipExtLaunchKernelGGL start/stop events; they include a ~4 us "
+            f"event floor that an empty kernel also shows, see tools/readfloor.hip).\n")
+
+# ---- PMC passes
+def pmc(which, counter):
+    path = one(f"{which}/**/*counter_collection.csv")
+    acc = defaultdict(lambda: [0.0, 0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or "alan::" not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size"]))
+        a = acc[key]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+        a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return {k: (v[0] / v[1], v[1], v[2] / v[1]) for k, v in acc.items()}
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+K, lit_M, big_M = 30, 300, 19200
+algo = {m: 4 * (m * K ** 3 + m * K + K * K) for m in (lit_M, big_M)}
+rows_keys = sorted([k for k in fetch if "rows_kernel" in k[0]], key=lambda k: k[1])
+assert len(rows_keys) == 2, rows_keys
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 "
+                 "tools/profile_rows.py; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide "
+                 "coalesced stream); KiB -> bytes", "kernel": rows_keys[0][0]}
+lines = ["# PMC counters of the reduce_Ks kernels (rocprofv3 --pmc, separate passes), round 1\n",
+         "Command: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 tools/profile_rows.py` (and "
+         "`--pmc WRITE_SIZE`).\nFETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide "
+         "coalesced\nstreaming read (MI355X_MICROARCH.md, HBM section), so HBM read bytes = 2 x FETCH_SIZE x 1024.\n",
+         "| kernel | grid (threads) | launches | counter | mean value (KiB) | corrected bytes | mean duration (us) |",
+         "|---|---|---|---|---|---|---|"]
+for name, tab, mult in (("FETCH_SIZE", fetch, 2048.0), ("WRITE_SIZE", write, 1024.0)):
+    for k in sorted(tab, key=lambda k: (k[0], k[1])):
+        v, n, dur = tab[k]
+        lines.append(f"| `{k[0]}` | {k[1]} | {n} | {name} | {v:.1f} | {v * mult:.4g} | {dur:.1f} |")
+for key, m, tag in ((rows_keys[0], lit_M, f"literal_K{K}_M{lit_M}"), (rows_keys[1], big_M, f"scaled_K{K}_M{big_M}")):
+    fb, wb = fetch[key][0] * 2048.0, write[key][0] * 1024.0
+    res[tag] = {"fetch_bytes": fb, "write_bytes": wb, "algorithmic_bytes": algo[m], "traffic_bytes": fb + wb,
+                "traffic_over_algorithmic": (fb + wb) / algo[m], "mean_duration_us": fetch[key][2]}
+lines.append(f"\nAlgorithmic bytes per launch of `rows_kernel` (S-ML plate step, K={K}): M={lit_M}: {algo[lit_M]:,} B; "
+             f"M={big_M}: {algo[big_M]:,} B.")
+lines.append(f"=> measured HBM traffic (reads + writes) / algorithmic bytes = "
+             f"{res[f'literal_K{K}_M{lit_M}']['traffic_over_algorithmic']:.2f} (literal) and "
+             f"{res[f'scaled_K{K}_M{big_M}']['traffic_over_algorithmic']:.2f} (scaled): no wasted re-reads.")
+open(os.path.join(OUT, "r1_rows_kernel_pmc.md"), "w").write("\n".join(lines) + "\n")
+json.dump(res, open(os.path.join(OUT, "r1_rows_kernel_pmc.json"), "w"), indent=1)
+print(open(os.path.join(OUT, "r1_rows_kernel_pmc.md")).read())
+print(open(os.path.join(OUT, "r1_bench_default_kernel_stats.md")).read())
