@@ -45,8 +45,7 @@ with open(os.path.join(OUT, "r1_bench_default_kernel_stats.md"), "w") as f:
     f.write(f"\n`alan::rows_kernel` (the dominant reduce_Ks kernel, S-ML plate step at the literal movielens size: 32.5 MB) "
             f"averages {float(rk['AverageNs']) / 1e3:.1f} us here; bench.py's live HIP-event measurement of the same launches "
             f"in the bench run committed beside this file (`r1_bench.json`, a separate process on the same box) gives "
-            f"{bench['roofline']['us_per_launch']:.1f} us (hipExtLaunchKernelGGL start/stop events; they include a ~4 us "
-            f"event floor that an empty kernel also shows, see tools/readfloor.hip).\n")
+            f"{bench['roofline']['us_per_launch']:.1f} us (hipExtLaunchKernelGGL start/stop events).\n")
 
 # ---- PMC passes
 def pmc(which, counter):
