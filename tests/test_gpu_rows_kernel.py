@@ -35,6 +35,21 @@ def test_lse_over_contiguous_dim(L, plate):
     _cmp(out, dims, ref[0], ref[1])
 
 
+@pytest.mark.parametrize("L,n_shared", [(30, 2), (30, 4), (100, 3), (32, 5), (9, 3)])
+def test_several_window_constant_small_factors(L, n_shared):
+    """movielens' plate step carries two of them (-(log Q + log K) and the data likelihood); the kernel keeps the
+    first two as pending loads and adds any further ones in a rolled loop."""
+    g = t.Generator().manual_seed(L * 7 + n_shared)
+    M, A = 6, max(3, 20000 // (6 * L) + 1)
+    F = t.randn(M, A, L, generator=g) * 4
+    facs = [(F, ("m", "a", "k"))]
+    for i in range(n_shared):
+        facs.append((t.randn(M, L, generator=g), ("m", "k")) if i % 2 == 0 else (t.randn(L, generator=g), ("k",)))
+    ref = orc.plate_sum(orc.logsumexp_sum(("k",), *facs), "m")
+    out, dims = E.reduce_factors([(x.to(DEV), d) for x, d in facs], reduce=("k",), plate=("m",))
+    _cmp(out, dims, ref[0], ref[1])
+
+
 @pytest.mark.parametrize("L", [30, 32, 100])
 def test_general_small_factor_depends_on_inner_keep_dim(L):
     g = t.Generator().manual_seed(L)
