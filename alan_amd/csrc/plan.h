@@ -26,6 +26,24 @@ struct GroupDesc {
     float out_scale;   // producer modes: out = out_scale * sum + add_const
 };
 
+// Compact argument of the small-problem kernel: at most 3 keep and 2 reduce dims (after merging), fp32
+// everywhere, 32-bit strides.  Everything a thread needs arrives in one round of scalar loads -- the generic
+// kernel walks its 1.4 KB descriptor with run-time loops, i.e. a chain of ~10 dependent scalar loads, which
+// is most of the duration of a launch that reads a few hundred elements.
+constexpr int SMALL_NK = 3, SMALL_NR = 2;
+struct SmallDesc {
+    const float *f[MAXF];
+    const float *w;
+    float *out;
+    uint32_t n_out, n_red;
+    int32_t nf;
+    float out_scale, add_const;
+    FastDiv kdiv[SMALL_NK], rdiv[SMALL_NR];
+    int32_t fks[MAXF][SMALL_NK], frs[MAXF][SMALL_NR];
+    int32_t wks[SMALL_NK], wrs[SMALL_NR], oks[SMALL_NK];
+    float fscale[MAXF];
+};
+
 struct GroupLaunch {
     int logG;
     bool block;
@@ -64,6 +82,9 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
 
 int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream,
                  const EvPair &ev = EvPair());
+// Small-problem variant of the group kernel; ALAN_ERR_UNSUPPORTED when the problem does not fit SmallDesc.
+int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
+                     hipStream_t stream, const EvPair &ev);
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
 // fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the

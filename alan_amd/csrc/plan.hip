@@ -231,6 +231,8 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     GroupLaunch gl;
     rc = plan_group(c, out.dtype, add_const, gd, gl, out_scale);
     if (rc != ALAN_OK) return rc;
+    rc = try_launch_small(c, gd, gl, mode, compute, stream, ev);
+    if (rc != ALAN_ERR_UNSUPPORTED) return rc;
     return launch_group(gd, gl, mode, compute, stream, ev);
 }
 

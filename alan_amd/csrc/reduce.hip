@@ -11,10 +11,89 @@
 //                  dim gives coalesced loads.
 //   rows kernel    (rows.hip) LDS-staged fast path for the dominant shape: reduce dim contiguous in
 //                  the largest factor (movielens F[M,Ka,Kb,Kz] over Kz), optional fused plate sum.
+#include <cstring>
+
 #include "common.h"
 #include "plan.h"
 
 namespace alan {
+
+// ------------------------------------------------------------------------------------------
+// One element of the reduce index: the mode's term from the loaded factor values (shared by both kernels).
+template <typename T, int MODE>
+__device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T wv, const float (&scale)[MAXF],
+                                           int nf, bool ok) {
+    if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
+        // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi));
+        // one term per (value, loc, scale) triple, weighted by the value factor's scale field
+        T lp = T(0);
+#pragma unroll
+        for (int tm = 0; tm < MAXF / 3; ++tm) {
+            if (3 * tm < nf) {
+                const T z = val[3 * tm] - val[3 * tm + 1];
+                const T sc = val[3 * tm + 2];
+                const bool logsc = MODE == ALAN_MODE_NORMAL_LOGSCALE || scale[3 * tm + 2] == 2.f;
+                const T one = logsc
+                    ? -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178)
+                    : -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+                lp += (T)scale[3 * tm] * one;
+            }
+        }
+        s += ok ? lp : T(0);
+    } else if (MODE == ALAN_MODE_BERNOULLI) {
+        // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
+        // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+        const T y = val[0], xl = val[1];
+        const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
+        s += ok ? ls - (T(1) - y) * xl : T(0);
+    } else {
+        T x = T(0);
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (f < nf) x += (T)scale[f] * val[f];
+        if (MODE == ALAN_MODE_LSE) {
+            if (ok) lse_push(m, s, x);
+        } else if (MODE == ALAN_MODE_SUM) {
+            s += ok ? x : T(0);
+        } else {
+            s += ok ? wv * Num<T>::exp(x) : T(0);
+        }
+    }
+}
+
+// Lanes of a group (or the 4 waves of a block) -> one value.
+template <typename T, int MODE, bool BLOCK>
+__device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
+    const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
+    if (MODE == ALAN_MODE_LSE) {
+        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) {
+            const T m2 = __shfl_xor(m, (int)ofs);
+            const T s2 = __shfl_xor(s, (int)ofs);
+            lse_merge(m, s, m2, s2);
+        }
+    } else {
+        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
+    }
+    if (BLOCK) {
+        __shared__ T sm[4], ss[4];
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            sm[wv] = m;
+            ss[wv] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = sm[0];
+            s = ss[0];
+            for (int i = 1; i < 4; ++i) {
+                if (MODE == ALAN_MODE_LSE)
+                    lse_merge(m, s, sm[i], ss[i]);
+                else
+                    s += ss[i];
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool BLOCK>
@@ -87,76 +166,14 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const bool ok = r0 + (uint32_t)u * G < d.n_red;
-            if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
-                // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi));
-                // one term per (value, loc, scale) triple, weighted by the value factor's scale field
-                T lp = T(0);
+            float sc[MAXF];
 #pragma unroll
-                for (int tm = 0; tm < MAXF / 3; ++tm) {
-                    if (3 * tm < d.nf) {
-                        const T z = val[u][3 * tm] - val[u][3 * tm + 1];
-                        const T sc = val[u][3 * tm + 2];
-                        const bool logsc = MODE == ALAN_MODE_NORMAL_LOGSCALE || d.f[3 * tm + 2].scale == 2.f;
-                        const T one = logsc
-                            ? -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178)
-                            : -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
-                        lp += (T)d.f[3 * tm].scale * one;
-                    }
-                }
-                s += ok ? lp : T(0);
-            } else if (MODE == ALAN_MODE_BERNOULLI) {
-                // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
-                // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
-                const T y = val[u][0], xl = val[u][1];
-                const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
-                s += ok ? ls - (T(1) - y) * xl : T(0);
-            } else {
-                T x = T(0);
-#pragma unroll
-                for (int f = 0; f < MAXF; ++f)
-                    if (f < d.nf) x += (T)d.f[f].scale * val[u][f];
-                if (MODE == ALAN_MODE_LSE) {
-                    if (ok) lse_push(m, s, x);
-                } else if (MODE == ALAN_MODE_SUM) {
-                    s += ok ? x : T(0);
-                } else {
-                    s += ok ? wv[u] * Num<T>::exp(x) : T(0);
-                }
-            }
+            for (int f = 0; f < MAXF; ++f) sc[f] = d.f[f].scale;
+            accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
         }
     }
 
-    // ---- combine the G lanes of the group
-    const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
-    if (MODE == ALAN_MODE_LSE) {
-        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) {
-            const T m2 = __shfl_xor(m, (int)ofs);
-            const T s2 = __shfl_xor(s, (int)ofs);
-            lse_merge(m, s, m2, s2);
-        }
-    } else {
-        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
-    }
-    if (BLOCK) {
-        __shared__ T sm[4], ss[4];
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            sm[wv] = m;
-            ss[wv] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            m = sm[0];
-            s = ss[0];
-            for (int i = 1; i < 4; ++i) {
-                if (MODE == ALAN_MODE_LSE)
-                    lse_merge(m, s, sm[i], ss[i]);
-                else
-                    s += ss[i];
-            }
-        }
-    }
+    combine_lanes<T, MODE, BLOCK>(m, s, G);
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
         if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI)
@@ -164,6 +181,153 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
         v += (T)d.add_const;
         store_as<T>(d.out, d.out_dtype, obase, v);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int MODE, bool BLOCK>
+__global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, const int logG) {
+    typedef float T;
+    const uint32_t G = BLOCK ? 256u : (1u << logG);
+    uint32_t grp, gl;
+    if (BLOCK) {
+        grp = blockIdx.x;
+        gl = threadIdx.x;
+    } else {
+        const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+        grp = gid >> logG;
+        gl = gid & (G - 1u);
+    }
+    const bool active = grp < d.n_out;
+    uint32_t o = active ? grp : d.n_out - 1u;
+
+    int32_t base[MAXF], wbase = 0, obase = 0;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) base[f] = 0;
+#pragma unroll
+    for (int k = SMALL_NK - 1; k >= 0; --k) {
+        const uint32_t q = fd_div(o, d.kdiv[k]);
+        const int32_t idx = (int32_t)(o - q * d.kdiv[k].d);
+        o = q;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) base[f] += idx * d.fks[f][k];
+        if (MODE == ALAN_MODE_WEXPSUM) wbase += idx * d.wks[k];
+        obase += idx * d.oks[k];
+    }
+    float sc[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) sc[f] = d.fscale[f];
+
+    constexpr int UNR = 4;
+    T m = Num<T>::ninf(), s = T(0);
+    for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
+        T val[UNR][MAXF];
+        T wv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t ru = r0 + (uint32_t)u * G;
+            uint32_t rr = ru < d.n_red ? ru : r0;     // clamped: the slot is masked in accumulate()
+            int32_t off[MAXF], woff = wbase;
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) off[f] = base[f];
+#pragma unroll
+            for (int k = SMALL_NR - 1; k >= 0; --k) {
+                const uint32_t q = fd_div(rr, d.rdiv[k]);
+                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+                rr = q;
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
+                if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.wrs[k];
+            }
+            // unused factor slots alias factor 0 with zero strides: the load is harmless and never used
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];
+            wv[u] = MODE == ALAN_MODE_WEXPSUM ? d.w[woff] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
+    }
+    combine_lanes<T, MODE, BLOCK>(m, s, G);
+    if (active && gl == 0) {
+        T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
+        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI)
+            v *= d.out_scale;
+        d.out[obase] = v + d.add_const;
+    }
+}
+
+template <int MODE>
+static void launch_small_T(const SmallDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
+    if (gl.block)
+        hipExtLaunchKernelGGL((reduce_small_kernel<MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop,
+                              0, sd, 8);
+    else
+        hipExtLaunchKernelGGL((reduce_small_kernel<MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+                              ev.stop, 0, sd, gl.logG);
+}
+
+int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
+                     hipStream_t stream, const EvPair &ev) {
+    if (compute_dtype != ALAN_F32 || gd.out_dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    if (c.nk > SMALL_NK || c.nr > SMALL_NR || c.nf < 1) return ALAN_ERR_UNSUPPORTED;
+    if (c.n_out * c.n_red > (1ll << 22)) return ALAN_ERR_UNSUPPORTED;   // big problems are not launch-bound
+    if (mode == ALAN_MODE_WEXPSUM && (!c.w.p || c.w.dtype != ALAN_F32)) return ALAN_ERR_UNSUPPORTED;
+    const int64_t lim = (1ll << 31) - 1;
+    SmallDesc sd;
+    std::memset(&sd, 0, sizeof(sd));
+    for (int k = 0; k < SMALL_NK; ++k) sd.kdiv[k] = make_fastdiv(1);
+    for (int k = 0; k < SMALL_NR; ++k) sd.rdiv[k] = make_fastdiv(1);
+    // right-align the problem's dims in the fixed-size arrays (leading slots: size 1, stride 0)
+    const int ko = SMALL_NK - c.nk, ro = SMALL_NR - c.nr;
+    for (int j = 0; j < c.nk; ++j) sd.kdiv[ko + j] = make_fastdiv((uint32_t)c.ksize[j]);
+    for (int j = 0; j < c.nr; ++j) sd.rdiv[ro + j] = make_fastdiv((uint32_t)c.rsize[j]);
+    for (int f = 0; f < MAXF; ++f) {
+        const KTensor &src = c.f[f < c.nf ? f : 0];
+        if (src.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+        sd.f[f] = (const float *)src.p;
+        sd.fscale[f] = f < c.nf ? src.scale : 0.f;
+        if (f >= c.nf) continue;                       // alias of factor 0, strides stay 0
+        for (int j = 0; j < c.nk; ++j) {
+            if (src.ks[j] > lim || src.ks[j] < -lim) return ALAN_ERR_UNSUPPORTED;
+            sd.fks[f][ko + j] = (int32_t)src.ks[j];
+        }
+        for (int j = 0; j < c.nr; ++j) {
+            if (src.rs[j] > lim || src.rs[j] < -lim) return ALAN_ERR_UNSUPPORTED;
+            sd.frs[f][ro + j] = (int32_t)src.rs[j];
+        }
+    }
+    if (mode == ALAN_MODE_WEXPSUM) {
+        sd.w = (const float *)c.w.p;
+        for (int j = 0; j < c.nk; ++j) {
+            if (c.w.ks[j] > lim || c.w.ks[j] < -lim) return ALAN_ERR_UNSUPPORTED;
+            sd.wks[ko + j] = (int32_t)c.w.ks[j];
+        }
+        for (int j = 0; j < c.nr; ++j) {
+            if (c.w.rs[j] > lim || c.w.rs[j] < -lim) return ALAN_ERR_UNSUPPORTED;
+            sd.wrs[ro + j] = (int32_t)c.w.rs[j];
+        }
+    }
+    for (int j = 0; j < c.nk; ++j) {
+        if (c.o.ks[j] > lim || c.o.ks[j] < -lim) return ALAN_ERR_UNSUPPORTED;
+        sd.oks[ko + j] = (int32_t)c.o.ks[j];
+    }
+    sd.out = (float *)const_cast<void *>(c.o.p);
+    sd.n_out = gd.n_out;
+    sd.n_red = gd.n_red;
+    sd.nf = c.nf;
+    sd.out_scale = gd.out_scale;
+    sd.add_const = (float)gd.add_const;
+    if (gd.n_out == 0) return ALAN_OK;
+    switch (mode) {
+        case ALAN_MODE_LSE: launch_small_T<ALAN_MODE_LSE>(sd, gl, stream, ev); break;
+        case ALAN_MODE_SUM: launch_small_T<ALAN_MODE_SUM>(sd, gl, stream, ev); break;
+        case ALAN_MODE_WEXPSUM: launch_small_T<ALAN_MODE_WEXPSUM>(sd, gl, stream, ev); break;
+        case ALAN_MODE_NORMAL: launch_small_T<ALAN_MODE_NORMAL>(sd, gl, stream, ev); break;
+        case ALAN_MODE_NORMAL_LOGSCALE: launch_small_T<ALAN_MODE_NORMAL_LOGSCALE>(sd, gl, stream, ev); break;
+        case ALAN_MODE_BERNOULLI: launch_small_T<ALAN_MODE_BERNOULLI>(sd, gl, stream, ev); break;
+        default: return ALAN_ERR_BAD_DESC;
+    }
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
 template <typename T, int MODE>

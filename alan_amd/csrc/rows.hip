@@ -468,6 +468,8 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     GroupLaunch gl;
     int rc = plan_group(s2, c.o.dtype, add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
+    rc = try_launch_small(s2, gd, gl, ALAN_MODE_SUM, ALAN_F32, stream, EvPair());
+    if (rc != ALAN_ERR_UNSUPPORTED) return rc;
     return launch_group(gd, gl, ALAN_MODE_SUM, ALAN_F32, stream);
 }
 
