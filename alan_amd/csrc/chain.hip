@@ -7,119 +7,210 @@
 // eps-in-log as utils.py:503-507), and a few levels of segments reduce T -> 1.  Re-bracketing only
 // changes rounding.  At T=1000, K=30 the whole input is 3.6 MB: this path is latency-bound, so the
 // design goal is few launches (3 levels), not bandwidth.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace alan {
 
 constexpr int CHAIN_THREADS = 256;
 
-// P, C: log-space [K,K] in LDS (row stride K).  On exit P = logmmexp(P, C).  pe/ce alias P/C.
 template <typename T>
-__device__ void logmm_step(T *P, T *C, T *pm, T *cm, int K) {
-    const int tid = threadIdx.x;
-    // row max of P, column max of C   (utils.py:503-504)
-    for (int i = tid; i < K; i += CHAIN_THREADS) {
-        T a = Num<T>::ninf(), b = Num<T>::ninf();
-        for (int k = 0; k < K; ++k) {
-            a = fmax(a, P[i * K + k]);
-            b = fmax(b, C[k * K + i]);
-        }
-        pm[i] = a;
-        cm[i] = b;
-    }
-    __syncthreads();
-    for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-        const int i = e / K, j = e - i * K;
-        P[e] = Num<T>::exp(P[e] - pm[i]);
-        C[e] = Num<T>::exp(C[e] - cm[j]);
-    }
-    __syncthreads();
-    // R = Pe @ Ce, kept in registers until everyone has finished reading Pe
-    constexpr int MAXE = 40;  // K <= 100 -> ceil(K*K/256) <= 40
-    T acc[MAXE];
-#pragma unroll
-    for (int q = 0; q < MAXE; ++q) {
-        const int e = tid + q * CHAIN_THREADS;
-        T a = T(0);
-        if (e < K * K) {
-            const int i = e / K, j = e - i * K;
-            for (int k = 0; k < K; ++k) a += P[i * K + k] * C[k * K + j];
-        }
-        acc[q] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < MAXE; ++q) {
-        const int e = tid + q * CHAIN_THREADS;
-        if (e < K * K) {
-            const int i = e / K, j = e - i * K;
-            P[e] = Num<T>::log(acc[q] + Num<T>::eps) + pm[i] + cm[j];  // utils.py:506-507
-        }
-    }
-    __syncthreads();
+struct alignas(4 * sizeof(T)) Vec4 {
+    T x, y, z, w;
+};
+
+template <typename T>
+__device__ __forceinline__ void lds_max(T *addr, T v) {   // ds_max_f32 / ds_max_f64: NaN-ignoring, like fmax
+    __hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // One workgroup per segment: out[seg] = ms[t0] (x) ms[t0+1] (x) ... (x) ms[t1-1]   (log-space)
 // If vec_out != nullptr (final level, one segment) also writes logsumexp(out, -1).
-template <typename T>
+//
+// A segment is a chain of DEPENDENT logmmexp steps (utils.py:503-507), so what matters is the latency of
+// one step.  Per step: 3 barriers; the row maxima of P and column maxima of C are gathered with LDS
+// float-max atomics while those matrices are being written (no separate max pass); the next matrix is
+// prefetched from global memory into registers during the step; the [K,K]x[K,K] product runs on 1x4
+// register tiles with 16-byte LDS reads (5 reads per 16 FMAs; rows padded to a multiple of 4, pad = 0).
+// ME / NT: matrix elements / 1x4 tiles per thread (compile-time, so the per-thread loops carry no dead, predicated
+// copies): (4, 1) for K <= 32, (16, 4) for K <= 64, (40, 10) for K <= 100.
+template <typename T, int ME, int NT>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
     const T *ms, int64_t sT, int64_t sRow, int64_t sCol, int T_total, int seg_len, int K,
     T *out, T *vec_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *P = reinterpret_cast<T *>(smem_raw);
-    T *C = P + K * K;
-    T *pm = C + K * K;
-    T *cm = pm + K;
+    const int KP = (K + 3) & ~3, NJG = KP >> 2;
+    const int PS = KP + 4;                       // row stride of P: rows on different banks (C rows are read by whole lanes-groups at once)
+    T *P = reinterpret_cast<T *>(smem_raw);     // [K][PS]   log-space between steps, exp-space inside one
+    T *C = P + (size_t)KP * PS;                  // [KP][KP]
+    T *pm = C + (size_t)KP * KP;                 // [2][KP] row maxima of P (double buffered)
+    T *cm = pm + 2 * KP;                         // [2][KP] column maxima of C
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * seg_len;
     const int t1 = min(T_total, t0 + seg_len);
+    const T NINF = Num<T>::ninf();
+    const int KK = K * K;
 
-    for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-        const int i = e / K, j = e - i * K;
-        P[e] = ms[(int64_t)t0 * sT + i * sRow + j * sCol];
-    }
-    for (int t = t0 + 1; t < t1; ++t) {
-        for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-            const int i = e / K, j = e - i * K;
-            C[e] = ms[(int64_t)t * sT + i * sRow + j * sCol];
-        }
-        __syncthreads();
-        logmm_step<T>(P, C, pm, cm, K);
+    for (int i = tid; i < 2 * KP; i += CHAIN_THREADS) {
+        pm[i] = NINF;
+        cm[i] = NINF;
     }
     __syncthreads();
+    // P <- matrix t0, C <- matrix t0+1 (log space), maxima by atomics
+    for (int e = tid; e < KK; e += CHAIN_THREADS) {
+        const int i = e / K, j = e - i * K;
+        const T v = ms[(int64_t)t0 * sT + i * sRow + j * sCol];
+        P[i * PS + j] = v;
+        lds_max(&pm[i], v);
+        if (t0 + 1 < t1) {
+            const T c = ms[(int64_t)(t0 + 1) * sT + i * sRow + j * sCol];
+            C[i * KP + j] = c;
+            lds_max(&cm[j], c);
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    T creg[ME];
+    auto prefetch = [&](int tt) {   // matrix tt -> registers; consumed one whole step later
+        if (tt < t1) {
+#pragma unroll
+            for (int q = 0; q < ME; ++q) {
+                const int e = tid + q * CHAIN_THREADS;
+                if (e < KK) {
+                    const int i = e / K, j = e - i * K;
+                    creg[q] = ms[(int64_t)tt * sT + i * sRow + j * sCol];
+                }
+            }
+        }
+    };
+    prefetch(t0 + 2);
+    for (int t = t0 + 1; t < t1; ++t) {
+        const T *pmc = pm + cur * KP, *cmc = cm + cur * KP;
+        T *pmn = pm + (cur ^ 1) * KP, *cmn = cm + (cur ^ 1) * KP;
+        const bool more = t + 1 < t1;
+        // ---- exp pass (utils.py:503-505), pads -> 0; the other max buffers are reset for this step's writes
+#pragma unroll 4
+        for (int e = tid; e < KP * KP; e += CHAIN_THREADS) {
+            const int i = e / KP, j = e - i * KP;
+            const bool in = i < K && j < K;
+            if (i < K) P[i * PS + j] = in ? Num<T>::exp(P[i * PS + j] - pmc[i]) : T(0);
+            C[e] = in ? Num<T>::exp(C[e] - cmc[j]) : T(0);
+        }
+        for (int i = tid; i < KP; i += CHAIN_THREADS) {
+            pmn[i] = NINF;
+            cmn[i] = NINF;
+        }
+        __syncthreads();
+        // ---- R = Pe @ Ce on 1x4 register tiles
+        Vec4<T> acc[NT];
+        const Vec4<T> *P4 = reinterpret_cast<const Vec4<T> *>(P);
+        const Vec4<T> *C4 = reinterpret_cast<const Vec4<T> *>(C);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tile = tid + q * CHAIN_THREADS;
+            Vec4<T> a = {T(0), T(0), T(0), T(0)};
+            if (tile < K * NJG) {
+                const int i = tile / NJG, jg = tile - i * NJG;
+#pragma unroll 4
+                for (int k4 = 0; k4 < NJG; ++k4) {
+                    const Vec4<T> p = P4[i * (NJG + 1) + k4];
+                    const Vec4<T> c0 = C4[(4 * k4) * NJG + jg], c1 = C4[(4 * k4 + 1) * NJG + jg],
+                                  c2 = C4[(4 * k4 + 2) * NJG + jg], c3 = C4[(4 * k4 + 3) * NJG + jg];
+                    a.x += p.x * c0.x + p.y * c1.x + p.z * c2.x + p.w * c3.x;
+                    a.y += p.x * c0.y + p.y * c1.y + p.z * c2.y + p.w * c3.y;
+                    a.z += p.x * c0.z + p.y * c1.z + p.z * c2.z + p.w * c3.z;
+                    a.w += p.x * c0.w + p.y * c1.w + p.z * c2.w + p.w * c3.w;
+                }
+            }
+            acc[q] = a;
+        }
+        __syncthreads();
+        // ---- P <- log(R + eps) + pm + cm (utils.py:506-507) with its new row maxima; C <- matrix t+1
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int tile = tid + q * CHAIN_THREADS;
+            if (tile < K * NJG) {
+                const int i = tile / NJG, jg = tile - i * NJG;
+                const T r[4] = {acc[q].x, acc[q].y, acc[q].z, acc[q].w};
+                T mx = NINF;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 4 * jg + c;
+                    if (j < K) {
+                        const T v = Num<T>::log(r[c] + Num<T>::eps) + pmc[i] + cmc[j];
+                        P[i * PS + j] = v;
+                        mx = fmax(mx, v);
+                    }
+                }
+                lds_max(&pmn[i], mx);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < ME; ++q) {
+                const int e = tid + q * CHAIN_THREADS;
+                if (e < KK) {
+                    const int i = e / K, j = e - i * K;
+                    C[i * KP + j] = creg[q];
+                    lds_max(&cmn[j], creg[q]);
+                }
+            }
+            prefetch(t + 2);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
     if (out)
-        for (int e = tid; e < K * K; e += CHAIN_THREADS) out[(int64_t)blockIdx.x * K * K + e] = P[e];
+        for (int e = tid; e < KK; e += CHAIN_THREADS) {
+            const int i = e / K, j = e - i * K;
+            out[(int64_t)blockIdx.x * KK + e] = P[i * PS + j];
+        }
     if (vec_out) {
         // torch.logsumexp(lp, -1)  (logpq.py:139): no eps; -inf rows stay -inf
         for (int i = tid; i < K; i += CHAIN_THREADS) {
-            T mx = Num<T>::ninf();
-            for (int j = 0; j < K; ++j) mx = fmax(mx, P[i * K + j]);
+            T mx = NINF;
+            for (int j = 0; j < K; ++j) mx = fmax(mx, P[i * PS + j]);
             T s = T(0);
-            const T mref = (mx == Num<T>::ninf() || mx == -Num<T>::ninf()) ? T(0) : mx;
-            for (int j = 0; j < K; ++j) s += Num<T>::exp(P[i * K + j] - mref);
+            const T mref = (mx == NINF || mx == -NINF) ? T(0) : mx;
+            for (int j = 0; j < K; ++j) s += Num<T>::exp(P[i * PS + j] - mref);
             vec_out[i] = Num<T>::log(s) + mref;
         }
     }
 }
 
-static int pick_segment(int64_t T) {
-    // 3 levels reach 1 for T <= seg^3: 10 covers T = 1000
-    int seg = 2;
-    while ((int64_t)seg * seg * seg < T && seg < 32) ++seg;
-    return seg;
+// Segment length: levels cost a launch each (a ~ 5.7 us measured), every level runs its longest segment's
+// (len - 1) dependent steps (b ~ 2.4 us at K <= 32, growing with the K^2 work of a step).  T = 1000, K = 30:
+// 4 (five levels of 3 steps) rather than 10 (three levels of 9).
+static int pick_segment(int64_t T, int64_t K) {
+    if (const char *e = getenv("ALAN_CHAIN_SEG")) return std::max(2, std::min(64, atoi(e)));   // tuning knob
+    const double kk = std::max(1.0, (double)K / 32.0);
+    const double a = 5.7, b = 2.44 * kk * kk;
+    int best = 2;
+    double best_cost = 1e300;
+    for (int seg = 2; seg <= 32; ++seg) {
+        double cost = 0;
+        for (int64_t n = T; n > 1; n = (n + seg - 1) / seg) cost += a + (double)(std::min<int64_t>(seg, n) - 1) * b;
+        if (cost < best_cost) best_cost = cost, best = seg;
+    }
+    return best;
 }
 
 template <typename T>
 static int chain_run(const void *ms_, int64_t Tn, int64_t K, int64_t sT, int64_t sRow, int64_t sCol,
                      void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream) {
     const size_t mat = (size_t)K * K * sizeof(T);
-    const size_t smem = 2 * mat + 2 * K * sizeof(T);
+    const size_t KP = (size_t)((K + 3) & ~3);
+    const size_t smem = (KP * (KP + 4) + KP * KP + 4 * KP) * sizeof(T);
     if (K > 100 || smem > 160 * 1024) return ALAN_ERR_UNSUPPORTED;
-    auto kern = chain_segment_kernel<T>;
+    auto kern = K <= 32 ? chain_segment_kernel<T, 4, 1> : K <= 64 ? chain_segment_kernel<T, 16, 4>
+                                                                  : chain_segment_kernel<T, 40, 10>;
     if (smem > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return ALAN_ERR_LAUNCH;
-    const int seg = pick_segment(Tn);
+    const int seg = pick_segment(Tn, K);
     const T *src = (const T *)ms_;
     int64_t n = Tn;
     T *bufs[2] = {(T *)ws, nullptr};
@@ -296,8 +387,7 @@ extern "C" int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64
 extern "C" size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
     if (T < 1 || K < 1) return 0;
     const size_t mat = (size_t)K * K * (dtype == ALAN_F64 ? 8 : 4);
-    int seg = 2;
-    while ((int64_t)seg * seg * seg < T && seg < 32) ++seg;
+    const int seg = alan::pick_segment(T, K);
     const int64_t n1 = (T + seg - 1) / seg;
     const int64_t n2 = (n1 + seg - 1) / seg;
     return ((n1 * mat + 255) & ~(size_t)255) + ((n2 * mat + 255) & ~(size_t)255);
