@@ -195,24 +195,42 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
             lq = sampler.reduce_logQ(neg_q, active_platedims, Kdim)
             neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
         return [lp, neg_q], (Kdim,), (), ()
+    # Several variables (a Group): a variable whose prior and posterior are both Normal on the group's own dims
+    # contributes log P - log Q as ONE launch (the first such one also carries the -log K); the others
+    # contribute a log P factor and their log Q to the sum that reduce_logQ sees (Sampler.py:118-134 is
+    # separable over variables whose log Q has no parent K, which is exactly when the fusion applies).
+    pqs = []
     for var in prog_P:
         x = sample[var]
         assert isinstance(x, PT)
-        lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
-                                           dimcache=dimcache)
-        lq, Kinit_q = prog_Q[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
-                                           dimcache=dimcache)
+        if not isinstance(prog_P[var], Timeseries) and not isinstance(prog_Q[var], Timeseries):
+            tP, tQ = prog_P[var].tdd(scope, dimcache), prog_Q[var].tdd(scope, dimcache)
+            pq = TorchDimDist.log_p_minus_q(tP, tQ, x, order, own, 0.0 if pqs else math.log(K))
+            if pq is not None:
+                pqs.append(pq)
+                continue
+            lp, Kinit_p = tP.log_prob_pt(x, dim_order=order), None
+            lq, Kinit_q = tQ.log_prob_pt(x, dim_order=order), None
+        else:
+            lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
+                                               dimcache=dimcache)
+            lq, Kinit_q = prog_Q[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
+                                               dimcache=dimcache)
         if Kinit_q is not None:
             assert Kinit_p is Kinit_q
         if Kinit_p is not None:
             Kinits.append(Kinit_p)
         logPs.append(lp)
         total_logQ = lq if total_logQ is None else pt_add(total_logQ, lq)
-    assert K == total_logQ.size_of(id(Kdim))
-    lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
-    # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
-    # factors on the fly, so pre-adding them would only cost extra launches)
-    neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
+    neg_q = None
+    if total_logQ is not None:
+        assert K == total_logQ.size_of(id(Kdim))
+        lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
+        # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
+        # factors on the fly, so pre-adding them would only cost extra launches)
+        neg_q = PT(t.sub(0.0 if pqs else -math.log(K), lq.x), lq.dims)
+    for pq in pqs:
+        neg_q = pq if neg_q is None else pt_add(neg_q, pq)
     logPs.sort(key=lambda p: -p.x.numel())
     for lp in logPs[2:]:                       # large Groups: keep the factor count of the step small
         neg_q = pt_add(neg_q, lp)
