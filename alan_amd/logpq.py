@@ -229,12 +229,10 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
         # factors on the fly, so pre-adding them would only cost extra launches)
         neg_q = PT(t.sub(0.0 if pqs else -math.log(K), lq.x), lq.dims)
-    for pq in pqs:
-        neg_q = pq if neg_q is None else pt_add(neg_q, pq)
-    logPs.sort(key=lambda p: -p.x.numel())
-    for lp in logPs[2:]:                       # large Groups: keep the factor count of the step small
-        neg_q = pt_add(neg_q, lp)
-    factors = [*logPs[:2], neg_q]
+    # every term stays its own factor: the contraction kernels add factors on the fly (up to 6 per launch; the
+    # planner pre-adds the smallest ones only when a step would exceed that), so pre-adding here would only
+    # cost launches
+    factors = [*logPs, *pqs] + ([neg_q] if neg_q is not None else [])
 
     if Kinits:
         for k in init_Ks:
