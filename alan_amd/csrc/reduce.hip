@@ -12,6 +12,7 @@
 //   rows kernel    (rows.hip) LDS-staged fast path for the dominant shape: reduce dim contiguous in
 //                  the largest factor (movielens F[M,Ka,Kb,Kz] over Kz), optional fused plate sum.
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 #include "plan.h"
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
 
     // ---- stream over the reduce index, UNR elements per step: their loads are all issued before the
     // first is consumed (small problems are pure latency chains; big ones want the loads in flight)
-    constexpr int UNR = 4;
     T m = Num<T>::ninf(), s = T(0);
+    auto stream = [&](auto unr_c) {
+    constexpr int UNR = decltype(unr_c)::value;
     for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
         T val[UNR][MAXF];
         T wv[UNR];
@@ -172,6 +174,13 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
             accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
         }
     }
+    };
+    // one element per lane (elementwise-like launches, e.g. the backward wrt the big factor): no unrolling,
+    // otherwise every lane would issue 3 masked duplicate loads
+    if (d.n_red <= G)
+        stream(std::integral_constant<int, 1>{});
+    else
+        stream(std::integral_constant<int, 4>{});
 
     combine_lanes<T, MODE, BLOCK>(m, s, G);
     if (active && gl == 0) {
