@@ -42,10 +42,19 @@ with open(os.path.join(OUT, "r1_bench_default_kernel_stats.md"), "w") as f:
             continue
         f.write(f"| `{short(r['Name'])}` | {calls} | {calls / evals:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |\n")
     rk = [r for r in rows if "rows_kernel" in r["Name"]][0]
+    # the events in bench.py time only the EAGER launches (the last `steps` ones); split the trace the same way
+    tr = [r for r in csv.DictReader(open(one("stats/**/*kernel_trace.csv"))) if "rows_kernel" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr]
+    n_eager = bench["steps"]
+    replay, eager = dur[:-n_eager], dur[-n_eager:]
     f.write(f"\n`alan::rows_kernel` (the dominant reduce_Ks kernel, S-ML plate step at the literal movielens size: 32.5 MB) "
             f"averages {float(rk['AverageNs']) / 1e3:.1f} us here; bench.py's live HIP-event measurement of the same launches "
             f"in the bench run committed beside this file (`r1_bench.json`, a separate process on the same box) gives "
-            f"{bench['roofline']['us_per_launch']:.1f} us (hipExtLaunchKernelGGL start/stop events).\n")
+            f"{bench['roofline']['us_per_launch']:.1f} us (hipExtLaunchKernelGGL start/stop events).  Those events exist only "
+            f"on the {n_eager} eager launches that follow the timed graph replays; in this trace the same split reads "
+            f"{sum(replay) / len(replay):.1f} us over the {len(replay)} launches inside warm-up / graph replays (back to back) and "
+            f"{sum(eager) / len(eager):.1f} us over the {len(eager)} eager ones (the GPU idles between Python-driven launches).\n")
 
 # ---- PMC passes
 def pmc(which, counter):
