@@ -37,12 +37,18 @@ def logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scop
     sharded = len(chunks) > 1 and getattr(computation_strategy, "sharded", lambda: False)()
     mine = computation_strategy.my_chunks(len(chunks)) if sharded else range(len(chunks))
 
-    lpq = None
+    parts = []
     for i in mine:
-        lpq = run(name=name, P=P, Q=Q, scope=scope, active_platedims=active_platedims,
-                  groupvarname2Kdim=groupvarname2Kdim, varname2groupvarname=varname2groupvarname,
-                  sampler=sampler, computation_strategy=computation_strategy, prev_lpq=lpq,
-                  dimcache=dimcache, **chunks[i])
+        parts.append(run(name=name, P=P, Q=Q, scope=scope, active_platedims=active_platedims,
+                         groupvarname2Kdim=groupvarname2Kdim, varname2groupvarname=varname2groupvarname,
+                         sampler=sampler, computation_strategy=computation_strategy, prev_lpq=None,
+                         dimcache=dimcache, **chunks[i]))
+    # the chunks' results are summed (logpq.py:151-153) -- in one stacked reduction rather than a chain of adds
+    lpq = parts[0]
+    if len(parts) > 1:
+        for p in parts[1:]:
+            assert set(p.ids) == set(lpq.ids)
+        lpq = PT(t.stack([pt_align(p, lpq.ids) for p in parts]).sum(0), lpq.dims)
     assert isinstance(lpq, PT)
     if sharded:
         lpq = all_reduce_sum(lpq, computation_strategy.group)
