@@ -232,10 +232,19 @@ class TorchDimDist:
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
             lazy = isinstance(scale, ExpPT) and not scale.materialised
             spec = (x.dims, loc.dims, scale.dims, out_dims, lazy, ab)
-            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, scale.raw if lazy else scale.x), out_dims)
+            sx = scale.raw if lazy else scale.x
+            if not (t.is_grad_enabled() and (x.x.requires_grad or loc.x.requires_grad or sx.requires_grad)):
+                from . import engine as E           # nothing to record: skip the autograd.Function round trip
+                return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.x.detach(), loc.dims), (sx.detach(), scale.dims),
+                                           out_dims, log_scale=lazy, affine=ab), out_dims)
+            return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, sx), out_dims)
         if kind == "bernoulli":
             logits = self.kwargs["logits"]
             spec = (x.dims, logits.dims, out_dims, ab)
+            if not (t.is_grad_enabled() and (x.x.requires_grad or logits.x.requires_grad)):
+                from . import engine as E
+                return PT(E.bernoulli_logprob((x.x.detach(), x.dims), (logits.x.detach(), logits.dims), out_dims, ab),
+                          out_dims)
             return PT(_FusedBernoulliLogProb.apply(spec, x.x, logits.x), out_dims)
         d = self._build(ids, n_sample)
         lp = d.log_prob(pt_align(x, ids))
@@ -473,16 +482,50 @@ def call_model_lambda(fn, named_args, dimcache=None):
         if perm != list(range(len(perm))):
             x = x.permute(*perm, *range(len(perm), x.ndim))
         args.append(x)
-    f = fn
-    for i in reversed(order):
-        f = t.vmap(f, in_dims=tuple(0 if i in p.ids else None for p in vals))
-    val = f(*args)
+    val = _nested_vmap(fn, args, [p.ids for p in vals], order, {i: d.size for i, d in seen.items()})
     if not isinstance(val, t.Tensor):
         raise Exception("Lambda on a distribution returned a non-Tensor")
     out = PT(val, [seen[i] for i in order])
     if memo is not None:
         memo[key] = (fn, vals, out)
     return out
+
+
+try:    # the functorch primitives torch.vmap is built from: 5-10 us per level instead of ~100 us of checks and pytrees
+    from torch._C._functorch import (_add_batch_dim, _remove_batch_dim, _vmap_decrement_nesting,
+                                     _vmap_increment_nesting)
+except ImportError:                                                        # pragma: no cover
+    _add_batch_dim = None
+
+
+def _nested_vmap(fn, args, arg_ids, order, sizes):
+    """fn mapped over the dims ``order`` (outermost first); every arg carries its present dims leading, in that
+    order.  Same semantics as nested ``torch.vmap(..., in_dims=0/None, out_dims=0, randomness="error")``."""
+    if _add_batch_dim is None:
+        f = fn
+        for i in reversed(order):
+            f = t.vmap(f, in_dims=tuple(0 if i in ids else None for ids in arg_ids))
+        return f(*args)
+    args = list(args)
+    levels = []
+    try:
+        for i in order:
+            lvl = _vmap_increment_nesting(sizes[i], "error")
+            levels.append((lvl, sizes[i]))
+            for k, ids in enumerate(arg_ids):
+                if i in ids:
+                    args[k] = _add_batch_dim(args[k], 0, lvl)
+        out = fn(*args)
+        if not isinstance(out, t.Tensor):
+            raise Exception("Lambda on a distribution returned a non-Tensor")
+        while levels:
+            lvl, size = levels.pop()
+            out = _remove_batch_dim(out, lvl, size, 0)
+            _vmap_decrement_nesting()
+        return out
+    finally:
+        for _ in levels:                    # only non-empty when fn raised
+            _vmap_decrement_nesting()
 
 
 def _as_dim(v, name, cache):

@@ -87,34 +87,41 @@ def _result_dtype(tensors):
 
 
 # --------------------------------------------------------------------------- autograd function
+def _reduce_forward(spec, tensors, need_grad):
+    """The launch behind _Reduce.forward.  Returns (out, out_dims, lse or None, sizes)."""
+    dimlists, reduce, plate, add_const = spec
+    factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
+    sizes = _space(factors)
+    for d in (*reduce, *plate):
+        if d not in sizes:
+            raise Exception(f"dim {d} to reduce is not on any factor")
+    keep = [d for d in sizes if d not in reduce and d not in plate]
+    dtype = _result_dtype(list(tensors))
+    device = tensors[0].device
+    out_dims = _out_order(factors, keep, sizes)
+    out = t.empty([sizes[d] for d in out_dims], dtype=dtype, device=device)
+    lse = None
+    if reduce:
+        roles = {d: (N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP) for d in sizes}
+        if plate and need_grad:
+            lse_dims = _out_order(factors, keep + list(plate), sizes)
+            lse = (t.empty([sizes[d] for d in lse_dims], dtype=dtype, device=device), lse_dims)
+        _launch(N.MODE_LSE, factors, sizes, roles, out, out_dims, lse_out=lse, add_const=add_const)
+        if lse is None:
+            lse = (out, out_dims)   # add_const is 0 whenever a backward is needed through here
+    else:
+        roles = {d: (N.REDUCE if d in plate else N.KEEP) for d in sizes}
+        _launch(N.MODE_SUM, factors, sizes, roles, out, out_dims, add_const=add_const)
+    return out, out_dims, lse, sizes
+
+
 class _Reduce(t.autograd.Function):
     """out[keep] = sum_plate  LSE_reduce( sum_f factor_f )  (+ add_const);  mode SUM when no reduce dims."""
 
     @staticmethod
     def forward(ctx, spec, *tensors):
         dimlists, reduce, plate, add_const = spec
-        factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
-        sizes = _space(factors)
-        for d in (*reduce, *plate):
-            if d not in sizes:
-                raise Exception(f"dim {d} to reduce is not on any factor")
-        keep = [d for d in sizes if d not in reduce and d not in plate]
-        dtype = _result_dtype(list(tensors))
-        device = tensors[0].device
-        out_dims = _out_order(factors, keep, sizes)
-        out = t.empty([sizes[d] for d in out_dims], dtype=dtype, device=device)
-        lse = None
-        if reduce:
-            roles = {d: (N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP) for d in sizes}
-            if plate and any(x.requires_grad for x in tensors):
-                lse_dims = _out_order(factors, keep + list(plate), sizes)
-                lse = (t.empty([sizes[d] for d in lse_dims], dtype=dtype, device=device), lse_dims)
-            _launch(N.MODE_LSE, factors, sizes, roles, out, out_dims, lse_out=lse, add_const=add_const)
-            if lse is None:
-                lse = (out, out_dims)   # add_const is 0 whenever a backward is needed through here
-        else:
-            roles = {d: (N.REDUCE if d in plate else N.KEEP) for d in sizes}
-            _launch(N.MODE_SUM, factors, sizes, roles, out, out_dims, add_const=add_const)
+        out, out_dims, lse, sizes = _reduce_forward(spec, tensors, any(x.requires_grad for x in tensors))
         ctx.spec = (dimlists, tuple(reduce), tuple(plate), add_const, tuple(out_dims), sizes)
         ctx.lse_dims = None if lse is None else tuple(lse[1])
         ctx.has_lse = bool(reduce)
@@ -197,7 +204,11 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
         out, dims = _reduce_factors(factors, reduce, plate, 0.0)
         return out + add_const, dims
     spec = (tuple(d for _, d in factors), reduce, plate, float(add_const))
-    out = _Reduce.apply(spec, *[x for x, _ in factors])
+    tensors = [x for x, _ in factors]
+    if not (t.is_grad_enabled() and any(x.requires_grad for x in tensors)):
+        out, out_dims, _, _ = _reduce_forward(spec, tensors, False)   # nothing to record: no autograd.Function
+        return out, tuple(out_dims)
+    out = _Reduce.apply(spec, *tensors)
     sizes = _space(factors)
     keep = [d for d in sizes if d not in reduce and d not in plate]
     return out, tuple(_out_order([(x.detach(), d) for x, d in factors], keep, sizes))

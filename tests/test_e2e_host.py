@@ -150,3 +150,30 @@ def test_reference_suite_models_host_logic(name, oracle_backend):
 @pytest.mark.parametrize("name", SMALL)
 def test_reference_suite_models_hip(name):
     _check_small(name, "cuda")
+
+
+def test_nested_vmap_matches_torch_vmap():
+    """dist._nested_vmap (functorch batching primitives, no per-call checks) == nested torch.vmap, including outputs
+    that do not depend on a mapped dim and clean nesting state after an exception inside the lambda."""
+    import torch as t
+    from alan_amd import dist as D
+    g = t.Generator().manual_seed(0)
+    z, x, y = t.randn(7, 5, 3, generator=g), t.randn(7, 3, 4, generator=g), t.randn(5, generator=g)
+    ids = [(1, 2), (1,), (2,)]
+    fns = [lambda z, x, y: z @ x, lambda z, x, y: x.sum(-1), lambda z, x, y: y * 2.0, lambda z, x, y: t.ones(3),
+           lambda z, x, y: z.exp() + y]
+    for fn in fns:
+        got = D._nested_vmap(fn, [z, x, y], ids, [1, 2], {1: 7, 2: 5})
+        f = fn
+        for i in reversed([1, 2]):
+            f = t.vmap(f, in_dims=tuple(0 if i in k else None for k in ids))
+        want = f(z, x, y)
+        assert got.shape == want.shape
+        t.testing.assert_close(got, want)
+    with pytest.raises(ZeroDivisionError):
+        D._nested_vmap(lambda z, x, y: 1 / 0, [z, x, y], ids, [1, 2], {1: 7, 2: 5})
+    t.testing.assert_close(t.vmap(lambda a: a * 2)(t.ones(3)), 2 * t.ones(3))    # vmap state is intact
+    zz = z.clone().requires_grad_(True)                                           # differentiable
+    out = D._nested_vmap(lambda z, x, y: z @ x, [zz, x, y], ids, [1, 2], {1: 7, 2: 5})
+    (gz,) = t.autograd.grad(out.sum(), zz)
+    t.testing.assert_close(gz, x.sum(-1)[:, None, :].expand(7, 5, 3))
