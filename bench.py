@@ -294,20 +294,34 @@ def main():
         out["producer"] = {"kernel": "alan::reduce_group_kernel<float, NORMAL> (fused Normal log-prob producer of F)",
                            "us_per_launch": sum(sel) / len(sel) * 1e3, "bytes_written": big,
                            "launches_timed": len(sel)}
-    if world > 1 and not args.no_extras:
-        # BASELINE config C4 in the same run: movielens K=100, plate_1 sharded over the ranks
+    if not args.no_extras:
+        # BASELINE config C4 in the same run, under the same key at every N: movielens K=100,
+        # Split('plate_1', 38) -- 8 chunks on one GPU, sharded over the ranks (one all-reduce) at N > 1
         s100 = draw(prob, 100)
         st100 = strategy_for(world, 100)
         try:
             d100, v100 = timed_evals(s100, st100, 10, 2, world, graph=use_graph)
             out["c4_movielens_K100"] = {"evals_per_s": 10 / d100, "ms_per_eval": d100 / 10 * 1e3, "elbo": v100,
-                                        "strategy": f"Split('plate_1', {st100.split_size}, shard=True)",
-                                        "note": "compare with sweep.K100 of the 1-GPU run (Split('plate_1', 38))"}
+                                        "n_gpus": world,
+                                        "strategy": f"Split('plate_1', {st100.split_size}" +
+                                                    (", shard=True)" if world > 1 else ")")}
         except Exception as e:
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
+        t.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extras:
         out["roofline_scaled"] = roofline_scaled(K)
+        # sample() + elbo per iteration, as examples/basic_runner.py:86-97 of the reference counts it (eager)
+        for _ in range(3):
+            prob.sample(K, reparam=False).elbo_nograd(strat)
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            prob.sample(K, reparam=False).elbo_nograd(strat)
+        t.cuda.synchronize()
+        dt_se = (time.perf_counter() - t0) / 20
+        out["sample_plus_elbo"] = {"ms_per_iter": dt_se * 1e3, "iters_per_s": 1 / dt_se,
+                                   "launch": "eager (a fresh sample every iteration)"}
         out["cpu_baseline"] = cpu_baseline(K)
         sweep = {}
         for k2 in (3, 10, 100):
