@@ -148,16 +148,33 @@ def timed_evals(sample, strat, steps, warmup, world, timer=None, graph=False):
     return dt, float(val)
 
 
-def cpu_baseline(K, budget_s=20.0):
-    """The same ELBO evaluated on the host cores through the CPU oracle (kind "port"): torch-CPU
-    log-probs + oracle/alan_oracle.py contractions, all cores.  Bounded to ~budget_s of CPU work."""
+def sample_on_cpu(sample, cpu_prob):
+    """The same particles as a Sample of the CPU problem (fresh Dim objects, matched by name)."""
+    import alan_amd as alan
+    from alan_amd.dims import PT, Dim
+    Kd = {g: Dim(str(d), d.size) for g, d in sample.groupvarname2Kdim.items()}
+    by_name = {str(d): d for d in Kd.values()}
+    by_name.update(cpu_prob.all_platedims)
+
+    def conv(tree):
+        return {k: (conv(v) if isinstance(v, dict) else PT(v.x.detach().cpu(), [by_name[str(d)] for d in v.dims]))
+                for k, v in tree.items()}
+
+    return alan.Sample(problem=cpu_prob, sample=conv(sample._pt_detached), groupvarname2Kdim=Kd,
+                       sampler=sample.sampler, reparam=False)
+
+
+def cpu_baseline(K, gpu_sample, gpu_elbo, budget_s=20.0):
+    """The same ELBO -- same model, data, parameters AND particles as the GPU run -- evaluated on the host cores
+    through the CPU oracle (kind "port"): torch-CPU log-probs + oracle/alan_oracle.py contractions, all cores.
+    Bounded to ~budget_s of CPU work."""
     from oracle import backend
     # torch-CPU elementwise ops stop scaling (and then regress) beyond a few dozen threads
     ncores = min(os.cpu_count() or 1, 32)
     t.set_num_threads(ncores)
     prob = build_problem("cpu")
     import alan_amd as alan
-    sample = draw(prob, K)
+    sample = sample_on_cpu(gpu_sample, prob)
     with backend.installed():
         t0 = time.perf_counter()
         v = sample.elbo_nograd(alan.no_checkpoint)       # warm
@@ -168,8 +185,9 @@ def cpu_baseline(K, budget_s=20.0):
             v = sample.elbo_nograd(alan.no_checkpoint)
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "ELBO evals/s", "cores": ncores, "kind": "port",
-            "sample": f"{n} evals of the same movielens K={K} ELBO on CPU (torch-CPU log-probs + oracle reduce_Ks)",
-            "elbo": float(v)}
+            "sample": f"{n} evals of the same movielens K={K} ELBO (same particles as the GPU run) on CPU "
+                      "(torch-CPU log-probs + oracle reduce_Ks)",
+            "elbo": float(v), "elbo_rel_diff_vs_gpu": abs(float(v) - gpu_elbo) / abs(gpu_elbo)}
 
 
 def pmc_traffic(key):
@@ -322,7 +340,7 @@ def main():
         dt_se = (time.perf_counter() - t0) / 20
         out["sample_plus_elbo"] = {"ms_per_iter": dt_se * 1e3, "iters_per_s": 1 / dt_se,
                                    "launch": "eager (a fresh sample every iteration)"}
-        out["cpu_baseline"] = cpu_baseline(K)
+        out["cpu_baseline"] = cpu_baseline(K, sample, elbo)
         sweep = {}
         for k2 in (3, 10, 100):
             s2 = draw(prob, k2)
