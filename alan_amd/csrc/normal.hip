@@ -19,21 +19,24 @@
 
 namespace alan {
 
+// Kernel argument (by value); the scalars every wave needs first sit in the leading two 64-byte lines.
 struct NormalDesc {
     const float *val, *loc, *scl;
     float *out;
-    int32_t E, Ep;                 // event length, padded to a multiple of 4
+    int32_t E, Ep;                 // event length; Ep = the kernel's EMAX (table row stride)
     uint32_t NV, NL, NS, l_chunk;
     int32_t nv;
-    FastDiv vdiv[MAXD];
-    int64_t v_vs[MAXD], v_os[MAXD];   // value / out strides over the value's keep dims
-    int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
-    int64_t l_os, s_os;               // out strides along the loc / scale dims
     int32_t log_scale;                // scl holds log(scale)
-    float out_scale, add_const;       // out = out_scale * log_prob + add_const
-    int32_t dbg;                      // ablation knob (ALAN_NORMAL_ABLATE): 1 prologue only, 2 no stores, 3 one scale row
     int32_t rows_contig;              // value rows of a workgroup are one contiguous, 16-byte aligned block
     int32_t vstage_off;               // LDS offset (floats) of the value staging area
+    float out_scale, add_const;       // out = out_scale * log_prob + add_const
+    int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
+    int64_t l_os, s_os;               // out strides along the loc / scale dims
+    FastDiv vdiv[MAXD];
+    int64_t v_vs[MAXD], v_os[MAXD];   // value / out strides over the value's keep dims
+#ifdef ALAN_ABLATE
+    int32_t dbg;                      // ablation knob (ALAN_NORMAL_ABLATE): 1 prologue only, 2 no stores, 3 one scale row
+#endif
 };
 
 // R = value rows per thread (rows t, t+256, ... of the workgroup's block of 256*R): every 16-byte read of a
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     }
     __syncthreads();
 
+#ifdef ALAN_ABLATE
     if (d.dbg == 1) {   // ablation: prologue only
         float q = lg[tid % d.NS];
 #pragma unroll
@@ -141,9 +145,14 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
         return;
     }
     const uint32_t ns_run = d.dbg == 3 ? 1u : d.NS;
+    const bool store_on = d.dbg != 2;
+#else
+    const uint32_t ns_run = d.NS;
+    constexpr bool store_on = true;
+#endif
     bool do_store[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) do_store[j] = active[j] && d.dbg != 2;
+    for (int j = 0; j < R; ++j) do_store[j] = active[j] && store_on;
     for (uint32_t il = l0; il < l1; ++il) {
         const float4 *m4 = reinterpret_cast<const float4 *>(mu + (size_t)(il - l0) * Ep);
         float dd[R][EMAX];
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
                     acc = fmaf(dd[j][4 * q + 3], ww[q].w, acc);
                 }
                 const float res = (-acc - lgi) * d.out_scale + d.add_const;
-                if (do_store[j] || res == 12345.678f)
+                if (do_store[j] || (!store_on && res == 12345.678f))
                     d.out[ooff[j] + (int64_t)il * d.l_os + (int64_t)is * d.s_os] = res;
             }
         }
@@ -238,7 +247,9 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
     d.log_scale = log_scale ? 1 : 0;
     d.out_scale = out_scale;
     d.add_const = (float)add_const;
+#ifdef ALAN_ABLATE
     if (const char *e = getenv("ALAN_NORMAL_ABLATE")) d.dbg = atoi(e);
+#endif
     {   // value rows contiguous in row-index order?  (voff(r) = r * E)
         bool contig = reinterpret_cast<uintptr_t>(d.val) % 16 == 0;   // (a workgroup's block starts 1 KiB-aligned)
         int64_t run = E;

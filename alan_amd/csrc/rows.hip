@@ -14,6 +14,7 @@
 //   * the plate sum is accumulated in a register across the chunk; each workgroup writes one partial
 //     per row, and a tiny second stage adds the chunks (deterministic: no float atomics).
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 
@@ -21,24 +22,37 @@
 
 namespace alan {
 
+// Kernel argument (by value).  Field ORDER matters: a wave's first global load depends on a chain of scalar
+// loads from this struct, one cache-line miss each -- everything the common path (one or two window-constant
+// small factors, partials or a direct store) needs sits in the first two 64-byte lines.
 struct RowsDesc {
+    // ---- line 0
     const float *F;
     int64_t total;          // elements of F reachable from F (tail guard for 16-byte loads)
     int32_t L, RB;
     uint32_t NO, P, p_chunk;
     int32_t nshared, ngen, nki, gs_off;
-    KTensor sh[MAXF];       // "shared" secondary factors: constant over the window (no inner keep dims)
-    int64_t sh_ps[MAXF];    //   stride along the plate dim
+    float add_const;
+    float *partial;         // per-chunk partials [n_chunks, NO] (n_chunks > 1) ...
+    // ---- line 1
+    float *out;             // ... or the final output
+    float *lse;             // optional per-row log-sum-exp values
+    int64_t l_ps;
+    const float *sh_p[2];   // first two "shared" secondary factors: constant over the window (no inner keep dims)
+    int64_t sh_ps[2];       //   stride along the plate dim
+    int32_t sh_rs[2];       //   stride along the row
+    // ---- the rest
+    const float *shx_p[MAXF];   // further shared factors (rare)
+    int64_t shx_ps[MAXF];
+    int32_t shx_rs[MAXF];
+    FastDiv kdiv[MAXD];     // inner keep dims
+    int64_t oks[MAXD];
+    int64_t lks[MAXD];
     KTensor gen[MAXF];      // general secondary factors: ks over INNER keep dims, rs[0] along the row
     int64_t gen_ps[MAXF];
-    FastDiv kdiv[MAXD];     // inner keep dims
-    float *out;             // final output (n_chunks == 1) ...
-    int64_t oks[MAXD];
-    float *partial;         // ... or per-chunk partials [n_chunks, NO]
-    float *lse;             // optional per-row log-sum-exp values
-    int64_t lks[MAXD], l_ps;
-    float add_const;
+#ifdef ALAN_ABLATE
     int32_t dbg;            // ablation knob (ALAN_ROWS_ABLATE): 1 = no reduction, 2 = no global loads
+#endif
 };
 
 #ifndef ROWS_NT
@@ -58,7 +72,9 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
     constexpr int NS = SHORT ? 8 : 16;   // float2 slots per lane: a lane holds <= 32 (SHORT: 16) row elements
     const int t = threadIdx.x;
     const int L = d.L;
+#ifdef ALAN_ABLATE
     if (d.dbg == 4) return;
+#endif
     const uint32_t o0 = blockIdx.x * (uint32_t)d.RB;
     const uint32_t nrows = min((uint32_t)d.RB, d.NO - o0);
     const uint32_t p0 = blockIdx.y * d.p_chunk;
@@ -104,7 +120,9 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
         const int64_t a0 = e0 & ~(int64_t)3;
         const int n4 = ((int)(e0 - a0) + (int)nrows * L + 3) >> 2;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(d.F + a0);
+#ifdef ALAN_ABLATE
         if (d.dbg >= 2) return;
+#endif
         if (a0 + 4 * (int64_t)n4 <= d.total) {  // whole slab inside the tensor (all but the very last one)
 #pragma unroll
             for (int u = 0; u < ROWS_UNR; ++u) {
@@ -144,11 +162,11 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
     auto shared_fetch = [&](uint32_t p) {
         gn0 = gn1 = gn_rest = 0.f;
         if (d.nshared > 0 && t < L) {
-            gn0 = ((const float *)d.sh[0].p)[(int64_t)p * d.sh_ps[0] + (int64_t)t * d.sh[0].rs[0]];
-            if (d.nshared > 1) gn1 = ((const float *)d.sh[1].p)[(int64_t)p * d.sh_ps[1] + (int64_t)t * d.sh[1].rs[0]];
+            gn0 = d.sh_p[0][(int64_t)p * d.sh_ps[0] + (int64_t)t * d.sh_rs[0]];
+            if (d.nshared > 1) gn1 = d.sh_p[1][(int64_t)p * d.sh_ps[1] + (int64_t)t * d.sh_rs[1]];
 #pragma unroll 1
             for (int f = 2; f < d.nshared; ++f)
-                gn_rest += ((const float *)d.sh[f].p)[(int64_t)p * d.sh_ps[f] + (int64_t)t * d.sh[f].rs[0]];
+                gn_rest += d.shx_p[f][(int64_t)p * d.shx_ps[f] + (int64_t)t * d.shx_rs[f]];
         }
     };
 
@@ -258,9 +276,12 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             }
         }
         float val;
+#ifdef ALAN_ABLATE
         if (d.dbg == 1 || d.dbg == 3) {
             val = x[0];
-        } else if (MODE == ALAN_MODE_LSE) {
+        } else
+#endif
+        if (MODE == ALAN_MODE_LSE) {
             float m = NEG;   // exact row max, then sum exp(x - max): the reference's two-pass arithmetic
 #pragma unroll
             for (int u = 0; u < 2 * NS; ++u) m = fmaxf(m, x[u]);
@@ -380,14 +401,28 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
         if (f == c.dominant) continue;
         bool shared = true;  // constant over the window: no inner keep dim
         for (int j = 0; j < d.nki; ++j) shared = shared && c.f[f].ks[k0 + j] == 0;
-        KTensor &dst = shared ? d.sh[d.nshared] : d.gen[d.ngen];
-        dst.p = c.f[f].p;
-        dst.dtype = c.f[f].dtype;
-        dst.scale = 1.f;
-        for (int j = 0; j < d.nki; ++j) dst.ks[j] = c.f[f].ks[k0 + j];
-        dst.rs[0] = c.f[f].rs[0];
-        (shared ? d.sh_ps[d.nshared] : d.gen_ps[d.ngen]) = k0 ? c.f[f].ks[0] : 0;
-        ++(shared ? d.nshared : d.ngen);
+        const int64_t ps = k0 ? c.f[f].ks[0] : 0;
+        if (shared) {
+            if (c.f[f].rs[0] > INT32_MAX || c.f[f].rs[0] < INT32_MIN) return ALAN_ERR_UNSUPPORTED;
+            const int i = d.nshared++;
+            if (i < 2) {
+                d.sh_p[i] = (const float *)c.f[f].p;
+                d.sh_ps[i] = ps;
+                d.sh_rs[i] = (int32_t)c.f[f].rs[0];
+            } else {
+                d.shx_p[i] = (const float *)c.f[f].p;
+                d.shx_ps[i] = ps;
+                d.shx_rs[i] = (int32_t)c.f[f].rs[0];
+            }
+        } else {
+            KTensor &dst = d.gen[d.ngen];
+            dst.p = c.f[f].p;
+            dst.dtype = c.f[f].dtype;
+            dst.scale = 1.f;
+            for (int j = 0; j < d.nki; ++j) dst.ks[j] = c.f[f].ks[k0 + j];
+            dst.rs[0] = c.f[f].rs[0];
+            d.gen_ps[d.ngen++] = ps;
+        }
     }
     d.out = (float *)const_cast<void *>(c.o.p);
     for (int j = 0; j < d.nki; ++j) d.oks[j] = c.o.ks[k0 + j];
@@ -396,7 +431,9 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     for (int j = 0; j < d.nki; ++j) d.lks[j] = c.l.ks[k0 + j];
     d.l_ps = k0 ? c.l.ks[0] : 0;
     d.add_const = two_stage ? 0.f : (float)add_const;
+#ifdef ALAN_ABLATE
     if (const char *e = getenv("ALAN_ROWS_ABLATE")) d.dbg = atoi(e);
+#endif
 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);

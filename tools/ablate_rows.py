@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Ablation of the rows kernel (env ALAN_ROWS_ABLATE: 1 = loads + LDS staging only, 2 = LDS reduction only)
+"""Ablation of the rows kernel (library built with `make -C alan_amd/csrc ABLATE=1`; env ALAN_ROWS_ABLATE:
+1 = loads + LDS staging only, 2 = LDS reduction only)
 across launch geometries; kernel time from library-recorded HIP events."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
