@@ -138,9 +138,14 @@ class _Reduce(t.autograd.Function):
         tensors = saved[:nf]
         factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
         grad_out = grad_out.detach()
+        need = [ctx.needs_input_grad[i + 1] for i in range(nf)]
+        if ctx.has_lse and any(need):
+            fused = _fused_backward(factors, need, sizes, reduce, plate, saved[nf], ctx.lse_dims, grad_out, out_dims)
+            if fused is not None:
+                return (None, *fused)
         grads = []
         for i, (x, dims) in enumerate(factors):
-            if not ctx.needs_input_grad[i + 1]:
+            if not need[i]:
                 grads.append(None)
                 continue
             g = t.empty(x.shape, dtype=x.dtype, device=x.device)
@@ -153,6 +158,42 @@ class _Reduce(t.autograd.Function):
                 _launch(N.MODE_SUM, [(grad_out, out_dims)], sizes, roles, g, dims)
             grads.append(g)
         return (None, *grads)
+
+
+def _fused_backward(factors, need, sizes, reduce, plate, lse, lse_dims, grad_out, out_dims):
+    """Every wanted gradient of an LSE(+plate) call from ONE pass over the largest factor
+    (alan_reduce_backward); None when the library declines the shape (the caller then issues one WEXPSUM
+    launch per factor)."""
+    if not all(x.dtype == t.float32 for x, _ in factors) or lse.dtype != t.float32 or grad_out.dtype != t.float32:
+        return None
+    space = list(sizes)
+    if len(space) > N.MAX_DIMS or len(factors) > N.MAX_FACTORS:
+        return None
+    bd = N.BackwardDesc()
+    desc = bd.fwd
+    desc.mode = N.MODE_LSE
+    desc.ndim = len(space)
+    for i, d in enumerate(space):
+        desc.size[i] = sizes[d]
+        desc.role[i] = N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP
+    desc.n_factors = len(factors)
+    device = factors[0][0].device
+    grads = []
+    for i, (x, dims) in enumerate(factors):
+        N.require_device(x, "log-prob factor")
+        N.fill_tensor(desc.factor[i], x, _strides(x, list(dims), space))
+        g = None
+        if need[i]:
+            g = t.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=device)
+            if g.untyped_storage().nbytes() != x.numel() * x.element_size():
+                return None                      # a factor with gaps / overlaps in memory: not this path
+            N.fill_tensor(bd.grad[i], g, _strides(g, list(dims), space))
+        grads.append(g)
+    go = grad_out.contiguous()
+    N.fill_tensor(desc.weight, go, _strides(go, list(out_dims), space))
+    N.fill_tensor(desc.lse_out, lse, _strides(lse, list(lse_dims), space))
+    N.fill_tensor(desc.out, go, _strides(go, list(out_dims), space))      # unused by the library
+    return grads if N.run_reduce_backward(bd, device) else None
 
 
 class _Tokens:

@@ -56,6 +56,10 @@ class ReduceDesc(C.Structure):
     ]
 
 
+class BackwardDesc(C.Structure):
+    _fields_ = [("fwd", ReduceDesc), ("grad", Tensor * MAX_FACTORS)]
+
+
 _lib = None
 
 
@@ -73,6 +77,10 @@ def lib():
         L.alan_reduce.argtypes = [C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_reduce_workspace_bytes.restype = C.c_size_t
         L.alan_reduce_workspace_bytes.argtypes = [C.POINTER(ReduceDesc)]
+        L.alan_reduce_backward.restype = C.c_int
+        L.alan_reduce_backward.argtypes = [C.POINTER(BackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_reduce_backward_workspace_bytes.restype = C.c_size_t
+        L.alan_reduce_backward_workspace_bytes.argtypes = [C.POINTER(BackwardDesc)]
         L.alan_chain_workspace_bytes.restype = C.c_size_t
         L.alan_chain_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp.restype = C.c_int
@@ -90,7 +98,8 @@ def lib():
     return _lib
 
 
-EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_chain_workspace_bytes",
+EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_backward",
+           "alan_reduce_backward_workspace_bytes", "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_abi_version", "alan_build_target")
 
@@ -139,6 +148,23 @@ def run_reduce(desc, device, algo_bytes=0):
     rc = L.alan_reduce(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,
                        current_stream(device))
     check(rc, "alan_reduce")
+
+
+ERR_UNSUPPORTED = -2
+
+
+def run_reduce_backward(desc, device):
+    """All gradients of an LSE call in one pass (alan_reduce_backward).  False when the problem does not fit
+    the streaming kernel -- the caller then falls back to one WEXPSUM launch per factor."""
+    L = lib()
+    nbytes = L.alan_reduce_backward_workspace_bytes(C.byref(desc))
+    ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
+    rc = L.alan_reduce_backward(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,
+                                current_stream(device))
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc, "alan_reduce_backward")
+    return True
 
 
 def chain_logmmexp(ms, want_chain=False):

@@ -107,6 +107,22 @@ size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *desc);
  * 256-byte aligned, and stay alive until the stream has passed this call. */
 int alan_reduce(const alan_reduce_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Backward of an ALAN_MODE_LSE call (with or without PLATE dims) with respect to EVERY factor in one pass over the
+ * largest one -- what autograd derives from utils.py:218-220 + logpq.py:149:
+ *     grad factor_f = sum_{dims not in f}  weight * exp(sum_f factor_f - lse)
+ *   fwd          the forward descriptor; fwd.weight = upstream gradient (strides over the KEEP dims), fwd.lse_out =
+ *                the per-(KEEP,PLATE) log-sum-exp values the forward saved (an INPUT here); fwd.out is not used
+ *   grad[f]      where factor f's gradient goes (data NULL = not wanted); same strides as factor f
+ * Returns ALAN_ERR_UNSUPPORTED when the problem does not have the shape of the streaming kernel (one contiguous
+ * REDUCE dim in the largest factor, every other factor constant over the KEEP dims, fp32); the caller then issues
+ * one ALAN_MODE_WEXPSUM call per factor. */
+typedef struct {
+    alan_reduce_desc_t fwd;
+    alan_tensor_t grad[ALAN_MAX_FACTORS];
+} alan_backward_desc_t;
+size_t alan_reduce_backward_workspace_bytes(const alan_backward_desc_t *desc);
+int alan_reduce_backward(const alan_backward_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Timeseries plate (utils.py:478-510, logpq.py:132-143).
  *   ms         [T, K, K] log transition factors, element strides (sT, sRow, sCol)
  *   out_chain  optional [K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)

@@ -75,11 +75,14 @@ def oracle_chain_backward(ms, vec, g):
 def installed():
     """Temporarily route alan_amd's launch seam to the oracle (CPU tensors accepted)."""
     from alan_amd import engine, native
-    saved = (engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward)
+    saved = (engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward,
+             native.run_reduce_backward)
     engine._launch, native.chain_logmmexp = oracle_launch, oracle_chain
     native.chain_logmmexp_backward = oracle_chain_backward
     native.require_device = lambda x, what="tensor": None
+    native.run_reduce_backward = lambda desc, device: False      # "not this shape": per-factor WEXPSUM launches
     try:
         yield
     finally:
-        engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward = saved
+        (engine._launch, native.chain_logmmexp, native.require_device, native.chain_logmmexp_backward,
+         native.run_reduce_backward) = saved

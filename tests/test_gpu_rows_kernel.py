@@ -167,3 +167,60 @@ def test_full_size_against_oracle_and_properties(M, K):
     rows, rd = E.reduce_factors([(Fd, dims[0]), (gd, dims[1])], reduce=("z",))
     mx = (Fd + gd[:, None, None, :]).amax(-1)
     assert bool((orc.align((rows.cpu(), rd), ("m", "a", "b")) >= mx.cpu() - 1e-5).all())
+
+
+@pytest.mark.parametrize("L,K2,plate", [(30, 30, True), (100, 12, True), (16, 40, True), (9, 50, True), (31, 20, True),
+                                        (30, 30, False), (64, 20, False)])
+def test_one_pass_backward_matches_per_factor_backward(L, K2, plate, monkeypatch):
+    """alan_reduce_backward (one pass over F: grad F streamed out, the small factors' gradients from the slab's column
+    sums) against the generic route (one WEXPSUM launch per factor) and against torch autograd on the CPU."""
+    from alan_amd import native as N
+    g = t.Generator().manual_seed(L * 3 + K2)
+    M = 9
+    shapes = [((M, K2, K2, L), ("m", "a", "b", "k")), ((M, L), ("m", "k")), ((L,), ("k",)), ((M,), ("m",))]
+    raw = [2 * t.randn(s, generator=g) for s, _ in shapes]
+    dims = [d for _, d in shapes]
+    pl = ("m",) if plate else ()
+
+    def run(fused):
+        calls = []
+        real = N.run_reduce_backward
+        monkeypatch.setattr(N, "run_reduce_backward",
+                            (lambda d, dev: calls.append(1) or real(d, dev)) if fused else (lambda d, dev: False))
+        leaves = [x.clone().to(DEV).requires_grad_(True) for x in raw]
+        out, odims = E.reduce_factors(list(zip(leaves, dims)), reduce=("k",), plate=pl)
+        w = t.randn(out.shape, generator=t.Generator().manual_seed(1)).to(DEV)
+        grads = t.autograd.grad((out * w).sum(), leaves)
+        monkeypatch.setattr(N, "run_reduce_backward", real)
+        return out, odims, w, grads, len(calls)
+
+    out_f, od, w, gf, n_f = run(True)
+    out_g, _, _, gg, n_g = run(False)
+    assert n_f == 1 and n_g == 0                                  # the one-pass path was taken (and completed)
+    for a, b in zip(gf, gg):
+        t.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)
+    cpu = [x.clone().requires_grad_(True) for x in raw]
+    ref = orc.logsumexp_sum(("k",), *zip(cpu, dims))
+    if plate:
+        ref = orc.plate_sum(ref, "m")
+    wc = orc.align((w.cpu(), tuple(od)), tuple(ref[1])).reshape(ref[0].shape) if od else w.cpu()
+    gref = t.autograd.grad((ref[0] * wc).sum(), cpu)
+    for a, b in zip(gf, gref):
+        t.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-4)
+
+
+def test_one_pass_backward_declines_row_dependent_small_factors():
+    """A small factor that varies over the window's rows is not the one-pass kernel's shape: the library says so
+    (ALAN_ERR_UNSUPPORTED) and autograd takes the per-factor route -- same gradients."""
+    g = t.Generator().manual_seed(3)
+    M, A, L = 6, 120, 30
+    raw = [t.randn(M, A, L, generator=g), t.randn(A, L, generator=g)]
+    dims = [("m", "a", "k"), ("a", "k")]
+    leaves = [x.clone().to(DEV).requires_grad_(True) for x in raw]
+    out, od = E.reduce_factors(list(zip(leaves, dims)), reduce=("k",), plate=("m",))
+    grads = t.autograd.grad(out.sum(), leaves)
+    cpu = [x.clone().requires_grad_(True) for x in raw]
+    ref = orc.plate_sum(orc.logsumexp_sum(("k",), *zip(cpu, dims)), "m")
+    gref = t.autograd.grad(ref[0].sum(), cpu)
+    for a, b in zip(grads, gref):
+        t.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-4)

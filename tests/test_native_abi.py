@@ -34,6 +34,15 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(N.Tensor) == 8 + 4 + 4 + 8 * N.MAX_DIMS
     expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8 + 16
     assert ctypes.sizeof(N.ReduceDesc) == expect
+    assert ctypes.sizeof(N.BackwardDesc) == expect + ctypes.sizeof(N.Tensor) * N.MAX_FACTORS
+
+
+def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
+    L = N.lib()
+    b = N.BackwardDesc()
+    assert L.alan_reduce_backward(None, None, 0, None) == -1
+    assert L.alan_reduce_backward(ctypes.byref(b), None, 0, None) == -1      # no weight / lse given
+    assert L.alan_reduce_backward_workspace_bytes(ctypes.byref(b)) == 0
 
 
 def test_bad_descriptors_are_rejected_without_touching_the_gpu():
