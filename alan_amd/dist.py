@@ -89,6 +89,11 @@ class _FusedNormalLogProb(t.autograd.Function):
         nev = value.ndim - len(vd)
         flat = lambda x, d: x.reshape(*x.shape[: len(d)], -1) if nev else x.unsqueeze(-1)
         v, l, s = flat(value.detach(), vd), flat(loc.detach(), ld), flat(scale.detach(), sd)
+        ids = lambda ds: {id(d) for d in ds}
+        if OUTER_BACKWARD and not (ids(vd) & ids(ld)) and not (ids(vd) & ids(sd)) and not (ids(ld) & ids(sd)) \
+                and ids(od) == ids(vd) | ids(ld) | ids(sd):
+            return (None, *_FusedNormalLogProb._backward_outer(ctx, G, v, l, s, value.shape, loc.shape,
+                                                                raw_scale.shape, log_scale))
         g, V, L, S = sub(od, False), sub(vd), sub(ld), sub(sd)
         w = 1.0 / (s * s)
         es = lambda expr, *ops: t.einsum(expr, *ops)
@@ -106,6 +111,58 @@ class _FusedNormalLogProb(t.autograd.Function):
                 gs = gs * s                                  # d/d log(scale)
             gs = gs.reshape(raw_scale.shape)
         return None, gv, gl, gs
+
+    @staticmethod
+    def _backward_outer(ctx, G, v, l, s, v_shape, l_shape, s_shape, log_scale):
+        """value / loc / scale on pairwise DISJOINT dims (the big K-cross-product factor, e.g. movielens
+        z[plate_1,K_z] ~ N(mu_z[K_mu], exp(psi_z)[K_psi])): one permuted copy of G, two GEMMs and a handful of
+        passes over [n_value, n_loc, event]-sized tensors -- with d = value - loc, w = 1 / (2 scale^2):
+            A = G @ 2w,   d value = -sum_loc d*A,   d loc = sum_value d*A,
+            d scale = (2w/scale) * <G, d^2> - <G>/scale          (d log scale = 2w <G, d^2> - <G>)."""
+        vd, ld, sd, od, _, _ = ctx.spec
+        pos = {id(d): k for k, d in enumerate(od)}
+        perm = [pos[id(d)] for d in (*vd, *ld, *sd)]
+        nV, nL, nS, E = v.numel() // v.shape[-1], l.numel() // l.shape[-1], s.numel() // s.shape[-1], v.shape[-1]
+        Gp = G.permute(*perm).reshape(nV * nL, nS)                      # one copy of G
+        v2, l2, s2 = v.reshape(nV, 1, E), l.reshape(1, nL, E), s.reshape(nS, E)
+        w2 = 1.0 / (s2 * s2)                                            # = 2w
+        gv = gl = gs = None
+        need_v, need_l, need_s = ctx.needs_input_grad[1:4]
+        D = v2 - l2                                                     # [nV, nL, E]
+        if need_v or need_l:
+            A = Gp @ w2
+            T = D * A.view(nV, nL, E)
+            if need_v:
+                gv = (-T.sum(1)).reshape(v_shape)
+            if need_l:
+                gl = _sum_leading(T.view(nV, nL * E)).reshape(l_shape)
+        if need_s:
+            # [nS, E] = Gp^T @ d^2 with K = n_value * n_loc (270,000 at movielens K=30): a batched product over row
+            # blocks, then the blocks summed by alan_reduce (no K = 270,000 GEMM, no multi-block torch reduction)
+            rows = nV * nL
+            blk = next((b for b in (1024, 1000, 900, 512, 500, 256, 250, 128, 100, 64, 50, 32, 30, 25, 16, 10, 8, 5, 4, 3, 2)
+                        if rows % b == 0), 1)
+            D2 = (D * D).view(rows // blk, blk, E)
+            S2 = _sum_leading(t.bmm(Gp.view(rows // blk, blk, nS).transpose(1, 2), D2).view(rows // blk, nS * E)).view(nS, E)
+            S0 = _sum_leading(Gp).unsqueeze(-1)                         # [nS, 1]
+            gs = w2 * S2 - S0 if log_scale else (w2 * S2 - S0) / s2
+            gs = gs.reshape(s_shape)
+        return gv, gl, gs
+
+
+def _sum_leading(x, blk=64):
+    """x[n, m].sum(0) as two short reductions (blocks of ``blk`` rows, then the blocks).  A single torch reduction
+    over a long leading dim is a multi-block kernel with a semaphore buffer cleared by a memset node; replayed
+    from a HIP graph onto an idle GPU that node was observed racing with its neighbours (the gradient of loc
+    changed with whether the host synchronised between replays).  Short reductions take the single-block path."""
+    n, m = x.shape
+    if n <= 4 * blk:
+        return x.sum(0)
+    main = (n // blk) * blk
+    part = x[:main].view(n // blk, blk, m).sum(1)
+    if main < n:
+        part = t.cat([part, x[main:].sum(0, keepdim=True)])
+    return _sum_leading(part, blk)
 
 
 class _FusedBernoulliLogProb(t.autograd.Function):
@@ -152,6 +209,9 @@ class _FusedBernoulliLogProb(t.autograd.Function):
 
 FUSE_NORMAL = True
 """Route Normal / Bernoulli(logits) log-probs on the GPU to the fused HIP producer kernels."""
+
+OUTER_BACKWARD = True
+"""Use the two-GEMM backward of the Normal producer when value / loc / scale carry disjoint dims."""
 
 
 class TorchDimDist:

@@ -177,3 +177,30 @@ def test_nested_vmap_matches_torch_vmap():
     out = D._nested_vmap(lambda z, x, y: z @ x, [zz, x, y], ids, [1, 2], {1: 7, 2: 5})
     (gz,) = t.autograd.grad(out.sum(), zz)
     t.testing.assert_close(gz, x.sum(-1)[:, None, :].expand(7, 5, 3))
+
+
+@pytest.mark.gpu
+def test_graphed_vi_step_does_not_depend_on_host_synchronisation():
+    """Replays of the captured training iteration must give bit-identical parameters whether or not the host
+    synchronises between them.  (A multi-block torch reduction in the producer's backward once made the gradient of
+    loc depend on it: its semaphore memset raced with neighbouring nodes when a replay started on an idle GPU.)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    def run(sync_each):
+        t.manual_seed(0)
+        t.cuda.manual_seed_all(0)
+        prob = bench.build_problem("cuda")
+        opt = t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True)
+        step = alan.GraphedStep(prob, 30, opt, method="vi")
+        t.cuda.synchronize()
+        for _ in range(4):
+            step()
+            if sync_each:
+                t.cuda.synchronize()
+        t.cuda.synchronize()
+        return [p.detach().clone() for p in prob.parameters()]
+
+    for a, b in zip(run(True), run(False)):
+        assert t.equal(a, b)

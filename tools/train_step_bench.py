@@ -10,7 +10,7 @@ import alan_amd as alan
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 prob = bench.build_problem("cuda")
 opt = t.optim.Adam(prob.parameters(), lr=1e-3)
-for mode in ("rws", "vi"):
+for mode in (() if os.environ.get("SKIP_EAGER") else ("rws", "vi")):
     for strat_name, strat in (("no_checkpoint", alan.no_checkpoint), ("checkpoint", alan.checkpoint)):
         def step():
             opt.zero_grad()
@@ -34,7 +34,7 @@ for mode in ("rws", "vi"):
 
 # ---- the same iteration as one HIP-graph replay
 from alan_amd.training import GraphedStep
-for mode in ("rws", "vi"):
+for mode in (os.environ.get("GRAPH_MODES", "rws,vi").split(",")):
     prob = bench.build_problem("cuda")
     # as examples/basic_runner.py:76-79 of the reference: RWS updates Q with maximize=True on (-elbo)
     opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, maximize=True) if mode == "rws"
