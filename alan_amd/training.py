@@ -37,9 +37,8 @@ class GraphedStep:
         self.graph = t.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         # Capture on the SAME stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it
-        # was first used on, and autograd runs it there -- on a different capture stream that puts the gradient
-        # accumulation on a parallel branch of the graph (PyTorch warns "AccumulateGrad node's stream does not
-        # match"), and replays that start on an idle GPU then raced with the optimizer update.
+        # was first used on and autograd runs it there; a different capture stream would put the gradient
+        # accumulation on a parallel branch of the graph (PyTorch warns "AccumulateGrad node's stream does not match").
         with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.elbo = self._iteration()
 
