@@ -35,14 +35,15 @@ struct RowsDesc {
     float add_const;
     float *partial;         // per-chunk partials [n_chunks, NO] (n_chunks > 1) ...
     // ---- line 1
-    float *out;             // ... or the final output
-    float *lse;             // optional per-row log-sum-exp values
+    void *out;              // ... or the final output (fp32, or fp64 when a small factor is fp64: see plan_rows)
+    void *lse;              // optional per-row log-sum-exp values (same dtype as out)
     int64_t l_ps;
-    const float *sh_p[2];   // first two "shared" secondary factors: constant over the window (no inner keep dims)
+    const void *sh_p[2];    // first two "shared" secondary factors: constant over the window (no inner keep dims)
     int64_t sh_ps[2];       //   stride along the plate dim
     int32_t sh_rs[2];       //   stride along the row
+    int32_t f64_mask;       // bit i: shared factor i is fp64; bit 30: out / lse are fp64
     // ---- the rest
-    const float *shx_p[MAXF];   // further shared factors (rare)
+    const void *shx_p[MAXF];    // further shared factors (rare)
     int64_t shx_ps[MAXF];
     int32_t shx_rs[MAXF];
     FastDiv kdiv[MAXD];     // inner keep dims
@@ -162,11 +163,12 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
     auto shared_fetch = [&](uint32_t p) {
         gn0 = gn1 = gn_rest = 0.f;
         if (d.nshared > 0 && t < L) {
-            gn0 = d.sh_p[0][(int64_t)p * d.sh_ps[0] + (int64_t)t * d.sh_rs[0]];
-            if (d.nshared > 1) gn1 = d.sh_p[1][(int64_t)p * d.sh_ps[1] + (int64_t)t * d.sh_rs[1]];
+            gn0 = load_as<float>(d.sh_p[0], d.f64_mask & 1, (int64_t)p * d.sh_ps[0] + (int64_t)t * d.sh_rs[0]);
+            if (d.nshared > 1)
+                gn1 = load_as<float>(d.sh_p[1], (d.f64_mask >> 1) & 1, (int64_t)p * d.sh_ps[1] + (int64_t)t * d.sh_rs[1]);
 #pragma unroll 1
             for (int f = 2; f < d.nshared; ++f)
-                gn_rest += d.shx_p[f][(int64_t)p * d.shx_ps[f] + (int64_t)t * d.shx_rs[f]];
+                gn_rest += load_as<float>(d.shx_p[f], (d.f64_mask >> f) & 1, (int64_t)p * d.shx_ps[f] + (int64_t)t * d.shx_rs[f]);
         }
     };
 
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
             val = s;
         }
         if (has_row && gl == 0) {
-            if (d.lse) d.lse[row_offset(d.lks) + (int64_t)p * d.l_ps] = val;
+            if (d.lse) store_as<float>(d.lse, (d.f64_mask >> 30) & 1, row_offset(d.lks) + (int64_t)p * d.l_ps, val);
             acc += val;
         }
         __syncthreads();
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const Ro
         if (d.partial)
             d.partial[(int64_t)blockIdx.y * d.NO + o0 + r] = acc;
         else
-            d.out[row_offset(d.oks)] = acc + d.add_const;
+            store_as<float>(d.out, (d.f64_mask >> 30) & 1, row_offset(d.oks), acc + d.add_const);
     }
 }
 
@@ -327,14 +329,25 @@ static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
 
 RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     RowsPlan rp;
-    if (compute_dtype != ALAN_F32 || (mode != ALAN_MODE_LSE && mode != ALAN_MODE_SUM)) return rp;
+    if (mode != ALAN_MODE_LSE && mode != ALAN_MODE_SUM) return rp;
+    (void)compute_dtype;   // the kernel computes in fp32 = the dominant factor's precision (see below)
     if (c.nr != 1 || !c.red_contig) return rp;
     const int64_t L = c.rsize[0];
     if (L < 8 || L > 256) return rp;
-    for (int f = 0; f < c.nf; ++f)
-        if (c.f[f].dtype != ALAN_F32) return rp;
-    if (c.o.dtype != ALAN_F32 || (c.l.p && c.l.dtype != ALAN_F32)) return rp;
+    // dtypes: the dominant factor must be fp32.  Window-constant small factors may be fp64 (real data sets carry
+    // fp64 observations, so the likelihood factor of an fp32 model arrives in fp64): they are converted on load,
+    // the reduction runs in fp32 -- the precision of the factor that holds all but a per-mille of the values --
+    // and the result is stored in the promoted dtype the caller expects.  (The reference would run such a step in
+    // fp64 throughout: a difference of fp32 rounding, inside the 1e-4 ELBO tolerance.)
     const KTensor &dom = c.f[c.dominant];
+    if (dom.dtype != ALAN_F32) return rp;
+    const int k0p = (c.nk > 0 && c.kplate[0]) ? 1 : 0;
+    for (int f = 0; f < c.nf; ++f) {
+        if (f == c.dominant || c.f[f].dtype == ALAN_F32) continue;
+        for (int j = k0p; j < c.nk; ++j)
+            if (c.f[f].ks[j] != 0) return rp;     // an fp64 factor that varies over the window's rows: not here
+    }
+    if (c.l.p && c.l.dtype != c.o.dtype) return rp;
     if ((reinterpret_cast<uintptr_t>(dom.p) & 15) != 0) return rp;
     if (dom.scale != 1.f) return rp;
     int64_t run = L;  // the dominant factor must be dense with rows of L
@@ -406,11 +419,13 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
             if (c.f[f].rs[0] > INT32_MAX || c.f[f].rs[0] < INT32_MIN) return ALAN_ERR_UNSUPPORTED;
             const int i = d.nshared++;
             if (i < 2) {
-                d.sh_p[i] = (const float *)c.f[f].p;
+                d.sh_p[i] = c.f[f].p;
+                if (c.f[f].dtype == ALAN_F64) d.f64_mask |= 1 << i;
                 d.sh_ps[i] = ps;
                 d.sh_rs[i] = (int32_t)c.f[f].rs[0];
             } else {
-                d.shx_p[i] = (const float *)c.f[f].p;
+                d.shx_p[i] = c.f[f].p;
+                if (c.f[f].dtype == ALAN_F64) d.f64_mask |= 1 << i;
                 d.shx_ps[i] = ps;
                 d.shx_rs[i] = (int32_t)c.f[f].rs[0];
             }
@@ -424,10 +439,11 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
             d.gen_ps[d.ngen++] = ps;
         }
     }
-    d.out = (float *)const_cast<void *>(c.o.p);
+    d.out = const_cast<void *>(c.o.p);
+    if (c.o.dtype == ALAN_F64) d.f64_mask |= 1 << 30;
     for (int j = 0; j < d.nki; ++j) d.oks[j] = c.o.ks[k0 + j];
     d.partial = two_stage ? (float *)workspace : nullptr;
-    d.lse = (float *)const_cast<void *>(c.l.p);
+    d.lse = const_cast<void *>(c.l.p);
     for (int j = 0; j < d.nki; ++j) d.lks[j] = c.l.ks[k0 + j];
     d.l_ps = k0 ? c.l.ks[0] : 0;
     d.add_const = two_stage ? 0.f : (float)add_const;

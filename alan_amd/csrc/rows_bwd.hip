@@ -151,7 +151,7 @@ int plan_backward(const alan_backward_desc_t &b, BwdPlan &bp) {
     if (!red) return ALAN_ERR_UNSUPPORTED;
     if (d.weight.dtype != ALAN_F32 || d.lse_out.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
     for (int f = 0; f < d.n_factors; ++f) {
-        if (d.factor[f].scale != 1.f) return ALAN_ERR_UNSUPPORTED;
+        if (d.factor[f].scale != 1.f || d.factor[f].dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
         if (!b.grad[f].data) continue;
         if (b.grad[f].dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
         for (int i = 0; i < d.ndim; ++i)   // gradients are laid out like their factors

@@ -224,3 +224,35 @@ def test_one_pass_backward_declines_row_dependent_small_factors():
     gref = t.autograd.grad(ref[0].sum(), cpu)
     for a, b in zip(grads, gref):
         t.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("plate", [False, True])
+@pytest.mark.parametrize("L", [30, 100])
+def test_fp64_small_factor_keeps_the_streaming_path(L, plate):
+    """A real data set's fp64 observations make the likelihood factor fp64 while the big factor stays fp32 (movielens:
+    F[plate_1,K,K,K] fp32 + obs term [plate_1,K_z] fp64).  The result has the promoted dtype the reference would
+    return; the reduction itself runs in fp32, so it agrees with the fp64 oracle to fp32 rounding."""
+    g = t.Generator().manual_seed(L + plate)
+    M, A = 7, max(3, 20000 // (7 * L) + 1)
+    F = t.randn(M, A, L, generator=g) * 4
+    sh64 = t.randn(M, L, generator=g, dtype=t.float64)
+    sh32 = t.randn(L, generator=g)
+    facs = [(F, ("m", "a", "k")), (sh64, ("m", "k")), (sh32, ("k",))]
+    ref = orc.logsumexp_sum(("k",), *facs)
+    if plate:
+        ref = orc.plate_sum(ref, "m")
+    out, dims = E.reduce_factors([(x.to(DEV), d) for x, d in facs], reduce=("k",), plate=("m",) if plate else ())
+    assert out.dtype == t.float64 == ref[0].dtype
+    _cmp(out, dims, ref[0], ref[1], rtol=3e-5, atol=3e-4)
+    # gradients through the mixed-dtype step (per-factor route; the one-pass backward is fp32 only)
+    leaves = [x.clone().to(DEV).requires_grad_(True) for x, _ in facs]
+    o2, _ = E.reduce_factors([(x, d) for x, (_, d) in zip(leaves, facs)], reduce=("k",), plate=("m",) if plate else ())
+    grads = t.autograd.grad(o2.sum(), leaves)
+    cpu = [x.clone().requires_grad_(True) for x, _ in facs]
+    r2 = orc.logsumexp_sum(("k",), *[(x, d) for x, (_, d) in zip(cpu, facs)])
+    if plate:
+        r2 = orc.plate_sum(r2, "m")
+    gref = t.autograd.grad(r2[0].sum(), cpu)
+    for a, b in zip(grads, gref):
+        assert a.dtype == b.dtype
+        t.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-4)
