@@ -7,10 +7,12 @@
 //   * a workgroup owns a window of RB consecutive rows and walks a chunk of the plate; per plate
 //     index it copies the window's contiguous slab (RB*L floats) HBM -> LDS with 16-byte loads,
 //     fully coalesced whatever L is (rows of 30 floats are only 8-byte aligned);
-//   * thread t then owns row t in LDS: pass 1 adds the small factors (L1/L2-resident) and takes the
-//     exact row max, pass 2 sums exp(x - max): the reference's two-pass arithmetic, so -inf / NaN
-//     corner cases fall out identically;  row stride L words with 8-byte reads is conflict-free for
-//     L = 2 (mod 4) (K = 10, 30) and 2-way for K = 100; pathological strides use a rotated start;
+//   * thread t (or G = 2/4/8 lanes for long rows) then owns row t: it reads the row from LDS ONCE into <= 32
+//     registers per lane -- straight-line reads with compile-time offsets, slots past the row's end masked --
+//     adds the window-constant small factors (staged once per slab in LDS), takes the exact row max and sums
+//     exp(x - max) from the registers: the reference's two-pass arithmetic, so -inf / NaN corner cases fall
+//     out identically; row stride L words with 8-byte reads is conflict-free for L = 2 (mod 4) (K = 10, 30)
+//     and 2-way for K = 100; rows whose stride is 0 (mod 16 words) are read as rotated float4 quads;
 //   * the plate sum is accumulated in a register across the chunk; each workgroup writes one partial
 //     per row, and a tiny second stage adds the chunks (deterministic: no float atomics).
 #include <algorithm>
