@@ -179,6 +179,42 @@ class ExpPT(PT):
         return ExpPT(self.raw.detach(), self.dims)
 
 
+class LazyNormalPT(PT):
+    """The log-prob factor of a Normal whose value / loc / scale carry disjoint dims (the big [plate, K, K, K]
+    tensor of a hierarchical model), not computed yet: ``.x`` produces it (alan_reduce mode NORMAL) the first time
+    anyone asks, but the plate recursion can hand the ingredients to the fused plate-step kernel instead
+    (engine.normal_lse) and never materialise it."""
+    __slots__ = ("value", "loc", "scale", "log_scale", "_val")
+
+    def __init__(self, value, loc, scale, log_scale, dims):
+        self.value, self.loc, self.scale, self.log_scale = value, loc, scale, log_scale
+        self._val = None
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @property
+    def x(self):
+        if self._val is None:
+            from . import engine as E
+            self._val = E.normal_logprob((self.value.x, self.value.dims), (self.loc.x, self.loc.dims),
+                                         (self.scale.x, self.scale.dims), self.dims, log_scale=self.log_scale)
+        return self._val
+
+    @property
+    def materialised(self):
+        return self._val is not None
+
+    @property
+    def n_pos(self):
+        return 0
+
+    def size_of(self, dim_id):
+        return self.dims[self.ids.index(dim_id)].size
+
+    def detach(self):
+        return self
+
+
 def pt_order(pts, lead=(), last=()):
     """Ordered union of the dims of several PTs: ``lead`` dims first, ``last`` dims last, others between.
     Returns (dims, ids)."""

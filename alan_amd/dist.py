@@ -14,7 +14,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -210,6 +210,12 @@ class _FusedBernoulliLogProb(t.autograd.Function):
 FUSE_NORMAL = True
 """Route Normal / Bernoulli(logits) log-probs on the GPU to the fused HIP producer kernels."""
 
+FUSE_PLATE_STEP = False
+"""Gradient-free evaluations hand a Normal factor on disjoint dims to the fused plate-step kernel
+(alan_normal_lse: producer + log-sum-exp + plate sum, the factor never materialised) when the plate's contraction
+has that shape.  Off by default: the default path keeps the materialised factor and the HBM-bound reduce_Ks kernel
+that bench.py's roofline is measured on."""
+
 OUTER_BACKWARD = True
 """Use the two-GEMM backward of the Normal producer when value / loc / scale carry disjoint dims."""
 
@@ -293,7 +299,15 @@ class TorchDimDist:
             lazy = isinstance(scale, ExpPT) and not scale.materialised
             spec = (x.dims, loc.dims, scale.dims, out_dims, lazy, ab)
             sx = scale.raw if lazy else scale.x
-            if not (t.is_grad_enabled() and (x.x.requires_grad or loc.x.requires_grad or sx.requires_grad)):
+            nograd = not (t.is_grad_enabled() and (x.x.requires_grad or loc.x.requires_grad or sx.requires_grad))
+            vi, li, si = set(x.ids), set(loc.ids), set(scale.ids)
+            if FUSE_PLATE_STEP and nograd and ab == (1.0, 0.0) and not drop and li and si \
+                    and not (vi & li) and not (vi & si) and not (li & si):
+                # the big K-cross-product factor: leave it unevaluated -- the plate recursion may fuse it into the
+                # log-sum-exp + plate sum that consumes it (logpq._contract); anyone else reading .x gets it made
+                return LazyNormalPT(PT(x.x.detach(), x.dims), PT(loc.x.detach(), loc.dims),
+                                    PT(sx.detach(), scale.dims), lazy, out_dims)
+            if nograd:
                 from . import engine as E           # nothing to record: skip the autograd.Function round trip
                 return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.x.detach(), loc.dims), (sx.detach(), scale.dims),
                                            out_dims, log_scale=lazy, affine=ab), out_dims)

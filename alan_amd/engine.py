@@ -297,6 +297,47 @@ def normal_logprob_pq(value, p, q, out_dims, affine=(1.0, 0.0)):
     return _produce(N.MODE_NORMAL, (value, pl, ps, value, ql, qs), out_dims, affine, scales)
 
 
+def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
+    """out[l, s] = sum_plate LSE_K( log N(value[plate,K,:]; loc[l,:], scale[s,:]) + sum small[plate,K] ) in one
+    launch, the [plate, l, s, K] factor never materialised (alan_normal_lse).  value = (tensor, (two dims: the plate
+    and K, any order)); loc / scale = (tensor, (one dim,)); smalls = [(tensor, dims within {plate, K})].
+    Returns (out, (loc dim, scale dim)) or None when the library declines."""
+    (xv, dv), (xl, dl), (xs, ds) = value, loc, scale
+    tensors = [xv, xl, xs, *[x for x, _ in smalls]]
+    if not all(x.is_cuda and x.dtype == t.float32 for x in tensors) or len(smalls) > 4:
+        return None
+    if len(dv) != 2 or len(dl) != 1 or len(ds) != 1:
+        return None
+    nev = xv.ndim - 2
+    if nev == 0:
+        xv, xl, xs = xv.unsqueeze(-1), xl.unsqueeze(-1), xs.unsqueeze(-1)
+    elif nev > 1:
+        xv, xl, xs = xv.flatten(2), xl.flatten(1), xs.flatten(1)
+    if not (xv.shape[-1] == xl.shape[-1] == xs.shape[-1]):
+        return None                                   # broadcasting event shapes: not this path
+    ip = 0 if dv[0] is plate else 1
+    if dv[ip] is not plate or dv[1 - ip] is not K:
+        return None
+    d = N.NormalLseDesc()
+    d.value, d.v_sm, d.v_sk, d.v_se = xv.data_ptr(), xv.stride(ip), xv.stride(1 - ip), xv.stride(2)
+    d.loc, d.l_sl, d.l_se = xl.data_ptr(), xl.stride(0), xl.stride(1)
+    d.scale, d.s_ss, d.s_se = xs.data_ptr(), xs.stride(0), xs.stride(1)
+    d.log_scale, d.n_small = int(bool(log_scale)), len(smalls)
+    for i, (x, dims) in enumerate(smalls):
+        st = {id(dd): (x.stride(j) if x.shape[j] > 1 else 0) for j, dd in enumerate(dims)}
+        if any(id(dd) not in (id(plate), id(K)) for dd in dims):
+            return None
+        d.small[i], d.small_sm[i], d.small_sk[i] = x.data_ptr(), st.get(id(plate), 0), st.get(id(K), 0)
+    d.M, d.NK, d.NL, d.NS, d.E = xv.shape[ip], xv.shape[1 - ip], xl.shape[0], xs.shape[0], xv.shape[2]
+    out = t.empty(xl.shape[0], xs.shape[0], dtype=t.float32, device=xv.device)
+    d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
+    keep = (xv, xl, xs)                               # (the reshaped views stay alive until the launch is queued)
+    if not N.run_normal_lse(d, xv.device):
+        return None
+    del keep
+    return out, (dl[0], ds[0])
+
+
 def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):
     """log Bernoulli(value; logits=logits), summed like ``normal_logprob`` (alan_reduce mode BERNOULLI)."""
     return _produce(N.MODE_BERNOULLI, (value, logits), out_dims, affine)

@@ -19,7 +19,7 @@ import torch as t
 import torch.utils.checkpoint
 
 from . import engine as E
-from .dims import PT, ExpPT, pt_add, pt_align
+from .dims import PT, ExpPT, LazyNormalPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
 from .dist import TorchDimDist
@@ -76,7 +76,34 @@ def _logPQ_plate_checkpointed(**kwargs):
     return PT(x, dims[0])
 
 
+def _fused_plate_step(lps, Ks, plate):
+    """The whole plate step as ONE launch (engine.normal_lse) when it has the hierarchical-Normal shape:
+    exactly one unevaluated Normal factor N(value[plate, K]; loc[l], scale[s]), every other factor on dims within
+    {plate, K}, log-sum-exp over K, sum over the plate.  None otherwise (the caller contracts as usual)."""
+    lazy = [lp for lp in lps if isinstance(lp, LazyNormalPT) and not lp.materialised]
+    if len(lazy) != 1 or len(plate) != 1 or len(Ks) != 1:
+        return None
+    z, pl, K = lazy[0], plate[0], Ks[0]
+    if set(z.value.ids) != {id(pl), id(K)} or len(z.loc.dims) != 1 or len(z.scale.dims) != 1:
+        return None
+    smalls = []
+    for lp in lps:
+        if lp is z:
+            continue
+        if lp.n_pos or not set(lp.ids) <= {id(pl), id(K)}:
+            return None
+        if t.is_grad_enabled() and lp.x.requires_grad:
+            return None                 # (elbo_rws: log Q carries the gradient) the fused kernel has no backward
+        smalls.append((lp.x, lp.dims))
+    res = E.normal_lse((z.value.x, z.value.dims), (z.loc.x, z.loc.dims), (z.scale.x, z.scale.dims), smalls, pl, K,
+                       log_scale=z.log_scale)
+    return None if res is None else PT(*res)
+
+
 def _contract(lps, Ks, plate=()):
+    fused = _fused_plate_step(lps, Ks, plate)
+    if fused is not None:
+        return fused
     for lp in lps:
         # "There shouldn't be any non-torchdim dimensions" (reduce_Ks.py:13-14)
         assert lp.n_pos == 0, "log-prob factors must have no positional dims"

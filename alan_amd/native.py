@@ -60,6 +60,16 @@ class BackwardDesc(C.Structure):
     _fields_ = [("fwd", ReduceDesc), ("grad", Tensor * MAX_FACTORS)]
 
 
+class NormalLseDesc(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("v_sm", C.c_int64), ("v_sk", C.c_int64), ("v_se", C.c_int64),
+                ("loc", C.c_void_p), ("l_sl", C.c_int64), ("l_se", C.c_int64),
+                ("scale", C.c_void_p), ("s_ss", C.c_int64), ("s_se", C.c_int64),
+                ("log_scale", C.c_int32), ("n_small", C.c_int32),
+                ("small", C.c_void_p * 4), ("small_sm", C.c_int64 * 4), ("small_sk", C.c_int64 * 4),
+                ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
+                ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64), ("add_const", C.c_double)]
+
+
 _lib = None
 
 
@@ -81,6 +91,10 @@ def lib():
         L.alan_reduce_backward.argtypes = [C.POINTER(BackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_reduce_backward_workspace_bytes.restype = C.c_size_t
         L.alan_reduce_backward_workspace_bytes.argtypes = [C.POINTER(BackwardDesc)]
+        L.alan_normal_lse.restype = C.c_int
+        L.alan_normal_lse.argtypes = [C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_normal_lse_workspace_bytes.restype = C.c_size_t
+        L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_chain_workspace_bytes.restype = C.c_size_t
         L.alan_chain_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp.restype = C.c_int
@@ -99,7 +113,8 @@ def lib():
 
 
 EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_backward",
-           "alan_reduce_backward_workspace_bytes", "alan_chain_workspace_bytes",
+           "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
+           "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_abi_version", "alan_build_target")
 
@@ -164,6 +179,20 @@ def run_reduce_backward(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_reduce_backward")
+    return True
+
+
+def run_normal_lse(desc, device):
+    """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
+    L = lib()
+    nbytes = L.alan_normal_lse_workspace_bytes(C.byref(desc))
+    if nbytes == 0:
+        return False
+    ws = t.empty(nbytes, dtype=t.uint8, device=device)
+    rc = L.alan_normal_lse(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc, "alan_normal_lse")
     return True
 
 

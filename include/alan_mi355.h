@@ -123,6 +123,26 @@ typedef struct {
 size_t alan_reduce_backward_workspace_bytes(const alan_backward_desc_t *desc);
 int alan_reduce_backward(const alan_backward_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The hierarchical-Normal plate step with the factor producer fused in (never materialises the [plate, K, K, K]
+ * log-prob factor): replaces TorchDimDist.py:127-162 + utils.py:147-152 (the Normal log-prob over the K cross
+ * product), reduce_Ks.py:249-251 + utils.py:218-220 (log-sum-exp over the child K) and logpq.py:149 (plate sum) for
+ *     out[l, s] = sum_m LSE_k( log N(value[m,k,:]; loc[l,:], scale[s,:]) + sum_f small_f[m,k] ) + add_const
+ * All tensors fp32; strides in elements; small factors may have stride 0 along m or k.  scale holds log(scale) when
+ * log_scale != 0.  ALAN_ERR_UNSUPPORTED (event length > 32, ...) -> produce the factor with ALAN_MODE_NORMAL and call
+ * alan_reduce instead. */
+typedef struct {
+    const void *value;  int64_t v_sm, v_sk, v_se;      /* [M, NK, E] */
+    const void *loc;    int64_t l_sl, l_se;            /* [NL, E]    */
+    const void *scale;  int64_t s_ss, s_se;            /* [NS, E]    */
+    int32_t log_scale, n_small;                        /* n_small <= 4 */
+    const void *small[4]; int64_t small_sm[4], small_sk[4];   /* [M, NK] each */
+    int64_t M, NK, NL, NS, E;
+    void *out;          int64_t o_sl, o_ss;            /* [NL, NS]   */
+    double add_const;
+} alan_normal_lse_desc_t;
+size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
+int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Timeseries plate (utils.py:478-510, logpq.py:132-143).
  *   ms         [T, K, K] log transition factors, element strides (sT, sRow, sCol)
  *   out_chain  optional [K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)
