@@ -146,6 +146,10 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
             break;
         }
     p.nsb = (int)((a.NS + 31) / 32);
+    // one lane per scale row: beyond 32 rows every (m, l) pair is walked by several half-waves, each rebuilding the
+    // d2 tile and re-reading it from LDS -- measured at K=100: 110 us per 38-user chunk against 49 + 32 us for the
+    // producer + rows kernels.  Until the kernel blocks two scale rows per lane, decline.
+    if (p.nsb > 1) return ALAN_ERR_UNSUPPORTED;
     const int64_t gx = (a.NL * p.nsb + NL_UNITS - 1) / NL_UNITS;
     int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, 2048 / std::max<int64_t>(1, gx)));
     p.m_chunk = (int)((a.M + nch - 1) / nch);

@@ -340,6 +340,17 @@ def main():
         dt_se = (time.perf_counter() - t0) / 20
         out["sample_plus_elbo"] = {"ms_per_iter": dt_se * 1e3, "iters_per_s": 1 / dt_se,
                                    "launch": "eager (a fresh sample every iteration)"}
+        # the optional fused plate step (dist.FUSE_PLATE_STEP: producer + log-sum-exp + plate sum in one launch, the
+        # factor never materialised) -- off by default, so `value` and `roofline` above describe the default path
+        from alan_amd import dist as _dist
+        _dist.FUSE_PLATE_STEP = True
+        try:
+            sf = draw(prob, K)
+            d_f, v_f = timed_evals(sf, strat, args.steps, args.warmup, world, graph=use_graph)
+            out["fused_plate_step"] = {"evals_per_s": args.steps / d_f, "us_per_eval": d_f / args.steps * 1e6,
+                                       "elbo": v_f, "default": False}
+        finally:
+            _dist.FUSE_PLATE_STEP = False
         out["cpu_baseline"] = cpu_baseline(K, sample, elbo)
         sweep = {}
         for k2 in (3, 10, 100):
