@@ -31,7 +31,8 @@ struct NLDesc {
 
 constexpr int NL_UNITS = 8;   // half-waves per workgroup
 
-template <int EMAX>
+// SPL = scale rows per lane (lane's rows: s0, s0 + 32, ...): every broadcast read of the d2 tile feeds 4*SPL FMAs.
+template <int EMAX, int SPL>
 __global__ __launch_bounds__(256) void normal_lse_kernel(const NLDesc d) {
     extern __shared__ __align__(16) float lds[];
     constexpr int EP = EMAX;
@@ -47,9 +48,8 @@ __global__ __launch_bounds__(256) void normal_lse_kernel(const NLDesc d) {
     const int q = blockIdx.x * NL_UNITS + u;          // (l, s-block) pair of this half-wave
     const int l = q / d.nsb, sb = q - l * d.nsb;
     const bool unit_ok = l < d.NL;
-    const int s = sb * 32 + lane;
-    const bool s_ok = unit_ok && s < NS;
-    const int sc = min(s, NS - 1), lc = min(l, d.NL - 1);
+    const int s0 = sb * (32 * SPL) + lane;           // this lane's scale rows: s0 + 32 j
+    const int lc = min(l, d.NL - 1);
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
 
     // ---- tables
@@ -74,13 +74,20 @@ __global__ __launch_bounds__(256) void normal_lse_kernel(const NLDesc d) {
     if (EP > 32 && lane + 32 < EP)
         mus[u * EP + lane + 32] = (lane + 32 < E) ? d.loc[(int64_t)lc * d.l_sl + (int64_t)(lane + 32) * d.l_se] : 0.f;
     __syncthreads();
-    float4 w4[EMAX / 4];
+    float4 w4[SPL][EMAX / 4];
+    float lgs[SPL];
 #pragma unroll
-    for (int qd = 0; qd < EMAX / 4; ++qd) w4[qd] = reinterpret_cast<const float4 *>(wt + (size_t)sc * EP)[qd];
-    const float lgs = lgt[sc];
+    for (int j = 0; j < SPL; ++j) {
+        const int sc = min(s0 + 32 * j, NS - 1);
+#pragma unroll
+        for (int qd = 0; qd < EMAX / 4; ++qd) w4[j][qd] = reinterpret_cast<const float4 *>(wt + (size_t)sc * EP)[qd];
+        lgs[j] = lgt[sc];
+    }
 
     float *dd = dds + (size_t)u * NK * EP;
-    float accm = 0.f;
+    float accm[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) accm[j] = 0.f;
     for (int m = m0; m < m1; ++m) {
         __syncthreads();                              // everyone is done with zs / hs / dds of the previous m
         for (int i = tid; i < NK * EP; i += 256) {
@@ -99,25 +106,36 @@ __global__ __launch_bounds__(256) void normal_lse_kernel(const NLDesc d) {
             dd[i] = df * df;
         }
         __syncthreads();
-        float mx = -__builtin_huge_valf(), sm = 0.f;
+        float mx[SPL], sm[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) mx[j] = -__builtin_huge_valf(), sm[j] = 0.f;
         for (int k = 0; k < NK; ++k) {
             const float4 *d4 = reinterpret_cast<const float4 *>(dd + (size_t)k * EP);
             float4 dv[EMAX / 4];
 #pragma unroll
             for (int qd = 0; qd < EMAX / 4; ++qd) dv[qd] = d4[qd];
-            float acc = 0.f;
+            const float hk = hs[k];
 #pragma unroll
-            for (int qd = 0; qd < EMAX / 4; ++qd) {
-                acc = fmaf(dv[qd].x, w4[qd].x, acc);
-                acc = fmaf(dv[qd].y, w4[qd].y, acc);
-                acc = fmaf(dv[qd].z, w4[qd].z, acc);
-                acc = fmaf(dv[qd].w, w4[qd].w, acc);
+            for (int j = 0; j < SPL; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int qd = 0; qd < EMAX / 4; ++qd) {
+                    acc = fmaf(dv[qd].x, w4[j][qd].x, acc);
+                    acc = fmaf(dv[qd].y, w4[j][qd].y, acc);
+                    acc = fmaf(dv[qd].z, w4[j][qd].z, acc);
+                    acc = fmaf(dv[qd].w, w4[j][qd].w, acc);
+                }
+                lse_push(mx[j], sm[j], (-acc - lgs[j]) + hk);     // (packed v_pk_fma_f32 over row pairs was slower)
             }
-            lse_push(mx, sm, (-acc - lgs) + hs[k]);
         }
-        accm += lse_finish(mx, sm);
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) accm[j] += lse_finish(mx[j], sm[j]);
     }
-    if (s_ok) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int s = s0 + 32 * j;
+        if (unit_ok && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[j];
+    }
 }
 
 }  // namespace alan
@@ -127,7 +145,7 @@ using namespace alan;
 namespace {
 
 struct NLPlan {
-    int em = 0, nsb = 1, m_chunk = 1, n_chunks = 1;
+    int em = 0, nsb = 1, spl = 1, m_chunk = 1, n_chunks = 1;
     size_t lds = 0, part_bytes = 0;
     dim3 grid;
 };
@@ -145,11 +163,12 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
             p.em = em;
             break;
         }
-    p.nsb = (int)((a.NS + 31) / 32);
-    // one lane per scale row: beyond 32 rows every (m, l) pair is walked by several half-waves, each rebuilding the
-    // d2 tile and re-reading it from LDS -- measured at K=100: 110 us per 38-user chunk against 49 + 32 us for the
-    // producer + rows kernels.  Until the kernel blocks two scale rows per lane, decline.
-    if (p.nsb > 1) return ALAN_ERR_UNSUPPORTED;
+    // scale rows per lane: with one row per lane and > 32 rows every (m, l) pair would be walked by several
+    // half-waves, each rebuilding and re-reading the d2 tile (measured at K=100: 110 us per 38-user chunk against
+    // 49 + 32 us for the producer + rows kernels) -- block 2 or 4 rows per lane instead (65 us)
+    p.spl = a.NS <= 32 ? 1 : a.NS <= 64 ? 2 : 4;
+    if (a.NS > 128) return ALAN_ERR_UNSUPPORTED;
+    p.nsb = 1;
     const int64_t gx = (a.NL * p.nsb + NL_UNITS - 1) / NL_UNITS;
     int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, 2048 / std::max<int64_t>(1, gx)));
     p.m_chunk = (int)((a.M + nch - 1) / nch);
@@ -203,16 +222,24 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         hipLaunchKernelGGL(kern, p.grid, dim3(256), p.lds, stream, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
+#define ALAN_NL_CASE(EM)                                                    \
+    case EM:                                                                \
+        rc = p.spl == 1 ? launch(normal_lse_kernel<EM, 1>)                  \
+             : p.spl == 2 ? launch(normal_lse_kernel<EM, 2>)                \
+                          : launch(normal_lse_kernel<EM, 4>);               \
+        break
     switch (p.em) {
-        case 4: rc = launch(normal_lse_kernel<4>); break;
-        case 8: rc = launch(normal_lse_kernel<8>); break;
-        case 12: rc = launch(normal_lse_kernel<12>); break;
-        case 16: rc = launch(normal_lse_kernel<16>); break;
-        case 20: rc = launch(normal_lse_kernel<20>); break;
-        case 24: rc = launch(normal_lse_kernel<24>); break;
-        case 28: rc = launch(normal_lse_kernel<28>); break;
-        default: rc = launch(normal_lse_kernel<32>); break;
+        ALAN_NL_CASE(4);
+        ALAN_NL_CASE(8);
+        ALAN_NL_CASE(12);
+        ALAN_NL_CASE(16);
+        ALAN_NL_CASE(20);
+        ALAN_NL_CASE(24);
+        ALAN_NL_CASE(28);
+        default: rc = p.spl == 1 ? launch(normal_lse_kernel<32, 1>)
+                      : p.spl == 2 ? launch(normal_lse_kernel<32, 2>) : launch(normal_lse_kernel<32, 4>);
     }
+#undef ALAN_NL_CASE
     if (rc != ALAN_OK) return rc;
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
