@@ -1,12 +1,15 @@
 // alan_chain_logmmexp: the timeseries plate.  Replaces utils.py:478-510 (chain_reduce / logmmexp /
 // chain_logmmexp) and the trailing t.logsumexp(lp, -1) of logpq.py:139.
 //
-// The reference reduces [T,K,K] by a pairwise tree (ceil(log2 T) rounds, ~9 torch ops per round).
-// Log-matrix multiplication is associative, so here each workgroup multiplies a contiguous SEGMENT
-// of matrices left to right entirely in LDS (one logmmexp per step, same normalisation and
-// eps-in-log as utils.py:503-507), and a few levels of segments reduce T -> 1.  Re-bracketing only
-// changes rounding.  At T=1000, K=30 the whole input is 3.6 MB: this path is latency-bound, so the
-// design goal is few launches (3 levels), not bandwidth.
+// The reference reduces [T,K,K] by a pairwise tree (ceil(log2 T) rounds, ~9 torch ops per round; an odd leftover
+// matrix is carried to the end of the next round, utils.py:488-495).  The same tree runs here, one launch per
+// round, one workgroup per pair, each logmmexp entirely in LDS with the normalisation and eps-in-log of
+// utils.py:503-507.  Log-matrix multiplication is associative, so longer left-to-right segments per workgroup
+// would need fewer launches (T=1000, K=30: 113 us per ELBO against 127 us) -- but only up to the +eps: on sharply
+// peaked transition matrices most entries sit on the eps floor and the result then depends on the bracketing, and
+// the reference's gradient is the gradient THROUGH that floor.  Keeping the reference's bracketing keeps both
+// (tests/golden/chain_peaked.pt).  Every round's output stays in the workspace (the "tree"): the backward walks it
+// top-down, one launch per round.  At T=1000, K=30 the whole input is 3.6 MB: this path is latency-bound.
 #include <algorithm>
 #include <cstdlib>
 
@@ -38,9 +41,14 @@ __device__ __forceinline__ void lds_max(T *addr, T v) {   // ds_max_f32 / ds_max
 // copies): (4, 1) for K <= 32, (16, 4) for K <= 64, (40, 10) for K <= 100.
 template <typename T, int ME, int NT>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
-    const T *ms, int64_t sT, int64_t sRow, int64_t sCol, int T_total, int seg_len, int K,
+    const T *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int T_total, int seg_len, int K,
     T *out, T *vec_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // blockIdx.y = which chain of the batch (timeseries plates nested under other plate / K dims: the reference's
+    // lp.order(T, K_init, K_curr) leaves those as torchdim batch dims of the matmuls, logpq.py:133-135)
+    ms += (int64_t)blockIdx.y * sB;
+    if (out) out += (int64_t)blockIdx.y * gridDim.x * K * K;
+    if (vec_out) vec_out += (int64_t)blockIdx.y * K;
     const int KP = (K + 3) & ~3, NJG = KP >> 2;
     const int PS = KP + 4;                       // row stride of P: rows on different banks (C rows are read by whole lanes-groups at once)
     T *P = reinterpret_cast<T *>(smem_raw);     // [K][PS]   log-space between steps, exp-space inside one
@@ -181,27 +189,33 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
     }
 }
 
-// Segment length: levels cost a launch each (a ~ 5.7 us measured), every level runs its longest segment's
-// (len - 1) dependent steps (b ~ 2.4 us at K <= 32, growing with the K^2 work of a step).  T = 1000, K = 30:
-// 4 (five levels of 3 steps) rather than 10 (three levels of 9).
-static int pick_segment(int64_t T, int64_t K) {
-    if (const char *e = getenv("ALAN_CHAIN_SEG")) return std::max(2, std::min(64, atoi(e)));   // tuning knob
-    const double kk = std::max(1.0, (double)K / 32.0);
-    const double a = 5.7, b = 2.44 * kk * kk;
-    int best = 2;
-    double best_cost = 1e300;
-    for (int seg = 2; seg <= 32; ++seg) {
-        double cost = 0;
-        for (int64_t n = T; n > 1; n = (n + seg - 1) / seg) cost += a + (double)(std::min<int64_t>(seg, n) - 1) * b;
-        if (cost < best_cost) best_cost = cost, best = seg;
-    }
-    return best;
+// ------------------------------------------------------------------------------------------------
+// The tree in memory: round r = 1..L holds n_r = ceil(n_{r-1} / 2) matrices per chain ([B][n_r][K][K], each round
+// 256-byte aligned), n_0 = T, n_L = 1 (the root = chain_logmmexp(ms)); T = 1 has one round holding a copy of ms[0].
+struct TreeLayout {
+    int L = 0;
+    int64_t n[34];          // n[0] = T
+    size_t off[34];         // byte offset of round r (off[0] unused)
+    size_t bytes = 0;
+};
+
+static TreeLayout tree_layout(int64_t B, int64_t T, int64_t K, size_t elt) {
+    TreeLayout t;
+    t.n[0] = T;
+    int64_t n = T;
+    do {
+        n = (n + 1) / 2;
+        ++t.L;
+        t.n[t.L] = n;
+        t.off[t.L] = t.bytes;
+        t.bytes += ((size_t)(B * n * K * K) * elt + 255) & ~(size_t)255;
+    } while (n > 1);
+    return t;
 }
 
 template <typename T>
-static int chain_run(const void *ms_, int64_t Tn, int64_t K, int64_t sT, int64_t sRow, int64_t sCol,
-                     void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream) {
-    const size_t mat = (size_t)K * K * sizeof(T);
+static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
+                     int64_t sCol, void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream) {
     const size_t KP = (size_t)((K + 3) & ~3);
     const size_t smem = (KP * (KP + 4) + KP * KP + 4 * KP) * sizeof(T);
     if (K > 100 || smem > 160 * 1024) return ALAN_ERR_UNSUPPORTED;
@@ -210,199 +224,216 @@ static int chain_run(const void *ms_, int64_t Tn, int64_t K, int64_t sT, int64_t
     if (smem > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return ALAN_ERR_LAUNCH;
-    const int seg = pick_segment(Tn, K);
+    const TreeLayout tl = tree_layout(B, Tn, K, sizeof(T));
+    if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
     const T *src = (const T *)ms_;
-    int64_t n = Tn;
-    T *bufs[2] = {(T *)ws, nullptr};
-    // ping-pong level buffers inside the workspace
-    const int64_t n1 = (Tn + seg - 1) / seg;
-    bufs[1] = (T *)((char *)ws + ((n1 * mat + 255) & ~(size_t)255));
-    int lvl = 0;
-    int64_t cT = sT, cR = sRow, cC = sCol;
-    while (true) {
-        const int64_t nseg = (n + seg - 1) / seg;
-        const bool last = nseg == 1;
-        T *dst = last ? (T *)out_chain : bufs[lvl & 1];
-        if (!last) {
-            const size_t need = (size_t)((char *)dst - (char *)ws) + (size_t)nseg * mat;
-            if (!ws || need > ws_bytes) return ALAN_ERR_WORKSPACE;
-        }
-        hipLaunchKernelGGL(kern, dim3((uint32_t)nseg), dim3(CHAIN_THREADS), smem, stream, src, cT, cR, cC,
-                           (int)n, seg, (int)K, dst, last ? (T *)out_vec : (T *)nullptr);
+    int64_t cB = sB, cT = sT, cR = sRow, cC = sCol;
+    for (int r = 1; r <= tl.L; ++r) {
+        T *dst = (T *)((char *)ws + tl.off[r]);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
+                           cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr);
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
-        if (last) break;
         src = dst;
+        cB = tl.n[r] * K * K;
         cT = K * K;
         cR = K;
         cC = 1;
-        n = nseg;
-        ++lvl;
     }
+    if (out_chain)
+        if (hipMemcpyAsync(out_chain, (char *)ws + tl.off[tl.L], (size_t)(B * K * K) * sizeof(T),
+                           hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            return ALAN_ERR_LAUNCH;
     return ALAN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of  out[i] = logsumexp_j (M_1 (x) ... (x) M_T)[i, j]  with respect to every M_t:
-//   d out_i / d M_t[a,b] = exp(alpha_{t-1}[i,a] + M_t[a,b] + beta_t[b] - out_i)       (a pairwise marginal)
-//   grad M_t[a,b] = sum_i g_i * (that)  = exp(la_{t-1}[a] + M_t[a,b] + beta_t[b]),
-//   la_0[a] = log|g_a| - out_a,  la_t[b] = LSE_a(la_{t-1}[a] + M_t[a,b]),  beta_T = 0,
-//   beta_{t-1}[a] = LSE_b(M_t[a,b] + beta_t[b]).
-// Two O(T K^2) scans (forward for la, backward for beta + the gradient), one workgroup; positive and
-// negative parts of g are scanned separately (log domain) and subtracted.  Latency-bound by design:
-// this is the gradient of a 3.6 MB / 54 MFLOP problem.
+// Backward, one round of the tree per launch, one workgroup per node of that round.  For a pair
+//   R = log(Pe @ Ce + eps) + pm + cm,   Pe = exp(P - pm), Ce = exp(C - cm),  pm = rowmax(P), cm = colmax(C)
+// and an upstream gradient G of R, autograd through utils.py:503-507 gives, with G' = G / (Pe @ Ce + eps):
+//   dP = Pe * (G' @ Ce^T)  +  [P == pm] * eps * rowsum(G') / ties      (the second term is the path through amax,
+//   dC = Ce * (Pe^T @ G')  +  [C == cm] * eps * colsum(G') / ties       which only matters on the eps floor)
+// A leftover node passes its gradient through.  At the root G comes from the caller:
+//   G = grad_chain  +  grad_vec[i] * exp(R[i,j] - vec[i])               (t.logsumexp(., -1) of logpq.py:139)
 template <typename T>
-__global__ __launch_bounds__(CHAIN_THREADS) void chain_backward_kernel(
-    const T *ms, int64_t sT, int64_t sRow, int64_t sCol, int Tn, int K, const T *out_vec,
-    const T *grad_out, T *grad_ms, T *la_ws /* [Tn][K] */, double *off_ws /* [Tn] */) {
+__global__ __launch_bounds__(CHAIN_THREADS) void chain_pair_backward_kernel(
+    const T *src, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_src, int K,
+    const T *G,                                           // [B][gridDim.x][K][K], or nullptr at the root
+    const T *root, int64_t rB, int64_t rRow, int64_t rCol, const T *vec, const T *grad_vec, const T *grad_chain,
+    T *dsrc) {                                            // [B][n_src][K][K]
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *M = reinterpret_cast<T *>(smem_raw);   // [K][K] current matrix
-    T *vec = M + K * K;                        // [K]  la_{t-1} or beta_t, max-normalised
-    T *nxt = vec + K;                          // [K]
-    const int tid = threadIdx.x;
+    const int KS = K | 1;                                 // odd row stride: column walks are conflict-free
+    T *Pe = reinterpret_cast<T *>(smem_raw);
+    T *Ce = Pe + (size_t)K * KS;
+    T *Gp = Ce + (size_t)K * KS;
+    T *pm = Gp + (size_t)K * KS, *cm = pm + K, *pw = cm + K, *cw = pw + K;
+    const int tid = threadIdx.x, KK = K * K;
+    const int64_t b = blockIdx.y, node = blockIdx.x;
+    const int t0 = 2 * (int)node, t1 = t0 + 1;
     const T NINF = Num<T>::ninf();
 
-    // Both scans keep their vectors max-normalised and carry the (large, mutually cancelling) offsets
-    // as double scalars: la ~ +|log evidence| and beta ~ -|log evidence| would otherwise lose
-    // ~1e-4 of relative precision in fp32 at T = 1000.
-    auto renorm = [&](double &off) {   // vec <- nxt - max(nxt); off += max   (every thread, uniformly)
-        T mx = NINF;
-        for (int a = 0; a < K; ++a) mx = fmax(mx, nxt[a]);
-        const T sub = (mx == NINF) ? T(0) : mx;
-        off += (double)sub;
-        __syncthreads();
-        for (int a = tid; a < K; a += CHAIN_THREADS) vec[a] = nxt[a] - sub;
-        __syncthreads();
+    auto upstream = [&](int i, int j) -> T {
+        if (G) return G[((b * gridDim.x + node) * K + i) * K + j];
+        T g = grad_chain ? grad_chain[(b * K + i) * K + j] : T(0);
+        if (grad_vec) {
+            const T v = vec[b * K + i];
+            if (v != NINF) g += grad_vec[b * K + i] * Num<T>::exp_acc(root[b * rB + i * rRow + j * rCol] - v);
+        }
+        return g;
     };
-
-    for (int sign = 0; sign < 2; ++sign) {
-        // ---- forward scan: la_t
-        for (int a = tid; a < K; a += CHAIN_THREADS) {
-            const T g = sign == 0 ? grad_out[a] : -grad_out[a];
-            nxt[a] = g > T(0) ? Num<T>::log(g) - out_vec[a] : NINF;
+    T *dP = dsrc + (b * n_src + t0) * (int64_t)KK;
+    if (t1 >= n_src) {                                    // leftover of this round (utils.py:488-495)
+        for (int e = tid; e < KK; e += CHAIN_THREADS) dP[e] = upstream(e / K, e % K);
+        return;
+    }
+    T *dC = dP + KK;
+    const T *Pg = src + b * sB + (int64_t)t0 * sT, *Cg = src + b * sB + (int64_t)t1 * sT;
+    for (int e = tid; e < KK; e += CHAIN_THREADS) {
+        const int i = e / K, j = e - i * K;
+        Pe[i * KS + j] = Pg[i * sRow + j * sCol];
+        Ce[i * KS + j] = Cg[i * sRow + j * sCol];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * K; i += CHAIN_THREADS) {
+        T mx = NINF;
+        if (i < K) {
+            for (int j = 0; j < K; ++j) mx = fmax(mx, Pe[i * KS + j]);
+            pm[i] = mx;
+        } else {
+            for (int k = 0; k < K; ++k) mx = fmax(mx, Ce[k * KS + (i - K)]);
+            cm[i - K] = mx;
         }
-        __syncthreads();
-        bool any = false;
-        for (int a = 0; a < K; ++a) any = any || (nxt[a] != NINF);
-        if (!any) {   // no weight of this sign (uniform decision)
-            if (sign == 0)
-                for (int64_t e = tid; e < (int64_t)Tn * K * K; e += CHAIN_THREADS) grad_ms[e] = T(0);
-            __syncthreads();
-            continue;
+    }
+    __syncthreads();
+    for (int e = tid; e < KK; e += CHAIN_THREADS) {
+        const int i = e / K, j = e - i * K;
+        Pe[i * KS + j] = Num<T>::exp_acc(Pe[i * KS + j] - pm[i]);
+        Ce[i * KS + j] = Num<T>::exp_acc(Ce[i * KS + j] - cm[j]);
+    }
+    __syncthreads();
+    for (int e = tid; e < KK; e += CHAIN_THREADS) {      // G' = G / (Pe @ Ce + eps)
+        const int i = e / K, j = e - i * K;
+        T s = T(0);
+        for (int k = 0; k < K; ++k) s += Pe[i * KS + k] * Ce[k * KS + j];
+        Gp[i * KS + j] = upstream(i, j) / (s + Num<T>::eps);
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * K; i += CHAIN_THREADS) {    // the amax paths: eps * sum(G') shared among the maxima
+        T sum = T(0), ties = T(0);
+        if (i < K) {
+            for (int j = 0; j < K; ++j) sum += Gp[i * KS + j], ties += Pe[i * KS + j] == T(1) ? T(1) : T(0);
+            pw[i] = Num<T>::eps * sum / ties;
+        } else {
+            const int j = i - K;
+            for (int k = 0; k < K; ++k) sum += Gp[k * KS + j], ties += Ce[k * KS + j] == T(1) ? T(1) : T(0);
+            cw[j] = Num<T>::eps * sum / ties;
         }
-        double off = 0.0;
-        renorm(off);
-        for (int a = tid; a < K; a += CHAIN_THREADS) la_ws[a] = vec[a];
-        if (tid == 0) off_ws[0] = off;
-        for (int t = 0; t + 1 < Tn; ++t) {
-            for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-                const int a = e / K, b = e - a * K;
-                M[e] = ms[(int64_t)t * sT + a * sRow + b * sCol];
-            }
-            __syncthreads();
-            for (int b = tid; b < K; b += CHAIN_THREADS) {
-                T m = NINF, s = T(0);
-                for (int a = 0; a < K; ++a) lse_push(m, s, vec[a] + M[a * K + b]);
-                nxt[b] = (m == NINF) ? NINF : Num<T>::log(s) + m;
-            }
-            __syncthreads();
-            renorm(off);
-            for (int b = tid; b < K; b += CHAIN_THREADS) la_ws[(int64_t)(t + 1) * K + b] = vec[b];
-            if (tid == 0) off_ws[t + 1] = off;
-        }
-        __syncthreads();
-        // ---- backward scan: beta_t and the gradient
-        double boff = 0.0;
-        for (int b = tid; b < K; b += CHAIN_THREADS) vec[b] = T(0);
-        __syncthreads();
-        for (int t = Tn - 1; t >= 0; --t) {
-            for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-                const int a = e / K, b = e - a * K;
-                M[e] = ms[(int64_t)t * sT + a * sRow + b * sCol];
-            }
-            __syncthreads();
-            const T shift = (T)(off_ws[t] + boff);
-            for (int e = tid; e < K * K; e += CHAIN_THREADS) {
-                const int a = e / K, b = e - a * K;
-                const T lw = la_ws[(int64_t)t * K + a];
-                const T gv = (lw == NINF) ? T(0) : Num<T>::exp((lw + M[e] + vec[b]) + shift);
-                T *dst = grad_ms + (int64_t)t * K * K + e;
-                if (sign == 0)
-                    *dst = gv;
-                else
-                    *dst -= gv;
-            }
-            for (int a = tid; a < K; a += CHAIN_THREADS) {
-                T m = NINF, s = T(0);
-                for (int b = 0; b < K; ++b) lse_push(m, s, M[a * K + b] + vec[b]);
-                nxt[a] = (m == NINF) ? NINF : Num<T>::log(s) + m;
-            }
-            __syncthreads();
-            renorm(boff);
-        }
+    }
+    __syncthreads();
+    for (int e = tid; e < KK; e += CHAIN_THREADS) {
+        const int i = e / K, k = e - i * K;               // dP[i,k] (threads walk k), then dC[i,k] as (k', j) = (i, k)
+        T a = T(0), c = T(0);
+        for (int j = 0; j < K; ++j) a += Gp[i * KS + j] * Ce[k * KS + j];
+        for (int r = 0; r < K; ++r) c += Pe[r * KS + i] * Gp[r * KS + k];
+        const T pe = Pe[i * KS + k], ce = Ce[i * KS + k];
+        dP[e] = pe * a + (pe == T(1) ? pw[i] : T(0));
+        dC[e] = ce * c + (ce == T(1) ? cw[k] : T(0));
     }
 }
 
 template <typename T>
-static int chain_backward_run(const void *ms, int64_t Tn, int64_t K, int64_t sT, int64_t sRow, int64_t sCol,
-                              const void *out_vec, const void *grad_out, void *grad_ms, void *ws,
-                              size_t ws_bytes, hipStream_t stream) {
-    const size_t smem = ((size_t)K * K + 2 * K) * sizeof(T);
-    if (K > 128 || smem > 160 * 1024) return ALAN_ERR_UNSUPPORTED;
-    const size_t la_bytes = ((size_t)Tn * K * sizeof(T) + 255) & ~(size_t)255;
-    if (!ws || ws_bytes < la_bytes + (size_t)Tn * sizeof(double)) return ALAN_ERR_WORKSPACE;
-    auto kern = chain_backward_kernel<T>;
+static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
+                              int64_t sCol, const void *tree, const void *out_vec, const void *grad_vec,
+                              const void *grad_chain, void *grad_ms, void *ws, size_t ws_bytes, hipStream_t stream) {
+    const size_t KS = (size_t)(K | 1);
+    const size_t smem = (3 * (size_t)K * KS + 4 * K) * sizeof(T);
+    if (smem > 160 * 1024) return ALAN_ERR_UNSUPPORTED;
+    const TreeLayout tl = tree_layout(B, Tn, K, sizeof(T));
+    if (tl.L > 1 && (!ws || ws_bytes < tl.bytes)) return ALAN_ERR_WORKSPACE;
+    auto kern = chain_pair_backward_kernel<T>;
     if (smem > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return ALAN_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(CHAIN_THREADS), smem, stream, (const T *)ms, sT, sRow, sCol, (int)Tn,
-                       (int)K, (const T *)out_vec, (const T *)grad_out, (T *)grad_ms, (T *)ws,
-                       (double *)((char *)ws + la_bytes));
-    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+    const T *root = (const T *)((const char *)tree + tl.off[tl.L]);
+    for (int r = tl.L; r >= 1; --r) {
+        const bool top = r == tl.L, bottom = r == 1;
+        const T *src = bottom ? (const T *)ms : (const T *)((const char *)tree + tl.off[r - 1]);
+        const int64_t cB = bottom ? sB : tl.n[r - 1] * K * K, cT = bottom ? sT : K * K, cR = bottom ? sRow : K,
+                      cC = bottom ? sCol : 1;
+        const T *G = top ? (const T *)nullptr : (const T *)((const char *)ws + tl.off[r]);
+        T *dsrc = bottom ? (T *)grad_ms : (T *)((char *)ws + tl.off[r - 1]);
+        hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
+                           cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K), (int64_t)K, (int64_t)1,
+                           (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
+        if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+    }
+    return ALAN_OK;
 }
 
 }  // namespace alan
 
 using namespace alan;
 
-extern "C" size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
-    if (T < 1 || K < 1) return 0;
-    return (((size_t)T * K * (dtype == ALAN_F64 ? 8 : 4) + 255) & ~(size_t)255) + (((size_t)T * 8 + 255) & ~(size_t)255);
-}
+static size_t elt_of(int32_t dtype) { return dtype == ALAN_F64 ? 8 : 4; }
 
-extern "C" int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,
-                                            int64_t sRow, int64_t sCol, const void *out_vec,
-                                            const void *grad_out, void *grad_ms, void *workspace,
-                                            size_t workspace_bytes, void *stream) {
-    if (!ms || !out_vec || !grad_out || !grad_ms || T < 1 || K < 1) return ALAN_ERR_BAD_DESC;
-    if (T >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
-    if (dtype == ALAN_F32)
-        return chain_backward_run<float>(ms, T, K, sT, sRow, sCol, out_vec, grad_out, grad_ms, workspace,
-                                         workspace_bytes, (hipStream_t)stream);
-    if (dtype == ALAN_F64)
-        return chain_backward_run<double>(ms, T, K, sT, sRow, sCol, out_vec, grad_out, grad_ms, workspace,
-                                          workspace_bytes, (hipStream_t)stream);
-    return ALAN_ERR_BAD_DESC;
+extern "C" size_t alan_chain_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype) {
+    if (B < 1 || T < 1 || K < 1) return 0;
+    return tree_layout(B, T, K, elt_of(dtype)).bytes;
 }
 
 extern "C" size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
-    if (T < 1 || K < 1) return 0;
-    const size_t mat = (size_t)K * K * (dtype == ALAN_F64 ? 8 : 4);
-    const int seg = alan::pick_segment(T, K);
-    const int64_t n1 = (T + seg - 1) / seg;
-    const int64_t n2 = (n1 + seg - 1) / seg;
-    return ((n1 * mat + 255) & ~(size_t)255) + ((n2 * mat + 255) & ~(size_t)255);
+    return alan_chain_batched_workspace_bytes(1, T, K, dtype);
+}
+
+extern "C" size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype) {
+    return alan_chain_batched_workspace_bytes(B, T, K, dtype);     // one gradient per tree node
+}
+
+extern "C" size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
+    return alan_chain_batched_workspace_bytes(1, T, K, dtype);
+}
+
+extern "C" int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K, int64_t sB,
+                                           int64_t sT, int64_t sRow, int64_t sCol, void *out_chain, void *out_vec,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    if (!ms || B < 1 || T < 1 || K < 1 || (!out_chain && !out_vec)) return ALAN_ERR_BAD_DESC;
+    if (T >= (1ll << 31) || B > 65535) return ALAN_ERR_UNSUPPORTED;      // B rides on gridDim.y
+    if (dtype == ALAN_F32)
+        return chain_run<float>(ms, B, T, K, sB, sT, sRow, sCol, out_chain, out_vec, workspace, workspace_bytes,
+                                (hipStream_t)stream);
+    if (dtype == ALAN_F64)
+        return chain_run<double>(ms, B, T, K, sB, sT, sRow, sCol, out_chain, out_vec, workspace, workspace_bytes,
+                                 (hipStream_t)stream);
+    return ALAN_ERR_BAD_DESC;
 }
 
 extern "C" int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,
                                    int64_t sRow, int64_t sCol, void *out_chain, void *out_vec,
                                    void *workspace, size_t workspace_bytes, void *stream) {
-    if (!ms || T < 1 || K < 1 || (!out_chain && !out_vec)) return ALAN_ERR_BAD_DESC;
-    if (T >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+    return alan_chain_logmmexp_batched(ms, dtype, 1, T, K, 0, sT, sRow, sCol, out_chain, out_vec, workspace,
+                                       workspace_bytes, stream);
+}
+
+extern "C" int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
+                                                    int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
+                                                    const void *tree, const void *out_vec, const void *grad_vec,
+                                                    const void *grad_chain, void *grad_ms, void *workspace,
+                                                    size_t workspace_bytes, void *stream) {
+    if (!ms || !tree || !grad_ms || B < 1 || T < 1 || K < 1) return ALAN_ERR_BAD_DESC;
+    if ((!grad_vec && !grad_chain) || (grad_vec && !out_vec)) return ALAN_ERR_BAD_DESC;
+    if (T >= (1ll << 31) || B > 65535) return ALAN_ERR_UNSUPPORTED;
     if (dtype == ALAN_F32)
-        return chain_run<float>(ms, T, K, sT, sRow, sCol, out_chain, out_vec, workspace, workspace_bytes,
-                                (hipStream_t)stream);
+        return chain_backward_run<float>(ms, B, T, K, sB, sT, sRow, sCol, tree, out_vec, grad_vec, grad_chain, grad_ms,
+                                         workspace, workspace_bytes, (hipStream_t)stream);
     if (dtype == ALAN_F64)
-        return chain_run<double>(ms, T, K, sT, sRow, sCol, out_chain, out_vec, workspace, workspace_bytes,
-                                 (hipStream_t)stream);
+        return chain_backward_run<double>(ms, B, T, K, sB, sT, sRow, sCol, tree, out_vec, grad_vec, grad_chain,
+                                          grad_ms, workspace, workspace_bytes, (hipStream_t)stream);
     return ALAN_ERR_BAD_DESC;
+}
+
+extern "C" int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,
+                                            int64_t sRow, int64_t sCol, const void *tree, const void *out_vec,
+                                            const void *grad_vec, const void *grad_chain, void *grad_ms,
+                                            void *workspace, size_t workspace_bytes, void *stream) {
+    return alan_chain_logmmexp_backward_batched(ms, dtype, 1, T, K, 0, sT, sRow, sCol, tree, out_vec, grad_vec,
+                                                grad_chain, grad_ms, workspace, workspace_bytes, stream);
 }

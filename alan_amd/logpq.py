@@ -185,13 +185,18 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         assert len(K_inits) == 1 and len(K_currs) == 1
         assert prev_lpq is None, "a timeseries plate cannot be split"
         lp = _contract(lps, Ks)
-        want = (id(platedim), id(K_inits[0]), id(K_currs[0]))
-        if set(lp.ids) != set(want):
-            raise NotImplementedError("alan_amd: timeseries plates nested under other K/plate dims are not "
-                                      "supported yet")
-        ms = pt_align(lp, want)
+        # lp.order(T, K_init, K_curr) (logpq.py:133): every other dim -- enclosing plates, Ks of parents in higher
+        # plates -- stays a batch dim of the chain
+        core = (platedim, K_inits[0], K_currs[0])
+        assert all(lp.has(d) for d in core)
+        batch = tuple(d for d in lp.dims if not any(d is c for c in core))
+        ms = pt_align(lp, tuple(id(d) for d in (*batch, *core)))
         from .contract import chain_logmmexp_lse
-        return PT(chain_logmmexp_lse(ms), (K_inits[0],))
+        if not batch:
+            return PT(chain_logmmexp_lse(ms), (K_inits[0],))
+        sizes = [d.size for d in batch]
+        flat = ms.reshape(-1, *ms.shape[-3:])
+        return PT(chain_logmmexp_lse(flat).reshape(*sizes, K_inits[0].size), (*batch, K_inits[0]))
 
     lp = _contract(lps, Ks, (platedim,))
     if prev_lpq is not None:

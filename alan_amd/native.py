@@ -103,9 +103,18 @@ def lib():
         L.alan_chain_backward_workspace_bytes.restype = C.c_size_t
         L.alan_chain_backward_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp_backward.restype = C.c_int
-        L.alan_chain_logmmexp_backward.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.alan_chain_logmmexp_backward.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 5), *([C.c_void_p] * 6),
                                                    C.c_size_t, C.c_void_p]
+        L.alan_chain_batched_workspace_bytes.restype = C.c_size_t
+        L.alan_chain_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+        L.alan_chain_logmmexp_batched.restype = C.c_int
+        L.alan_chain_logmmexp_batched.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 7), C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_chain_backward_batched_workspace_bytes.restype = C.c_size_t
+        L.alan_chain_backward_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+        L.alan_chain_logmmexp_backward_batched.restype = C.c_int
+        L.alan_chain_logmmexp_backward_batched.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 7),
+                                                           *([C.c_void_p] * 6), C.c_size_t, C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -116,6 +125,8 @@ EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
+           "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched",
+           "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_abi_version", "alan_build_target")
 
 
@@ -196,37 +207,55 @@ def run_normal_lse(desc, device):
     return True
 
 
+CHAIN_MAX_BATCH = 65535      # the batch rides on gridDim.y
+
+
 def chain_logmmexp(ms, want_chain=False):
-    """ms: [T,K,K] device tensor -> (vec[K], chain[K,K] or None)."""
+    """ms: [T,K,K] or a batch [B,T,K,K] (device tensor) -> (vec[(B,)K], chain[(B,)K,K] or None, tree).
+    ``tree`` holds every round of the reference's pairwise tree (what the backward walks)."""
     require_device(ms, "timeseries factor")
     L = lib()
-    T, K, K2 = ms.shape
+    batched = ms.ndim == 4
+    m4 = ms if batched else ms.unsqueeze(0)
+    B, T, K, K2 = m4.shape
     assert K == K2
+    if B > CHAIN_MAX_BATCH:
+        raise NativeError(f"alan_chain_logmmexp_batched: at most {CHAIN_MAX_BATCH} chains per call, got {B}")
     code = dtype_code(ms.dtype)
-    vec = t.empty(K, dtype=ms.dtype, device=ms.device)
-    chain = t.empty(K, K, dtype=ms.dtype, device=ms.device) if want_chain else None
-    nbytes = L.alan_chain_workspace_bytes(T, K, code)
-    ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
-    rc = L.alan_chain_logmmexp(ms.data_ptr(), code, T, K, ms.stride(0), ms.stride(1), ms.stride(2),
-                               chain.data_ptr() if want_chain else None, vec.data_ptr(),
-                               ws.data_ptr(), nbytes, current_stream(ms.device))
-    check(rc, "alan_chain_logmmexp")
-    return vec, chain
+    vec = t.empty(B, K, dtype=ms.dtype, device=ms.device)
+    chain = t.empty(B, K, K, dtype=ms.dtype, device=ms.device) if want_chain else None
+    nbytes = L.alan_chain_batched_workspace_bytes(B, T, K, code)
+    tree = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
+    rc = L.alan_chain_logmmexp_batched(m4.data_ptr(), code, B, T, K, *m4.stride(),
+                                       chain.data_ptr() if want_chain else None, vec.data_ptr(),
+                                       tree.data_ptr(), nbytes, current_stream(ms.device))
+    check(rc, "alan_chain_logmmexp_batched")
+    if not batched:
+        return vec[0], (chain[0] if want_chain else None), tree
+    return vec, chain, tree
 
 
-def chain_logmmexp_backward(ms, out_vec, grad_out):
-    """Gradient of logsumexp(chain_logmmexp(ms), -1) wrt ms: [T,K,K]."""
+def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):
+    """Gradient wrt ms [T,K,K] (or [B,T,K,K]) of logsumexp(chain_logmmexp(ms), -1) given grad_vec, and / or of
+    chain_logmmexp(ms) given grad_chain -- autograd through utils.py:478-510, walked down the forward's tree."""
     require_device(ms, "timeseries factor")
     L = lib()
-    T, K, _ = ms.shape
+    batched = ms.ndim == 4
+    m4 = ms if batched else ms.unsqueeze(0)
+    B, T, K, _ = m4.shape
     code = dtype_code(ms.dtype)
-    grad = t.empty(T, K, K, dtype=ms.dtype, device=ms.device)
-    out_vec = out_vec.contiguous()
-    grad_out = grad_out.to(ms.dtype).contiguous()
-    nbytes = L.alan_chain_backward_workspace_bytes(T, K, code)
+    grad = t.empty(B, T, K, K, dtype=ms.dtype, device=ms.device)
+    if grad_vec is not None:
+        out_vec = out_vec.reshape(B, K).contiguous()
+        grad_vec = grad_vec.to(ms.dtype).reshape(B, K).contiguous()
+    if grad_chain is not None:
+        grad_chain = grad_chain.to(ms.dtype).reshape(B, K, K).contiguous()
+    nbytes = L.alan_chain_backward_batched_workspace_bytes(B, T, K, code)
     ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
-    rc = L.alan_chain_logmmexp_backward(ms.data_ptr(), code, T, K, ms.stride(0), ms.stride(1), ms.stride(2),
-                                        out_vec.data_ptr(), grad_out.data_ptr(), grad.data_ptr(),
-                                        ws.data_ptr(), nbytes, current_stream(ms.device))
-    check(rc, "alan_chain_logmmexp_backward")
-    return grad
+    ptr = lambda x: None if x is None else x.data_ptr()
+    rc = L.alan_chain_logmmexp_backward_batched(m4.data_ptr(), code, B, T, K, *m4.stride(), tree.data_ptr(),
+                                                ptr(out_vec) if grad_vec is not None else None, ptr(grad_vec),
+                                                ptr(grad_chain), grad.data_ptr(), ws.data_ptr(), nbytes,
+                                                current_stream(ms.device))
+    check(rc, "alan_chain_logmmexp_backward_batched")
+    return grad if batched else grad[0]

@@ -143,25 +143,47 @@ typedef struct {
 size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Timeseries plate (utils.py:478-510, logpq.py:132-143).
- *   ms         [T, K, K] log transition factors, element strides (sT, sRow, sCol)
+/* Timeseries plate: utils.py:478-510 chain_logmmexp + the t.logsumexp(., -1) of logpq.py:139.
+ *   ms         [T, K, K] with element strides (sT, sRow, sCol); ms[t][i][j] = log weight of going from particle i
+ *              of step t-1 to particle j of step t
  *   out_chain  optional [K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)
  *   out_vec    optional [K]   contiguous: logsumexp(chain, -1)                    (what the ELBO uses)
- * Associative re-bracketing of the reference's pairwise tree: results agree to rounding. */
+ * The reference's own pairwise tree (one launch per round, an odd leftover carried to the end, utils.py:488-495) with
+ * its normalisation and eps-in-log (utils.py:503-507): where that eps floors entries the bracketing matters, so it
+ * is kept.  The workspace receives EVERY round of the tree (alan_chain_workspace_bytes is about the size of ms);
+ * keep it if a backward is to follow. */
 size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K,
                         int64_t sT, int64_t sRow, int64_t sCol,
                         void *out_chain, void *out_vec,
                         void *workspace, size_t workspace_bytes, void *stream);
 
-/* Backward of out_vec = logsumexp(chain_logmmexp(ms), -1) with respect to ms (what autograd derives from
- * utils.py:478-510 + logpq.py:139).  out_vec is the forward result [K], grad_out the upstream gradient [K],
- * grad_ms receives [T, K, K] contiguous.  Two O(T K^2) log-space scans. */
+/* Backward of the above with respect to ms: what autograd derives from utils.py:478-510 (+ logpq.py:139), INCLUDING
+ * the paths through the eps floor and through amax.  `tree` is the forward's workspace, untouched since.  The
+ * upstream gradient is grad_vec [K] (of out_vec; then out_vec must be given) and / or grad_chain [K, K] (of
+ * out_chain); both given = their sum.  grad_ms receives [T, K, K] contiguous.  One launch per round of the tree. */
 size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K,
                                  int64_t sT, int64_t sRow, int64_t sCol,
-                                 const void *out_vec, const void *grad_out, void *grad_ms,
-                                 void *workspace, size_t workspace_bytes, void *stream);
+                                 const void *tree, const void *out_vec, const void *grad_vec, const void *grad_chain,
+                                 void *grad_ms, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same two operations on a BATCH of B independent chains: a timeseries plate nested under other plates or carrying
+ * parent K dims (logpq.py:133-135: lp.order(T, K_init, K_curr) leaves every other torchdim as a batch dim of the
+ * matmuls in utils.py:503-507).  ms is [B, T, K, K] with element strides (sB, sT, sRow, sCol); out_chain [B, K, K],
+ * out_vec / grad_vec [B, K], grad_chain [B, K, K] and grad_ms [B, T, K, K] are contiguous.  B <= 65535.  The
+ * unbatched entry points above are these with B = 1. */
+size_t alan_chain_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
+int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
+                                int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
+                                void *out_chain, void *out_vec,
+                                void *workspace, size_t workspace_bytes, void *stream);
+size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
+int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
+                                         int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
+                                         const void *tree, const void *out_vec, const void *grad_vec,
+                                         const void *grad_chain, void *grad_ms,
+                                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);

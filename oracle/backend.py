@@ -56,18 +56,29 @@ def oracle_launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_o
 
 
 def oracle_chain(ms, want_chain=False):
+    """[T,K,K] or a batch [B,T,K,K]: the reference keeps batch dims as torchdims, i.e. one independent chain each."""
     from oracle import alan_oracle as orc
     import torch as t
-    chain = orc.chain_logmmexp(ms)
-    return t.logsumexp(chain, -1), (chain if want_chain else None)
+    if ms.ndim == 4:
+        chain = t.stack([orc.chain_logmmexp(m) for m in ms], 0)
+    else:
+        chain = orc.chain_logmmexp(ms)
+    return t.logsumexp(chain, -1), (chain if want_chain else None), None
 
 
-def oracle_chain_backward(ms, vec, g):
+def oracle_chain_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):
     import torch as t
     from oracle import alan_oracle as orc
     with t.enable_grad():
         x = ms.detach().clone().requires_grad_(True)
-        (grad,) = t.autograd.grad(orc.timeseries_plate(x), x, g)
+        chains = t.stack([orc.chain_logmmexp(m) for m in x], 0) if x.ndim == 4 else orc.chain_logmmexp(x)
+        total = 0
+        if grad_vec is not None:
+            out = t.logsumexp(chains, -1)
+            total = total + (out * grad_vec.reshape(out.shape)).sum()
+        if grad_chain is not None:
+            total = total + (chains * grad_chain.reshape(chains.shape)).sum()
+        (grad,) = t.autograd.grad(total, x)
     return grad
 
 

@@ -13,6 +13,9 @@ What is captured:
   seam_recorded.pt   every reduce_Ks call made by elbo_nograd on real reference models
                      (linear_gaussian, linear_gaussian_latents, model1, movielens, bus_breakdown)
   chain.pt           logmmexp / chain_logmmexp            (utils.py:478-510)
+  chain_peaked.pt    the same on sharply peaked transition matrices, where the +eps inside the log (utils.py:506)
+                     floors most entries: results then depend on the tree's bracketing, and autograd differentiates
+                     through the floor.  Includes batches of chains (torchdim batch dims, logpq.py:133-139).
   e2e_*.pt           sample tree + data + params + ELBO under no_checkpoint / checkpoint / Split
 
 This-container-only accommodations (none touches the hot path's arithmetic):
@@ -280,6 +283,31 @@ def gen_chain():
     save("chain.pt", cases)
 
 
+def gen_chain_peaked():
+    """Transition factors of a random-walk timeseries with a small noise scale: log N(x_t[j]; 0.9 x_{t-1}[i], 0.1).
+    Most pairs are > 16 nats below the row / column maxima, so log(. + eps) floors them."""
+    cases = []
+    for (B, T, K, dtype, seed) in [(1, 4, 5, t.float32, 1), (1, 25, 30, t.float32, 2), (1, 11, 8, t.float64, 3),
+                                   (6, 13, 10, t.float32, 4), (3, 64, 30, t.float32, 5), (1, 7, 100, t.float32, 6)]:
+        g = t.Generator().manual_seed(7000 + seed)
+        x = t.randn(B, T + 1, K, generator=g, dtype=dtype)
+        ms = td.Normal(0.9 * x[:, :-1, :, None], 0.1).log_prob(x[:, 1:, None, :])          # [B, T, K_prev, K_curr]
+        ms = ms - float(t.log(t.tensor(float(K))))
+        leaves = ms.clone().requires_grad_(True)
+        outs = [t.logsumexp(ref_utils.chain_logmmexp(leaves[b]), -1) for b in range(B)]     # logpq.py:135-139
+        out = t.stack(outs, 0)
+        chain = t.stack([ref_utils.chain_logmmexp(ms[b]) for b in range(B)], 0)
+        gw = t.softmax(out.detach() + t.randn(B, K, generator=g, dtype=dtype), -1)          # ELBO-like upstream weights
+        (grad,) = t.autograd.grad((out * gw).sum(), leaves)
+        gc = t.randn(B, K, K, generator=g, dtype=dtype)
+        l2 = ms.clone().requires_grad_(True)
+        (grad_c,) = t.autograd.grad(sum((ref_utils.chain_logmmexp(l2[b]) * gc[b]).sum() for b in range(B)), l2)
+        cases.append(dict(B=B, T=T, K=K, dtype=str(dtype), ms=ms, chain=chain, out=out, grad_out=gw, grad=grad,
+                          grad_chain_out=gc, grad_chain=grad_c,
+                          floored=float((chain < chain.amax(-1, keepdim=True) - 15.5).double().mean())))
+    save("chain_peaked.pt", cases)
+
+
 # ------------------------------------------------------------------ 4. recorded + e2e
 class Recorder:
     def __init__(self):
@@ -422,7 +450,11 @@ def gen_models():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["chain_peaked"]:          # one fixture only (the others are not regenerated)
+        gen_chain_peaked()
+        sys.exit(0)
     gen_lse_dims()
     gen_seam_synthetic()
     gen_chain()
+    gen_chain_peaked()
     gen_models()

@@ -1,0 +1,89 @@
+"""Batched timeseries chains (alan_chain_logmmexp_batched and its backward): a timeseries plate nested under other
+plates / parent K dims.  The reference reaches this through torchdim batch dims left on ``lp`` after
+``lp.order(T, K_init, K_curr)`` (logpq.py:133-139), i.e. one independent chain per batch element -- so the checker
+is the oracle's chain (pinned on tests/golden/chain.pt) applied to each element."""
+import pytest
+import torch as t
+
+from alan_amd import native as N
+from alan_amd.contract import chain_logmmexp_lse, chain_logmmexp
+from oracle import alan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ms(B, T, K, dtype, seed):
+    g = t.Generator().manual_seed(seed)
+    # log-density-like entries with a per-step offset, so normalisation matters
+    return (-0.5 * t.randn(B, T, K, K, generator=g, dtype=t.float64) ** 2 - 0.9
+            + t.randn(B, T, 1, 1, generator=g, dtype=t.float64)).to(dtype)
+
+
+def _oracle(ms):
+    chain = t.stack([orc.chain_logmmexp(m) for m in ms.double()], 0)
+    return t.logsumexp(chain, -1), chain
+
+
+SHAPES = [(1, 1, 3), (3, 2, 3), (5, 7, 3), (4, 50, 30), (700, 9, 10), (2, 33, 40), (3, 12, 100), (2500, 4, 30)]
+
+
+@pytest.mark.parametrize("B,T,K", SHAPES, ids=[f"B{b}_T{T}_K{k}" for b, T, k in SHAPES])
+@pytest.mark.parametrize("dtype", [t.float32, t.float64], ids=["f32", "f64"])
+def test_batched_chain_matches_the_oracle_per_element(B, T, K, dtype):
+    ms = _ms(B, T, K, dtype, 7 * B + T + K)
+    want_vec, want_chain = _oracle(ms)
+    if dtype == t.float64 and K > 96:          # two fp64 [K,K] operands no longer fit LDS: the host takes the scan
+        with pytest.raises(N.NativeError):
+            N.chain_logmmexp(ms.to(DEV))
+        t.testing.assert_close(chain_logmmexp_lse(ms.to(DEV)).cpu(), want_vec, rtol=1e-11, atol=1e-10)
+        return
+    vec, chain, _ = N.chain_logmmexp(ms.to(DEV), want_chain=True)
+    kw = dict(rtol=2e-5, atol=2e-5 * (1 + T ** 0.5)) if dtype == t.float32 else dict(rtol=1e-11, atol=1e-10)
+    t.testing.assert_close(vec.cpu().double(), want_vec, **kw)
+    t.testing.assert_close(chain.cpu().double(), want_chain, **kw)
+    # the batch is the unbatched kernel run B times: bit-identical per element
+    if B <= 5:
+        for b in range(B):
+            v1, _, _ = N.chain_logmmexp(ms[b].to(DEV))
+            assert t.equal(v1, vec[b])
+
+
+def test_batched_chain_takes_strided_batches():
+    """[T, K, B, K]-ordered storage viewed as [B, T, K, K]: strides travel through the C ABI, no copy."""
+    B, T, K = 6, 11, 30
+    ms = _ms(B, T, K, t.float32, 3)
+    store = ms.permute(1, 2, 0, 3).contiguous().to(DEV)          # [T, K, B, K]
+    view = store.permute(2, 0, 1, 3)
+    assert not view.is_contiguous()
+    vec, _, _ = N.chain_logmmexp(view)
+    want, _ = _oracle(ms)
+    t.testing.assert_close(vec.cpu().double(), want, rtol=2e-5, atol=1e-4)
+    exp = store[:, :, :1, :].expand(T, K, B, K).permute(2, 0, 1, 3)     # stride-0 batch: B copies of one chain
+    vec2, _, _ = N.chain_logmmexp(exp)
+    assert t.equal(vec2[0], vec2[B - 1])
+
+
+@pytest.mark.parametrize("B,T,K", [(1, 5, 3), (4, 9, 10), (300, 4, 30), (3, 40, 64)])
+@pytest.mark.parametrize("dtype", [t.float32, t.float64], ids=["f32", "f64"])
+def test_batched_chain_backward_matches_autograd_of_the_oracle(B, T, K, dtype):
+    ms = _ms(B, T, K, dtype, 11 + B)
+    g = t.randn(B, K, generator=t.Generator().manual_seed(5), dtype=t.float64)
+    x = ms.double().requires_grad_(True)
+    out = t.stack([orc.timeseries_plate(m) for m in x], 0)
+    (want,) = t.autograd.grad(out, x, g)
+    y = ms.to(DEV).requires_grad_(True)
+    got_out = chain_logmmexp_lse(y)
+    (got,) = t.autograd.grad(got_out, y, g.to(DEV, dtype))
+    kw = dict(rtol=2e-3, atol=2e-5) if dtype == t.float32 else dict(rtol=1e-8, atol=1e-10)
+    t.testing.assert_close(got.cpu().double(), want, **kw)
+
+
+def test_large_K_batch_goes_through_the_matvec_scan():
+    """K > 100 (the reference's ground-truth tests use K = 1000): the right-to-left log-matvec scan, batched."""
+    B, T, K = 3, 4, 130
+    ms = _ms(B, T, K, t.float32, 9)
+    got = chain_logmmexp_lse(ms.to(DEV))
+    want, _ = _oracle(ms)
+    t.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=1e-4)
+    assert chain_logmmexp(ms[:, :, :3, :3].to(DEV)).shape == (B, 3, 3)

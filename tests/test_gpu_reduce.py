@@ -207,13 +207,13 @@ def _chain_input(case):
                          ids=lambda c: f"T{c['T']}K{c['K']}")
 def test_chain_logmmexp_golden(case):
     ms = _chain_input(case).to(DEV)
-    vec, chain = N.chain_logmmexp(ms, want_chain=True)
+    vec, chain, _ = N.chain_logmmexp(ms, want_chain=True)
     kw = dict(rtol=2e-5, atol=5e-5) if ms.dtype == t.float32 else dict(rtol=1e-10, atol=1e-10)
     t.testing.assert_close(chain.cpu(), case["chain"], **kw)
     t.testing.assert_close(vec.cpu(), case["out"], **kw)
     # strided input (time axis last in memory)
     ms2 = ms.permute(1, 2, 0).contiguous().permute(2, 0, 1)
-    vec2, _ = N.chain_logmmexp(ms2)
+    vec2, _, _ = N.chain_logmmexp(ms2)
     t.testing.assert_close(vec2, vec, rtol=0, atol=0)
 
 
@@ -269,8 +269,49 @@ def test_chain_backward_golden(case):
         kw = dict(rtol=1e-4, atol=1e-5) if ms.dtype == t.float32 else dict(rtol=1e-9, atol=1e-10)
         t.testing.assert_close(grad.cpu(), case["grad"], **kw)
     s, a = case["grad_checksum"]
-    assert abs(float(grad.double().sum()) - s) <= 2e-4 * max(1.0, a)
-    assert abs(float(grad.double().abs().sum()) - a) <= 2e-4 * max(1.0, a)
+    # the gradient's total mass is sum_i g_i exp(chain[i,:] - out[i]): an fp32 `out` of magnitude ~2000 (T = 1000) is
+    # only known to 2.4e-4, in the reference's run as much as in ours
+    tol = 2e-4 + 2 * float(t.finfo(ms.dtype).eps) * float(case["out"].abs().max())
+    assert abs(float(grad.double().sum()) - s) <= tol * max(1.0, a)
+    assert abs(float(grad.double().abs().sum()) - a) <= tol * max(1.0, a)
+
+
+PEAKED = load_golden("chain_peaked.pt")
+
+
+@pytest.mark.parametrize("case", PEAKED, ids=[f"B{c['B']}T{c['T']}K{c['K']}" for c in PEAKED])
+def test_chain_on_the_eps_floor_matches_the_reference_forward_and_backward(case):
+    """Sharply peaked transition matrices (a random walk with a small noise scale): 23-38 % of the chain's entries
+    sit on the floor that the +eps inside the log creates (utils.py:506), so the value depends on the tree's
+    bracketing and autograd differentiates through the floor and through amax.  The kernels keep the reference's
+    tree and differentiate it node by node: values and gradients agree with the reference's own."""
+    from alan_amd.contract import chain_logmmexp_lse, chain_logmmexp
+    assert case["floored"] > 0.2
+    f32 = case["ms"].dtype == t.float32
+    for b in range(case["B"]):                               # unbatched entry points, one chain at a time
+        ms = case["ms"][b].to(DEV).requires_grad_(True)
+        out = chain_logmmexp_lse(ms)
+        t.testing.assert_close(out.cpu(), case["out"][b], **(dict(rtol=2e-5, atol=2e-4) if f32 else dict(rtol=1e-10, atol=1e-9)))
+        (grad,) = t.autograd.grad(out, ms, case["grad_out"][b].to(DEV))
+        kw = dict(rtol=2e-3, atol=2e-5) if f32 else dict(rtol=1e-8, atol=1e-10)
+        t.testing.assert_close(grad.cpu(), case["grad"][b], **kw)
+        if b:
+            continue
+        ms2 = case["ms"][b].to(DEV).requires_grad_(True)     # the full [K,K] chain and ITS backward
+        ch = chain_logmmexp(ms2)
+        t.testing.assert_close(ch.cpu(), case["chain"][b], **(dict(rtol=2e-5, atol=2e-4) if f32 else dict(rtol=1e-10, atol=1e-9)))
+        (gc,) = t.autograd.grad(ch, ms2, case["grad_chain_out"][b].to(DEV))
+        # one product of the batch's gradient: compare against the reference's per-chain slice
+        if case["B"] == 1:
+            t.testing.assert_close(gc.cpu(), case["grad_chain"][b], **(dict(rtol=2e-3, atol=2e-4) if f32 else dict(rtol=1e-8, atol=1e-9)))
+    msb = case["ms"].to(DEV).requires_grad_(True)            # the batched entry points
+    outb = chain_logmmexp_lse(msb)
+    t.testing.assert_close(outb.cpu(), case["out"], **(dict(rtol=2e-5, atol=2e-4) if f32 else dict(rtol=1e-10, atol=1e-9)))
+    (gb,) = t.autograd.grad(outb, msb, case["grad_out"].to(DEV))
+    t.testing.assert_close(gb.cpu(), case["grad"], **(dict(rtol=2e-3, atol=2e-5) if f32 else dict(rtol=1e-8, atol=1e-10)))
+    msc = case["ms"].to(DEV).requires_grad_(True)
+    (gcb,) = t.autograd.grad(chain_logmmexp(msc), msc, case["grad_chain_out"].to(DEV))
+    t.testing.assert_close(gcb.cpu(), case["grad_chain"], **(dict(rtol=2e-3, atol=2e-4) if f32 else dict(rtol=1e-8, atol=1e-9)))
 
 
 @pytest.mark.parametrize("shapes", ["movielens", "shared_dims", "scalar_event"])

@@ -76,7 +76,11 @@ def test_workspace_query():
     assert L.alan_reduce_workspace_bytes(ctypes.byref(d)) == 256      # 30 floats, 256-aligned
     d.role[0] = N.KEEP
     assert L.alan_reduce_workspace_bytes(ctypes.byref(d)) == 0
-    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) > 100 * 30 * 30 * 4
+    # every round of the pairwise tree stays in the workspace: 500 + 250 + 125 + 63 + 32 + 16 + 8 + 4 + 2 + 1 nodes
+    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) >= 1001 * 30 * 30 * 4
+    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) < 1001 * 30 * 30 * 4 + 10 * 256
+    assert L.alan_chain_batched_workspace_bytes(7, 1, 5, N.F64) == (7 * 25 * 8 + 255) // 256 * 256
+    assert L.alan_chain_backward_batched_workspace_bytes(3, 9, 4, N.F32) == L.alan_chain_batched_workspace_bytes(3, 9, 4, N.F32)
 
 
 def test_cpu_tensors_are_refused_not_silently_computed():

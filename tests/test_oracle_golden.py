@@ -87,6 +87,21 @@ def test_chain_logmmexp(case):
     t.testing.assert_close(orc.timeseries_plate(ms), case["out"], rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", load_golden("chain_peaked.pt"), ids=lambda c: f"B{c['B']}T{c['T']}K{c['K']}")
+def test_chain_on_the_eps_floor(case):
+    """Peaked transition matrices: a quarter or more of the result sits on the +eps floor (utils.py:506); the oracle
+    follows the reference's bracketing there and its autograd is the reference's, floor and amax paths included."""
+    x = case["ms"].clone().requires_grad_(True)
+    chains = t.stack([orc.chain_logmmexp(m) for m in x], 0)
+    out = t.logsumexp(chains, -1)
+    t.testing.assert_close(chains, case["chain"], rtol=1e-6, atol=1e-5)
+    t.testing.assert_close(out, case["out"], rtol=1e-6, atol=1e-5)
+    (g,) = t.autograd.grad((out * case["grad_out"]).sum(), x, retain_graph=True)
+    t.testing.assert_close(g, case["grad"], rtol=1e-5, atol=1e-7)
+    (gc,) = t.autograd.grad((chains * case["grad_chain_out"]).sum(), x)
+    t.testing.assert_close(gc, case["grad_chain"], rtol=1e-5, atol=1e-6)
+
+
 def test_logmmexp():
     (case,) = [c for c in load_golden("chain.pt") if c.get("name") == "logmmexp"]
     t.testing.assert_close(orc.logmmexp(case["prev"], case["curr"]), case["out"], rtol=0, atol=0)

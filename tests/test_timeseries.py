@@ -72,25 +72,8 @@ def test_timeseries_T1000_K30_runs_and_matches_oracle_chain():
     gpu = float(sample.elbo_nograd(alan.no_checkpoint))
     assert math.isfinite(gpu)
     # move the identical sample tree to the CPU and evaluate with the oracle backend
-    import models
-    from alan_amd.dims import dims_of
     cpu_prob, _ = kalman_problem(1000)
-    Kd = {g: alan.dims.Dim(str(d), 30) for g, d in sample.groupvarname2Kdim.items()}
-    by = {**{str(d): d for d in Kd.values()}, **{n: d for n, d in cpu_prob.all_platedims.items()}}
-
-    def cpu_tree(tree):
-        out = {}
-        for k, v in tree.items():
-            if isinstance(v, dict):
-                out[k] = cpu_tree(v)
-            else:
-                ds = dims_of(v)
-                pos = v.order(*ds).cpu()
-                out[k] = pos[tuple(by[str(d)] for d in ds)]
-        return out
-
-    cs = alan.Sample(problem=cpu_prob, sample=cpu_tree(sample.detached_sample), groupvarname2Kdim=Kd,
-                     sampler=alan.PermutationSampler, reparam=False)
+    cs = _same_sample_on_cpu(sample, cpu_prob, 30)
     with backend.installed():
         cpu = float(cs.elbo_nograd(alan.no_checkpoint))
     assert abs(gpu - cpu) <= 1e-4 * abs(cpu) + 1e-3, (gpu, cpu)
@@ -137,3 +120,111 @@ def test_timeseries_posterior_host_logic(oracle_backend):
 @pytest.mark.gpu
 def test_timeseries_posterior_gpu():
     _ts_posterior_check("cuda", 300, 20000)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# timeseries plates NESTED under another plate and depending on a latent of a higher plate (the shape of the
+# reference's examples/models/covid/covid.py:55-75): lp keeps the enclosing plate and the parent's K as batch dims of
+# the chain (logpq.py:133-139).  Everything is linear-Gaussian, so the evidence is a multivariate Normal.
+DRIFT, REGIONS = 0.3, 3
+
+
+def nested_problem(T, seed=0, opt=False):
+    """drift ~ N(0, DRIFT);  region r: init_r ~ N(0, INIT_SCALE), ts_rt ~ N(A ts_r,t-1 + drift, NOISE), obs ~ N(ts, OBS)"""
+    R = REGIONS
+    g = t.Generator().manual_seed(seed)
+    # ts as a linear map of z = (drift, init_1..R, eps_11..eps_RT), by running the recursion on basis vectors
+    nz = 1 + R + R * T
+    M = t.zeros(R, T, nz, dtype=t.float64)
+    for r in range(R):
+        prev = t.zeros(nz, dtype=t.float64)
+        prev[1 + r] = 1.0
+        for i in range(T):
+            cur = A * prev
+            cur[0] += 1.0
+            cur[1 + R + r * T + i] += 1.0
+            M[r, i] = cur
+            prev = cur
+    var = t.cat([t.tensor([DRIFT ** 2]), t.full((R,), INIT_SCALE ** 2), t.full((R * T,), NOISE ** 2)]).double()
+    Mf = M.reshape(R * T, nz)
+    total = Mf @ t.diag(var) @ Mf.T + OBS ** 2 * t.eye(R * T, dtype=t.float64)
+    L = t.linalg.cholesky(total)
+    y = L @ t.randn(R * T, generator=g, dtype=t.float64)
+    known = t.distributions.MultivariateNormal(t.zeros(R * T, dtype=t.float64), scale_tril=L).log_prob(y)
+    P = Plate(drift=Normal(0, DRIFT),
+              R=Plate(init=Normal(0, INIT_SCALE),
+                      T=Plate(ts=Timeseries("init", Normal(lambda prev, drift: A * prev + drift, NOISE)),
+                              obs=Normal("ts", OBS))))
+    if opt:
+        from alan_amd import OptParam
+        Q = Plate(drift=Normal(OptParam(0.05), DRIFT),
+                  R=Plate(init=Normal(OptParam(0.1), 1),
+                          T=Plate(ts=Normal(OptParam(-0.1), OptParam(0.1, transformation=t.exp)), obs=Data())))
+    else:
+        Q = Plate(drift=Normal(0, DRIFT), R=Plate(init=Normal(0, 1), T=Plate(ts=Normal(0, 1), obs=Data())))
+    sizes = {"R": R, "T": T}
+    prob = Problem(BoundPlate(P, sizes), BoundPlate(Q, sizes),
+                   {"obs": y.reshape(R, T).float().refine_names("R", "T")})
+    return prob, float(known)
+
+
+def _same_sample_on_cpu(sample, cpu_prob, K):
+    from alan_amd.dims import dims_of
+    Kd = {g: alan.dims.Dim(str(d), K) for g, d in sample.groupvarname2Kdim.items()}
+    by = {**{str(d): d for d in Kd.values()}, **{n: d for n, d in cpu_prob.all_platedims.items()}}
+
+    def cpu_tree(tree):
+        out = {}
+        for k, v in tree.items():
+            if isinstance(v, dict):
+                out[k] = cpu_tree(v)
+            else:
+                ds = dims_of(v)
+                out[k] = v.order(*ds).cpu()[tuple(by[str(d)] for d in ds)]
+        return out
+
+    return alan.Sample(problem=cpu_prob, sample=cpu_tree(sample.detached_sample), groupvarname2Kdim=Kd,
+                       sampler=alan.PermutationSampler, reparam=False)
+
+
+def test_nested_timeseries_elbo_host_logic(oracle_backend):
+    prob, known = nested_problem(4)
+    mean, stderr, vals = _band(prob, known, 200, 6, "cpu")
+    assert mean - 6 * stderr - 0.05 < known
+    assert known < mean + 6 * stderr + 1.0, (known, mean, stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [60, 300], ids=["chain_kernel", "matvec_scan"])
+def test_nested_timeseries_elbo_ground_truth_gpu(K):
+    prob, known = nested_problem(4)
+    mean, stderr, vals = _band(prob, known, K, 12, "cuda")
+    assert mean - 6 * stderr - 0.05 < known
+    assert known < mean + 6 * stderr + (1.5 if K < 100 else 0.6), (known, mean, stderr)
+
+
+@pytest.mark.gpu
+def test_nested_timeseries_hip_equals_oracle_on_the_same_sample_and_has_gradients():
+    """Same particles through the batched HIP chain and through the CPU oracle backend; then elbo_rws backward through
+    the batched chain's backward kernel against autograd through the oracle."""
+    from oracle import backend
+    K = 30
+    prob, _ = nested_problem(25, opt=True)
+    prob.to("cuda")
+    t.manual_seed(2)
+    sample = prob.sample(K, reparam=False)
+    gpu = float(sample.elbo_nograd(alan.no_checkpoint))
+    sample.elbo_rws(alan.no_checkpoint).backward()
+    cpu_prob, _ = nested_problem(25, opt=True)
+    with backend.installed():
+        cs = _same_sample_on_cpu(sample, cpu_prob, K)
+        cpu = float(cs.elbo_nograd(alan.no_checkpoint))
+        cs.elbo_rws(alan.no_checkpoint).backward()
+    assert math.isfinite(gpu) and abs(gpu - cpu) <= 1e-4 * abs(cpu) + 1e-3, (gpu, cpu)
+    grads = 0
+    for (n1, p1), (n2, p2) in zip(prob.Q.named_parameters(), cpu_prob.Q.named_parameters()):
+        assert n1 == n2 and p1.grad is not None and p2.grad is not None, n1
+        scale = float(p2.grad.abs().max()) + 1e-6
+        t.testing.assert_close(p1.grad.cpu(), p2.grad, rtol=2e-3, atol=2e-4 * scale, msg=lambda m: f"{n1}: {m}")
+        grads += 1
+    assert grads >= 4
