@@ -189,6 +189,132 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
     }
 }
 
+// Up to THREE rounds of the tree in one launch (K <= 32): a workgroup of 4 x 256 threads takes 8 consecutive nodes;
+// its four quarter-groups multiply the four pairs of the first round side by side, two of them the second round's
+// pairs, one the third's -- operands of every round in their own LDS slots, so a product's result goes straight into
+// its parent's P (left child: with row maxima) or C (right child: with column maxima) slot and, fire-and-forget, into
+// the tree in global memory for the backward.  Same arithmetic as chain_segment_kernel, product for product; T = 1000
+// is 4 launches of 3 + 3 + 3 + 1 rounds instead of 10.
+constexpr int TREE_THREADS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(TREE_THREADS) void chain_tree_kernel(
+    const T *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_in, int K, int rounds,
+    T *out1, T *out2, T *out3, int n1, int n2, int n3, T *vec_out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int KP = (K + 3) & ~3, NJG = KP >> 2, PS = KP + 4, KK = K * K;
+    const int SLOT = KP * PS + KP * KP + 2 * KP;        // P [KP][PS], C [KP][KP], row maxima of P, column maxima of C
+    T *base = reinterpret_cast<T *>(smem_raw);
+    auto P_of = [&](int s) { return base + (size_t)s * SLOT; };
+    auto C_of = [&](int s) { return base + (size_t)s * SLOT + KP * PS; };
+    auto pm_of = [&](int s) { return base + (size_t)s * SLOT + KP * PS + KP * KP; };
+    auto cm_of = [&](int s) { return base + (size_t)s * SLOT + KP * PS + KP * KP + KP; };
+    const int first_slot[4] = {0, 4, 6, 7};             // round 0: slots 0-3, round 1: 4-5, round 2: 6, result: 7
+    const int tid = threadIdx.x, g = tid >> 8, gt = tid & 255;
+    const int64_t b = blockIdx.y;
+    const int seg = blockIdx.x, W = 1 << rounds;        // input nodes per workgroup
+    const T NINF = Num<T>::ninf();
+    T *const outs[3] = {out1, out2, out3};
+    const int ns[3] = {n1, n2, n3};
+    ms += b * sB;
+
+    for (int i = tid; i < 8 * 2 * KP; i += TREE_THREADS) pm_of(i / (2 * KP))[i % (2 * KP)] = NINF;
+    __syncthreads();
+    int m = min(W, n_in - seg * W);                     // nodes entering the current round, in this workgroup
+    {
+        const int a = 2 * g;
+        T *P = P_of(g), *C = C_of(g), *pm = pm_of(g), *cm = cm_of(g);
+        for (int e = gt; e < KK; e += 256) {
+            const int i = e / K, j = e - i * K;
+            if (a < m) {
+                const T v = ms[(int64_t)(seg * W + a) * sT + i * sRow + j * sCol];
+                P[i * PS + j] = v;
+                lds_max(&pm[i], v);
+            }
+            if (a + 1 < m) {
+                const T c = ms[(int64_t)(seg * W + a + 1) * sT + i * sRow + j * sCol];
+                C[i * KP + j] = c;
+                lds_max(&cm[j], c);
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < rounds; ++l) {
+        const bool exists = g < (4 >> l) && 2 * g < m, pair = g < (4 >> l) && 2 * g + 1 < m;
+        const int s = first_slot[l] + (g < (4 >> l) ? g : 0);
+        T *P = P_of(s), *C = C_of(s);
+        const T *pm = pm_of(s), *cm = cm_of(s);
+        if (pair) {                                     // utils.py:503-505, pads -> 0
+            for (int e = gt; e < KP * KP; e += 256) {
+                const int i = e / KP, j = e - i * KP;
+                const bool in = i < K && j < K;
+                if (i < K) P[i * PS + j] = in ? Num<T>::exp(P[i * PS + j] - pm[i]) : T(0);
+                C[e] = in ? Num<T>::exp(C[e] - cm[j]) : T(0);
+            }
+        }
+        __syncthreads();
+        const int ds = first_slot[l + 1] + (g >> 1);
+        const bool asC = g & 1;                         // right child: the parent's C operand
+        T *D = asC ? C_of(ds) : P_of(ds);
+        T *dmax = asC ? cm_of(ds) : pm_of(ds);
+        const int DS = asC ? KP : PS;
+        T *gout = (exists && outs[l]) ? outs[l] + ((b * ns[l]) + (int64_t)seg * (W >> (l + 1)) + g) * KK : nullptr;
+        if (pair) {
+            if (gt < K * NJG) {
+                const int i = gt / NJG, jg = gt - i * NJG;
+                const Vec4<T> *P4 = reinterpret_cast<const Vec4<T> *>(P);
+                const Vec4<T> *C4 = reinterpret_cast<const Vec4<T> *>(C);
+                Vec4<T> a = {T(0), T(0), T(0), T(0)};
+#pragma unroll 4
+                for (int k4 = 0; k4 < NJG; ++k4) {
+                    const Vec4<T> p = P4[i * (NJG + 1) + k4];
+                    const Vec4<T> c0 = C4[(4 * k4) * NJG + jg], c1 = C4[(4 * k4 + 1) * NJG + jg],
+                                  c2 = C4[(4 * k4 + 2) * NJG + jg], c3 = C4[(4 * k4 + 3) * NJG + jg];
+                    a.x += p.x * c0.x + p.y * c1.x + p.z * c2.x + p.w * c3.x;
+                    a.y += p.x * c0.y + p.y * c1.y + p.z * c2.y + p.w * c3.y;
+                    a.z += p.x * c0.z + p.y * c1.z + p.z * c2.z + p.w * c3.z;
+                    a.w += p.x * c0.w + p.y * c1.w + p.z * c2.w + p.w * c3.w;
+                }
+                const T r[4] = {a.x, a.y, a.z, a.w};
+                T mx = NINF;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 4 * jg + c;
+                    if (j < K) {
+                        const T v = Num<T>::log(r[c] + Num<T>::eps) + pm[i] + cm[j];     // utils.py:506-507
+                        D[i * DS + j] = v;
+                        if (gout) gout[i * K + j] = v;
+                        if (asC) lds_max(&dmax[j], v);
+                        mx = fmax(mx, v);
+                    }
+                }
+                if (!asC) lds_max(&dmax[i], mx);
+            }
+        } else if (exists) {                            // the leftover of this round passes through (utils.py:488-495)
+            for (int e = gt; e < KK; e += 256) {
+                const int i = e / K, j = e - i * K;
+                const T v = P[i * PS + j];
+                D[i * DS + j] = v;
+                if (gout) gout[e] = v;
+                lds_max(&dmax[asC ? j : i], v);
+            }
+        }
+        __syncthreads();
+        m = (m + 1) >> 1;
+    }
+    if (vec_out) {                                      // torch.logsumexp(lp, -1)  (logpq.py:139): no eps
+        const T *R = P_of(first_slot[rounds]);
+        for (int i = tid; i < K; i += TREE_THREADS) {
+            T mx = NINF;
+            for (int j = 0; j < K; ++j) mx = fmax(mx, R[i * PS + j]);
+            T sum = T(0);
+            const T mref = (mx == NINF || mx == -NINF) ? T(0) : mx;
+            for (int j = 0; j < K; ++j) sum += Num<T>::exp(R[i * PS + j] - mref);
+            vec_out[b * K + i] = Num<T>::log(sum) + mref;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The tree in memory: round r = 1..L holds n_r = ceil(n_{r-1} / 2) matrices per chain ([B][n_r][K][K], each round
 // 256-byte aligned), n_0 = T, n_L = 1 (the root = chain_logmmexp(ms)); T = 1 has one round holding a copy of ms[0].
@@ -228,16 +354,42 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
     if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
     const T *src = (const T *)ms_;
     int64_t cB = sB, cT = sT, cR = sRow, cC = sCol;
-    for (int r = 1; r <= tl.L; ++r) {
-        T *dst = (T *)((char *)ws + tl.off[r]);
-        hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
-                           cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr);
-        if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
-        src = dst;
-        cB = tl.n[r] * K * K;
-        cT = K * K;
-        cR = K;
-        cC = 1;
+    static const bool per_round = getenv("ALAN_CHAIN_PER_ROUND") != nullptr;      // ablation: one round per launch
+    if (K <= 32 && !per_round) {
+        const size_t slot = (KP * (KP + 4) + KP * KP + 2 * KP) * sizeof(T);
+        auto tk = chain_tree_kernel<T>;
+        if (hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * slot)) != hipSuccess)
+            return ALAN_ERR_LAUNCH;
+        for (int r = 0; r < tl.L;) {
+            const int rounds = std::min(3, tl.L - r);
+            const int64_t nseg = (tl.n[r] + (1 << rounds) - 1) >> rounds;
+            T *o[3] = {nullptr, nullptr, nullptr};
+            int nn[3] = {0, 0, 0};
+            for (int q = 0; q < rounds; ++q) o[q] = (T *)((char *)ws + tl.off[r + 1 + q]), nn[q] = (int)tl.n[r + 1 + q];
+            const bool last = r + rounds == tl.L;
+            hipLaunchKernelGGL(tk, dim3((uint32_t)nseg, (uint32_t)B), dim3(TREE_THREADS), 8 * slot, stream, src, cB, cT,
+                               cR, cC, (int)tl.n[r], (int)K, rounds, o[0], o[1], o[2], nn[0], nn[1], nn[2],
+                               last ? (T *)out_vec : (T *)nullptr);
+            if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            r += rounds;
+            src = o[rounds - 1];
+            cB = tl.n[r] * K * K;
+            cT = K * K;
+            cR = K;
+            cC = 1;
+        }
+    } else {
+        for (int r = 1; r <= tl.L; ++r) {
+            T *dst = (T *)((char *)ws + tl.off[r]);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
+                               cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr);
+            if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            src = dst;
+            cB = tl.n[r] * K * K;
+            cT = K * K;
+            cR = K;
+            cC = 1;
+        }
     }
     if (out_chain)
         if (hipMemcpyAsync(out_chain, (char *)ws + tl.off[tl.L], (size_t)(B * K * K) * sizeof(T),
