@@ -30,6 +30,7 @@ struct NormalDesc {
     int32_t rows_contig;              // value rows of a workgroup are one contiguous, 16-byte aligned block
     int32_t vstage_off;               // LDS offset (floats) of the value staging area
     float out_scale, add_const;       // out = out_scale * log_prob + add_const
+    uint32_t out_bytes;               // bytes spanned by out (MFMA kernel: buffer descriptor range)
     int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
     int64_t l_os, s_os;               // out strides along the loc / scale dims
     FastDiv vdiv[MAXD];
@@ -193,6 +194,203 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same producer on the matrix cores.  For one loc row l the block out[., l, .] IS a GEMM over the event dim,
+//   out[v, l, s] = -( sum_e w[s,e] * d2[v,e] + lg[s] ),   d2[v,e] = (value[v,e] - loc[l,e])^2,  w = 0.5 / scale^2,
+// and v_mfma_f32_32x32x2_f32 computes it as an exact k-ordered fp32 fmaf chain (same numerics as the loop above) at
+// the packed-FMA rate WITHOUT the operand traffic: the vector kernel's main loop is bound by its broadcast LDS reads
+// of the scale rows, here A (32 scale rows x 2 events per instruction) and B (2 events x 32 value rows) are one VGPR
+// each, held for the whole kernel (A) or rebuilt with two VALU ops per loc row (B).  A wave owns 32 value rows and all
+// scale rows (NST tiles of 32); the log-normaliser lg[s] enters as the C operand of the first MFMA.  No LDS, no
+// barriers: every wave is independent.  D[i = scale row][j = value row]: lanes run along the value rows, which is
+// the output's contiguous dim in the plate step (K_z), so each store instruction writes two runs of up to 128 bytes.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int EH, int NST>      // EH = ceil(E / 2) MFMA steps; NST = tiles of 32 scale rows
+__global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
+    constexpr int EP = 2 * EH, NSP = 32 * NST;
+    __shared__ float wt[NSP * EP];            // 0.5 / scale^2, zero padded to [NSP][EP]
+    __shared__ float lgt[NSP * EP];           // log scale, zero padded; lgt[s * EP] becomes the row's log-normaliser
+    extern __shared__ __align__(16) float mut[];   // [l_chunk][EP] this workgroup's loc rows, zero padded
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int E = d.E;
+    const uint32_t l0 = blockIdx.y * d.l_chunk, l1 = min(d.NL, l0 + d.l_chunk);
+    // ---- workgroup-uniform tables: every scale element once per workgroup (one thread each), summed per row after
+#pragma unroll 2
+    for (int i = tid; i < NSP * EP; i += 256) {
+        const uint32_t srow = i / EP;
+        const int e = i - srow * EP;
+        float wv = 0.f, lgv = 0.f;
+        if (srow < d.NS && e < E) {
+            const float sc = d.scl[(int64_t)srow * d.s_rs + e];
+            wv = d.log_scale ? 0.5f * expf(-2.f * sc) : 0.5f / (sc * sc);
+            lgv = d.log_scale ? sc : logf(sc);
+        }
+        wt[i] = wv;
+        lgt[i] = lgv;
+    }
+    for (int i = tid; i < (int)(l1 - l0) * EP; i += 256) {
+        const int il = i / EP, e = i - il * EP;
+        mut[i] = e < E ? d.loc[(int64_t)(l0 + il) * d.l_rs + e] : 0.f;
+    }
+    __syncthreads();
+    float rowsum = 0.f;
+    if (tid < NSP) {
+#pragma unroll
+        for (int e = 0; e < EP; ++e) rowsum += lgt[tid * EP + e];
+    }
+    __syncthreads();
+    if (tid < NSP) lgt[tid * EP] = rowsum + (float)E * 0.91893853320467274178f;
+    __syncthreads();
+    const uint32_t v0 = (blockIdx.x * 4u + wave) * 32u;
+    if (v0 >= d.NV) return;                   // (no barriers below)
+    const uint32_t vr = v0 + j;
+    const bool active = vr < d.NV;
+    int64_t voff = 0, ooff = 0;
+    {
+        uint32_t o = active ? vr : d.NV - 1u;
+        for (int k = d.nv - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(o, d.vdiv[k]);
+            const int64_t idx = (int64_t)(o - q * d.vdiv[k].d);
+            o = q;
+            voff += idx * d.v_vs[k];
+            ooff += idx * d.v_os[k];
+        }
+    }
+    // ---- A operand: lane (j, h) holds w[32 st + j][2 step + h]; C operand of the first MFMA: the log-normaliser of
+    // the 16 rows this lane's accumulator registers stand for
+    float wreg[NST][EH];
+    f32x16 cinit[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+#pragma unroll
+        for (int step = 0; step < EH; ++step) wreg[st][step] = wt[(32 * st + j) * EP + 2 * step + h];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[st][r] = lgt[(32 * st + (r & 3) + 8 * (r >> 2) + 4 * h) * EP];
+    }
+    // ---- this lane's half of its value row (pad slots 0, like the loc table's)
+    float z[EH];
+#pragma unroll
+    for (int step = 0; step < EH; ++step) {
+        const int e = 2 * step + h;
+        const float x = d.val[voff + min(e, E - 1)];
+        z[step] = e < E ? x : 0.f;
+    }
+#ifdef ALAN_ABLATE
+    const bool store_on = d.dbg != 2, mfma_on = d.dbg != 4;
+    if (d.dbg == 1) {
+        if (z[0] + wreg[0][0] + cinit[0][0] == 12345.678f) d.out[0] = 1.f;
+        return;
+    }
+#else
+    constexpr bool store_on = true, mfma_on = true;
+#endif
+    // Buffer stores: address = descriptor base + (wave-uniform byte offset of the (loc row, scale tile), an SGPR) +
+    // (this lane's byte offset, ONE VGPR stepped from scale row to scale row).  With flat stores the compiler kept 16
+    // 64-bit row addresses per tile in vector registers (312 VGPRs at NST = 4: one wave per SIMD).  Lanes without a
+    // value row, and scale rows beyond NS, get an offset beyond the descriptor's range: the hardware drops the store.
+    const uint32_t row_bstride = (uint32_t)d.s_os * 4u;
+    const uint32_t OOB = 0x80000000u;          // >= the descriptor's range with or without the SGPR offset added (out spans < 2 GiB)
+    const uint32_t lane_boff = active ? (uint32_t)(ooff + 4 * h * d.s_os) * 4u : OOB;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)d.out_bytes, 0x00020000);
+    for (uint32_t il = l0; il < l1; ++il) {
+        const float *lp = mut + (size_t)(il - l0) * EP + h;
+        float dd[EH];
+#pragma unroll
+        for (int step = 0; step < EH; ++step) {
+            const float t = z[step] - lp[2 * step];
+            dd[step] = t * t;
+        }
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            f32x16 acc = cinit[st];
+            if (mfma_on) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[st][0], dd[0], cinit[st], 0, 0, 0);
+#pragma unroll
+                for (int step = 1; step < EH; ++step)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[st][step], dd[step], acc, 0, 0, 0);
+            } else {
+                acc[0] += dd[0] + dd[EH - 1];
+            }
+            const uint32_t tile_boff = (uint32_t)((int64_t)il * d.l_os + (int64_t)(32 * st) * d.s_os) * 4u;
+            if (!store_on) {
+                float q = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) q += acc[r];
+                if (q == 12345.678f) d.out[0] = q;
+            } else {
+                const int rows_ok = (int)d.NS - 32 * st - 4 * h;      // this lane's rows (r&3) + 8 (r>>2) below it exist
+                uint32_t vo = lane_boff;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(uint32_t, -acc[r] * d.out_scale + d.add_const), rsrc,
+                        row < rows_ok ? vo : OOB, tile_boff, 0);
+                    if (lane_boff != OOB) vo += (r & 3) == 3 ? 5u * row_bstride : row_bstride;
+                }
+            }
+        }
+    }
+}
+
+template <int EH>
+static void launch_normal_mfma(int nst, dim3 grid, hipStream_t stream, const EvPair &ev, const NormalDesc &d) {
+    const uint32_t lds = d.l_chunk * 2u * EH * sizeof(float);        // the loc rows of a workgroup
+    if (nst == 1)
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+    else if (nst == 2)
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 2>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+    else
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 4>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+}
+
+// d is filled except for l_chunk.  Declines (false) outside E <= 32, NS <= 128.
+static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const EvPair &ev) {
+    static const bool off = getenv("ALAN_NORMAL_MFMA") && atoi(getenv("ALAN_NORMAL_MFMA")) == 0;   // ablation knob
+    if (off || d.E > 32 || d.NS > 128) return false;
+    {   // lanes address the output by a 32-bit element offset from a wave-uniform base
+        int64_t span = (int64_t)(d.NL - 1) * d.l_os + (int64_t)(d.NS - 1) * d.s_os;
+        for (int k = 0; k < d.nv; ++k) span += (int64_t)(d.vdiv[k].d - 1) * d.v_os[k];
+        if (d.l_os < 0 || d.s_os < 0 || span >= (1ll << 29) - 8) return false;
+        d.out_bytes = (uint32_t)((span + 1) * 4);
+        // beyond the 256 MiB Infinity Cache the factor streams to HBM, where this kernel's 2 x 128-byte runs per store
+        // reach 2.3 TB/s against the vector kernel's 3.0 (K=100 unsplit, 1.2 GB); inside it, 4.2 against 2.9
+        static const bool force = getenv("ALAN_NORMAL_MFMA") && atoi(getenv("ALAN_NORMAL_MFMA")) == 2;
+        if (d.out_bytes > (224u << 20) && !force) return false;
+        for (int k = 0; k < d.nv; ++k)
+            if (d.v_os[k] < 0) return false;
+    }
+    const int nst = d.NS <= 32 ? 1 : d.NS <= 64 ? 2 : 4;
+    const uint32_t gx = (uint32_t)((NV + 127) / 128);
+    // ONE residency round: the workgroups that fit the chip at once (256 CUs x the waves per SIMD the kernel's
+    // registers allow: 204 at NST = 4, 84 at NST = 1), each walking as many loc rows as that takes.  (600 workgroups on
+    // 512 slots ran two rounds: 25 us of MFMA phase for 11 us of MFMAs.)
+    const uint32_t slots = 256u * (nst == 4 ? 2u : nst == 2 ? 3u : 4u);
+    uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, slots / std::max(1u, gx)));
+    if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
+    d.l_chunk = (d.NL + gy - 1) / gy;
+    gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
+    const dim3 grid(gx, gy);
+    const int eh = (d.E + 1) / 2;
+    switch (eh) {
+        case 1: launch_normal_mfma<1>(nst, grid, stream, ev, d); break;
+        case 2: launch_normal_mfma<2>(nst, grid, stream, ev, d); break;
+        case 3: launch_normal_mfma<3>(nst, grid, stream, ev, d); break;
+        case 4: launch_normal_mfma<4>(nst, grid, stream, ev, d); break;
+        case 5: launch_normal_mfma<5>(nst, grid, stream, ev, d); break;
+        case 6: launch_normal_mfma<6>(nst, grid, stream, ev, d); break;
+        case 7: case 8: launch_normal_mfma<8>(nst, grid, stream, ev, d); break;
+        case 9: launch_normal_mfma<9>(nst, grid, stream, ev, d); break;
+        case 10: launch_normal_mfma<10>(nst, grid, stream, ev, d); break;
+        case 11: case 12: launch_normal_mfma<12>(nst, grid, stream, ev, d); break;
+        default: launch_normal_mfma<16>(nst, grid, stream, ev, d);
+    }
+    return true;
+}
+
 // Returns ALAN_ERR_UNSUPPORTED when the canonical problem is not an outer-product Normal.
 int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
                             const EvPair &ev) {
@@ -250,6 +448,7 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
 #ifdef ALAN_ABLATE
     if (const char *e = getenv("ALAN_NORMAL_ABLATE")) d.dbg = atoi(e);
 #endif
+    if (try_normal_mfma(d, NV, stream, ev)) return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     {   // value rows contiguous in row-index order?  (voff(r) = r * E)
         bool contig = reinterpret_cast<uintptr_t>(d.val) % 16 == 0;   // (a workgroup's block starts 1 KiB-aligned)
         int64_t run = E;

@@ -309,7 +309,8 @@ def main():
     if res_prod:
         big = max(b for b, _ in res_prod)
         sel = [m for b, m in res_prod if b == big]
-        out["producer"] = {"kernel": "alan::reduce_group_kernel<float, NORMAL> (fused Normal log-prob producer of F)",
+        out["producer"] = {"kernel": "alan::normal_mfma_kernel (fused Normal log-prob producer of F: v_mfma_f32_32x32x2_f32 over "
+                                     "the event dim, store-bound)",
                            "us_per_launch": sum(sel) / len(sel) * 1e3, "bytes_written": big,
                            "launches_timed": len(sel)}
     if not args.no_extras:

@@ -1,4 +1,4 @@
-// Floor probe: how fast can ANY kernel read N bytes once on this chip, at the literal movielens size
+// Floor probe: how fast can ANY kernel read (or write) N bytes once on this chip, at the literal movielens size
 // (32.5 MB, cache-resident, ~1 residency wave) and in the bandwidth regime (2 GB)?  Sets the yardstick for
 // rows_kernel's achieved GB/s.  Build: hipcc -O3 --offload-arch=gfx950 tools/readfloor.hip -o tools/_build/readfloor
 #include <hip/hip_runtime.h>
@@ -91,6 +91,12 @@ int main() {
             printf("%8.1f MB blocks=%5d  unr1 %8.2f us %7.0f GB/s | unr4 %8.2f us %7.0f GB/s | unr8 %8.2f us %7.0f GB/s\n",
                    bytes / 1e6, blocks, u1, bytes / u1 / 1e3, u4, bytes / u4 / 1e3, u8, bytes / u8 / 1e3);
             fflush(stdout);
+        }
+        // write floor: a plain 16-byte-per-lane fill of the same buffer (what the factor PRODUCER is bounded by)
+        for (int blocks : {1024, 2048, 4096, 8192}) {
+            const float uw = time_us([&](hipEvent_t a, hipEvent_t b) {
+                hipExtLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, a, b, 0, p, n4); }, 30, s);
+            printf("%8.1f MB FILL blocks=%5d %8.2f us %7.0f GB/s\n", bytes / 1e6, blocks, uw, bytes / uw / 1e3);
         }
         // cold-ish: a fill (write) of the same buffer between reads, as the producer does in the ELBO
         {
