@@ -393,7 +393,7 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
 
 // Returns ALAN_ERR_UNSUPPORTED when the canonical problem is not an outer-product Normal.
 int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
-                            const EvPair &ev) {
+                            const EvPair &ev, bool dry) {
     if (c.nf != 3 || c.nr != 1) return ALAN_ERR_UNSUPPORTED;
     if (c.f[0].scale != 1.f || c.f[2].scale == 2.f) return ALAN_ERR_UNSUPPORTED;   // weighted / flagged terms: generic kernel
     for (int f = 0; f < 3; ++f)
@@ -429,6 +429,7 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
         }
     }
     if (NV * d.NL * d.NS < 65536) return ALAN_ERR_UNSUPPORTED;  // tiny: the generic kernel is fine
+    if (dry) return ALAN_OK;
     d.val = (const float *)c.f[0].p;
     d.loc = (const float *)c.f[1].p;
     d.scl = (const float *)c.f[2].p;

@@ -31,6 +31,8 @@ struct GroupDesc {
 // kernel walks its 1.4 KB descriptor with run-time loops, i.e. a chain of ~10 dependent scalar loads, which
 // is most of the duration of a launch that reads a few hundred elements.
 constexpr int SMALL_NK = 3, SMALL_NR = 2;
+constexpr int SMALL_MULTI = 4;     // problems per reduce_small_multi_kernel launch
+
 struct SmallDesc {
     const float *f[MAXF];
     const float *w;
@@ -85,6 +87,9 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
 // Small-problem variant of the group kernel; ALAN_ERR_UNSUPPORTED when the problem does not fit SmallDesc.
 int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
                      hipStream_t stream, const EvPair &ev);
+// The two halves of it, for alan_reduce_batch: fill a SmallDesc; launch up to SMALL_MULTI of them as one kernel.
+int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype, SmallDesc &sd);
+int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream);
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
 // fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the
@@ -101,7 +106,8 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
                 size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 
 // normal.hip: register-blocked Normal producer (value / loc / scale on disjoint dims).
+// (dry: only answer whether it would take the problem)
 int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
-                            const EvPair &ev);
+                            const EvPair &ev, bool dry = false);
 
 }  // namespace alan

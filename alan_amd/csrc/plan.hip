@@ -265,9 +265,73 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
     return ALAN_OK;
 }
 
+// alan_reduce_batch: is this problem one launch of the small kernel?  Fills what that launch needs.
+static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
+    uint32_t keep, red, plate;
+    if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
+    mode = d.mode;
+    if (mode == ALAN_MODE_WEXPSUM) return false;
+    if (mode == ALAN_MODE_LSE && red == 0) mode = ALAN_MODE_SUM;
+    Canon c;
+    if (canonicalise(d, keep, red, d.out, c) != ALAN_OK) return false;
+    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI;
+    const float out_scale = producer ? d.out.scale : 1.f;
+    if ((mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE) &&
+        try_launch_normal_outer(c, mode == ALAN_MODE_NORMAL_LOGSCALE, out_scale, d.add_const, nullptr, EvPair(), true) !=
+            ALAN_ERR_UNSUPPORTED)
+        return false;
+    if (plan_rows(c, mode, d.out.dtype).ok) return false;
+    GroupDesc gd;
+    if (plan_group(c, d.out.dtype, d.add_const, gd, gl, out_scale) != ALAN_OK) return false;
+    if (build_small(c, gd, mode, d.out.dtype, sd) != ALAN_OK) return false;
+    if (gd.n_out == 0) gl.grid = 0;
+    return true;
+}
+
 }  // namespace alan
 
 using namespace alan;
+
+extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t n, void *stream_) {
+    if (!descs || n < 0) return ALAN_ERR_BAD_DESC;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i]) return ALAN_ERR_BAD_DESC;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the problems are independent, so their order is free: every small one first, SMALL_MULTI per launch, then the
+    // others one by one
+    SmallDesc sd[SMALL_MULTI];
+    GroupLaunch gl[SMALL_MULTI];
+    int mode[SMALL_MULTI], m = 0, lone = -1;
+    auto flush_small = [&]() -> int {
+        int rc = ALAN_OK;
+        if (m >= 2)
+            rc = launch_small_multi(sd, gl, mode, m, stream);
+        else if (m == 1)
+            rc = alan_reduce(descs[lone], nullptr, 0, stream_);
+        m = 0;
+        return rc;
+    };
+    bool other[64];
+    if (n > 64) return ALAN_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+        other[i] = !prepare_small(*descs[i], sd[m], gl[m], mode[m]);
+        if (other[i]) continue;
+        lone = i;
+        if (++m == SMALL_MULTI) {
+            const int rc = flush_small();
+            if (rc != ALAN_OK) return rc;
+        }
+    }
+    int rc = flush_small();
+    if (rc != ALAN_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (!other[i]) continue;
+        if (alan_reduce_workspace_bytes(descs[i]) != 0) return ALAN_ERR_WORKSPACE;
+        rc = alan_reduce(descs[i], nullptr, 0, stream_);
+        if (rc != ALAN_OK) return rc;
+    }
+    return ALAN_OK;
+}
 
 extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;

@@ -15,6 +15,8 @@
 #include <type_traits>
 
 #include "common.h"
+#include <cstddef>
+
 #include "plan.h"
 
 namespace alan {
@@ -194,15 +196,15 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
 
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool BLOCK>
-__global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, const int logG) {
+__device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id) {
     typedef float T;
     const uint32_t G = BLOCK ? 256u : (1u << logG);
     uint32_t grp, gl;
     if (BLOCK) {
-        grp = blockIdx.x;
+        grp = block_id;
         gl = threadIdx.x;
     } else {
-        const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t gid = block_id * 256u + threadIdx.x;
         grp = gid >> logG;
         gl = gid & (G - 1u);
     }
@@ -265,6 +267,70 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
     }
 }
 
+template <int MODE, bool BLOCK>
+__global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, const int logG) {
+    small_body<MODE, BLOCK>(d, logG, blockIdx.x);
+}
+
+// Several INDEPENDENT small problems in one launch (alan_reduce_batch): the per-variable log-prob producers of a
+// plate are a handful of launch-latency-bound kernels (4-5 us each inside a replayed graph) that do not depend on
+// each other.  Workgroups are dealt to the problems in order; mode and lane-group shape are run-time here.
+struct SmallMulti {
+    int32_t n;
+    int32_t mode[SMALL_MULTI], logG[SMALL_MULTI], block[SMALL_MULTI];
+    uint32_t first_block[SMALL_MULTI + 1];
+    SmallDesc d[SMALL_MULTI];
+};
+
+template <int MODE>
+__device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool block, uint32_t bid) {
+    if (block)
+        small_body<MODE, true>(d, 8, bid);
+    else
+        small_body<MODE, false>(d, logG, bid);
+}
+
+__global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMulti m) {
+    int p = 0;
+    while (p + 1 < m.n && blockIdx.x >= m.first_block[p + 1]) ++p;       // workgroup-uniform
+    const uint32_t bid = blockIdx.x - m.first_block[p];
+    // m.d[p] through the kernel-argument segment itself (scalar loads at a uniform offset): indexing the by-value
+    // struct with a run-time p makes the compiler copy all of it to scratch first
+    typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+    const SmallDesc &d = *reinterpret_cast<const SmallDesc *>(
+        (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallMulti, d) + (size_t)p * sizeof(SmallDesc)));
+    const bool block = m.block[p] != 0;
+    const int logG = m.logG[p];
+    switch (m.mode[p]) {
+        case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE>(d, logG, block, bid); break;
+        case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM>(d, logG, block, bid); break;
+        case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL>(d, logG, block, bid); break;
+        case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE>(d, logG, block, bid); break;
+        case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
+        default: break;                                                    // (WEXPSUM is not batched)
+    }
+}
+
+int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream) {
+    if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;
+    SmallMulti m;
+    std::memset(&m, 0, sizeof(m));
+    m.n = n;
+    uint32_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        m.mode[i] = mode[i];
+        m.logG[i] = gl[i].logG;
+        m.block[i] = gl[i].block ? 1 : 0;
+        m.first_block[i] = blocks;
+        blocks += gl[i].grid;
+        m.d[i] = sd[i];
+    }
+    m.first_block[n] = blocks;
+    if (blocks == 0) return ALAN_OK;
+    hipLaunchKernelGGL(reduce_small_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+}
+
 template <int MODE>
 static void launch_small_T(const SmallDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.block)
@@ -275,14 +341,12 @@ static void launch_small_T(const SmallDesc &sd, const GroupLaunch &gl, hipStream
                               ev.stop, 0, sd, gl.logG);
 }
 
-int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
-                     hipStream_t stream, const EvPair &ev) {
+int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype, SmallDesc &sd) {
     if (compute_dtype != ALAN_F32 || gd.out_dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
     if (c.nk > SMALL_NK || c.nr > SMALL_NR || c.nf < 1) return ALAN_ERR_UNSUPPORTED;
     if (c.n_out * c.n_red > (1ll << 22)) return ALAN_ERR_UNSUPPORTED;   // big problems are not launch-bound
     if (mode == ALAN_MODE_WEXPSUM && (!c.w.p || c.w.dtype != ALAN_F32)) return ALAN_ERR_UNSUPPORTED;
     const int64_t lim = (1ll << 31) - 1;
-    SmallDesc sd;
     std::memset(&sd, 0, sizeof(sd));
     for (int k = 0; k < SMALL_NK; ++k) sd.kdiv[k] = make_fastdiv(1);
     for (int k = 0; k < SMALL_NR; ++k) sd.rdiv[k] = make_fastdiv(1);
@@ -326,6 +390,14 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
     sd.nf = c.nf;
     sd.out_scale = gd.out_scale;
     sd.add_const = (float)gd.add_const;
+    return ALAN_OK;
+}
+
+int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
+                     hipStream_t stream, const EvPair &ev) {
+    SmallDesc sd;
+    const int rc = build_small(c, gd, mode, compute_dtype, sd);
+    if (rc != ALAN_OK) return rc;
     if (gd.n_out == 0) return ALAN_OK;
     switch (mode) {
         case ALAN_MODE_LSE: launch_small_T<ALAN_MODE_LSE>(sd, gl, stream, ev); break;

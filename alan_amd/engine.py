@@ -74,7 +74,7 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
     algo = sum(x.numel() * x.element_size() for x, _ in factors) + out.numel() * out.element_size()
     if weight is not None:
         algo += weight[0].numel() * weight[0].element_size()
-    N.run_reduce(desc, device, algo)
+    N.run_reduce(desc, device, algo, keepalive=([x for x, _ in factors], out, weight, lse_out))
 
 
 def _result_dtype(tensors):
@@ -228,6 +228,7 @@ class _Tokens:
 def reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     """Fused ``sum(factors)`` -> log-sum-exp over ``reduce`` -> sum over ``plate``.
     Returns (tensor, dims)."""
+    N.flush()          # consumers read what queued producer launches write (native.deferring)
     tok = _Tokens()
     factors = [(x, tok.many(d)) for x, d in factors]
     for d in (*reduce, *plate):
@@ -302,6 +303,7 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
     launch, the [plate, l, s, K] factor never materialised (alan_normal_lse).  value = (tensor, (two dims: the plate
     and K, any order)); loc / scale = (tensor, (one dim,)); smalls = [(tensor, dims within {plate, K})].
     Returns (out, (loc dim, scale dim)) or None when the library declines."""
+    N.flush()          # consumers read what queued producer launches write (native.deferring)
     (xv, dv), (xl, dl), (xs, ds) = value, loc, scale
     tensors = [xv, xl, xs, *[x for x, _ in smalls]]
     if not all(x.is_cuda and x.dtype == t.float32 for x in tensors) or len(smalls) > 4:
@@ -417,6 +419,7 @@ def plan_elimination(dimsets, sizes, Ks):
 def contract(factors, Ks, plate=()):
     """reduce_Ks on positional factors, with the trailing plate sum fused into the last launch.
     Returns (result, dims, per-step record) -- the record is what sample_Ks-style consumers need."""
+    N.flush()          # consumers read what queued producer launches write (native.deferring)
     tok = _Tokens()
     factors = [(x, tok.many(d)) for x, d in factors]
     sizes = _space(factors)

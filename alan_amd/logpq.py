@@ -13,6 +13,7 @@ first-class dims.  Differences from the reference that matter for the GPU (resul
   * reduce_Ks and the plate sum are one fused contraction (engine.contract with plate=...);
   * factors are produced with the plate dims outermost and the group's own K innermost.
 """
+import contextlib
 import math
 
 import torch as t
@@ -23,6 +24,7 @@ from .dims import PT, ExpPT, LazyNormalPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
 from .dist import TorchDimDist
+from . import native as N
 from .timeseries import Timeseries
 
 
@@ -45,6 +47,8 @@ def logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scop
                          dimcache=dimcache, **chunks[i]))
     # the chunks' results are summed (logpq.py:151-153) -- in one stacked reduction rather than a chain of adds
     lpq = parts[0]
+    if len(parts) > 1 or sharded:
+        N.flush()                  # a data-only plate's chunk results may still be queued producer launches
     if len(parts) > 1:
         for p in parts[1:]:
             assert set(p.ids) == set(lpq.ids)
@@ -139,8 +143,9 @@ def plate_factors(name, P, Q, sample, inputs_params, data, extra_log_factors, sc
             lps.append(lp)
         elif kind == "data":
             assert sample.get(child) is None
-            lp, _ = P.flat_prog[child].log_prob(data[child], scope, dim_order=(active_platedims, ()),
-                                                dimcache=dimcache)
+            with N.may_defer():          # a factor of this plate's contraction and nothing else
+                lp, _ = P.flat_prog[child].log_prob(data[child], scope, dim_order=(active_platedims, ()),
+                                                    dimcache=dimcache)
             lps.append(lp)
         else:
             facs, k_plain, k_ts, k_init = logPQ_group(
@@ -164,9 +169,11 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         platedim = all_platedims[name]
         inner = update_scope(update_scope(scope, inputs_params), sample)
         lp = None
+        only = len(Q.grouped_prog) == 1 and prev_lpq is None      # then the result is a factor of the parent's launch
         for _, child, _ in Q.entries():
-            f, _ = P.flat_prog[child].log_prob(data[child], inner, dim_order=(active_platedims, ()),
-                                               dimcache=dimcache, sum_dims=(platedim,))
+            with (N.may_defer() if only else contextlib.nullcontext()):
+                f, _ = P.flat_prog[child].log_prob(data[child], inner, dim_order=(active_platedims, ()),
+                                                   dimcache=dimcache, sum_dims=(platedim,))
             lp = f if lp is None else pt_add(lp, f)
         if prev_lpq is not None:
             assert set(lp.ids) == set(prev_lpq.ids)
@@ -224,11 +231,14 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
     if single:
         (var,) = prog_P
         tP, tQ = prog_P[var].tdd(scope, dimcache), prog_Q[var].tdd(scope, dimcache)
-        pq = TorchDimDist.log_p_minus_q(tP, tQ, sample[var], order, own, math.log(K))
+        # (these results only ever feed the plate's contraction -- or reduce_logQ, itself a launch: may_defer)
+        with N.may_defer():
+            pq = TorchDimDist.log_p_minus_q(tP, tQ, sample[var], order, own, math.log(K))
         if pq is not None:                      # log P - log Q - log K in one launch
             return [pq], (Kdim,), (), ()
-        lp = tP.log_prob_pt(sample[var], dim_order=order)
-        neg_q = tQ.log_prob_pt(sample[var], dim_order=order, affine=(-1.0, -math.log(K), own))
+        with N.may_defer():
+            lp = tP.log_prob_pt(sample[var], dim_order=order)
+            neg_q = tQ.log_prob_pt(sample[var], dim_order=order, affine=(-1.0, -math.log(K), own))
         if not set(neg_q.ids) <= own:           # log Q carries a parent K: reduce it first (Sampler.py:118-134)
             lq = sampler.reduce_logQ(neg_q, active_platedims, Kdim)
             neg_q = PT(t.sub(-math.log(K), lq.x), lq.dims)
@@ -243,7 +253,8 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         assert isinstance(x, PT)
         if not isinstance(prog_P[var], Timeseries) and not isinstance(prog_Q[var], Timeseries):
             tP, tQ = prog_P[var].tdd(scope, dimcache), prog_Q[var].tdd(scope, dimcache)
-            pq = TorchDimDist.log_p_minus_q(tP, tQ, x, order, own, 0.0 if pqs else math.log(K))
+            with N.may_defer():
+                pq = TorchDimDist.log_p_minus_q(tP, tQ, x, order, own, 0.0 if pqs else math.log(K))
             if pq is not None:
                 pqs.append(pq)
                 continue

@@ -4,6 +4,7 @@ ctypes binding of libalan_mi355.so (C ABI in include/alan_mi355.h).
 There is deliberately no fallback: if the shared library is missing, or a tensor is not on a
 HIP device, the call raises.  PyTorch is used only for device memory and the current stream.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -87,6 +88,8 @@ def lib():
         L.alan_reduce.argtypes = [C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_reduce_workspace_bytes.restype = C.c_size_t
         L.alan_reduce_workspace_bytes.argtypes = [C.POINTER(ReduceDesc)]
+        L.alan_reduce_batch.restype = C.c_int
+        L.alan_reduce_batch.argtypes = [C.POINTER(C.POINTER(ReduceDesc)), C.c_int32, C.c_void_p]
         L.alan_reduce_backward.restype = C.c_int
         L.alan_reduce_backward.argtypes = [C.POINTER(BackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_reduce_backward_workspace_bytes.restype = C.c_size_t
@@ -121,7 +124,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_backward",
+EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
@@ -165,8 +168,67 @@ def current_stream(device):
 _TIMER = [None]     # set by profiling.KernelTimer
 
 
-def run_reduce(desc, device, algo_bytes=0):
+# ---- deferred small launches -------------------------------------------------------------------------------------
+# The per-variable log-prob producers of a plate are independent, launch-latency-bound kernels (4-5 us each even
+# inside a replayed HIP graph).  Inside ``deferring()`` (one gradient-free evaluation) a producer issued under
+# ``may_defer()`` is only queued; the queue goes out as ONE multi-problem launch (alan_reduce_batch) as soon as
+# anything else is launched, or at the end.  Stream order is unchanged, so this is invisible to every later alan
+# launch; it is NOT invisible to a torch op that reads a queued output -- hence the explicit ``may_defer()`` at the
+# call sites whose result only ever feeds another alan launch (logpq.py), and ``flush()`` for anyone in doubt.
+_PENDING = []            # [(desc, device, keepalive tensors)]
+_DEFER = [0, 0]          # nesting of deferring() / may_defer()
+DEFER_SMALL_LAUNCHES = True
+
+
+@contextlib.contextmanager
+def deferring():
+    _DEFER[0] += 1
+    try:
+        yield
+        if _DEFER[0] == 1:
+            flush()
+    finally:
+        _DEFER[0] -= 1
+        if _DEFER[0] == 0:
+            _PENDING.clear()          # (only non-empty after an exception)
+
+
+@contextlib.contextmanager
+def may_defer():
+    _DEFER[1] += 1
+    try:
+        yield
+    finally:
+        _DEFER[1] -= 1
+
+
+def flush():
+    """Issue every queued launch now (in order)."""
+    if not _PENDING:
+        return
+    items = list(_PENDING)
+    _PENDING.clear()
     L = lib()
+    device = items[0][1]
+    if len(items) == 1:
+        rc = L.alan_reduce(C.byref(items[0][0]), None, 0, current_stream(device))
+        check(rc, "alan_reduce")
+        return
+    arr = (C.POINTER(ReduceDesc) * len(items))(*[C.pointer(d) for d, _, _ in items])
+    rc = L.alan_reduce_batch(arr, len(items), current_stream(device))
+    check(rc, "alan_reduce_batch")
+
+
+def run_reduce(desc, device, algo_bytes=0, keepalive=()):
+    L = lib()
+    if (DEFER_SMALL_LAUNCHES and _DEFER[0] and _DEFER[1] and _TIMER[0] is None and not t.is_grad_enabled()
+            and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
+            and (not _PENDING or _PENDING[0][1] == device)):
+        _PENDING.append((desc, device, keepalive))
+        if len(_PENDING) >= 8:
+            flush()
+        return
+    flush()
     if _TIMER[0] is not None:
         _TIMER[0].attach(desc, algo_bytes)
     nbytes = L.alan_reduce_workspace_bytes(C.byref(desc))
@@ -183,6 +245,7 @@ def run_reduce_backward(desc, device):
     """All gradients of an LSE call in one pass (alan_reduce_backward).  False when the problem does not fit
     the streaming kernel -- the caller then falls back to one WEXPSUM launch per factor."""
     L = lib()
+    flush()
     nbytes = L.alan_reduce_backward_workspace_bytes(C.byref(desc))
     ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
     rc = L.alan_reduce_backward(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,
@@ -196,6 +259,7 @@ def run_reduce_backward(desc, device):
 def run_normal_lse(desc, device):
     """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
     L = lib()
+    flush()
     nbytes = L.alan_normal_lse_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         return False
@@ -215,6 +279,7 @@ def chain_logmmexp(ms, want_chain=False):
     ``tree`` holds every round of the reference's pairwise tree (what the backward walks)."""
     require_device(ms, "timeseries factor")
     L = lib()
+    flush()
     batched = ms.ndim == 4
     m4 = ms if batched else ms.unsqueeze(0)
     B, T, K, K2 = m4.shape

@@ -3,6 +3,8 @@
 ``elbo_vi / elbo_rws / elbo_nograd`` (Sample.py:69-148 of the reference).  The returned value is a
 0-dim tensor on the Problem's device; every K dim has been summed out on the HIP engine.
 """
+import contextlib
+
 import torch as t
 
 from .dims import PT, sum_positional
@@ -108,13 +110,16 @@ class Sample:
         else:
             from .model import empty_tree
             extra = empty_tree(self.P.plate)
-        lp, *_ = logPQ_plate(
-            name=None, P=self.P.plate, Q=self.Q.plate, sample=self._as_pt(sample),
-            inputs_params=problem.inputs_params_pt(), data=problem.data_pt(),
-            extra_log_factors=extra, scope={}, active_platedims=[], all_platedims=self.all_platedims,
-            groupvarname2Kdim=self.groupvarname2Kdim,
-            varname2groupvarname=self._v2g(),
-            sampler=self.sampler, computation_strategy=computation_strategy, dimcache={})
+        from . import native as N
+        # gradient-free evaluations may queue their small independent producer launches (native.deferring)
+        with (contextlib.nullcontext() if t.is_grad_enabled() else N.deferring()):
+            lp, *_ = logPQ_plate(
+                name=None, P=self.P.plate, Q=self.Q.plate, sample=self._as_pt(sample),
+                inputs_params=problem.inputs_params_pt(), data=problem.data_pt(),
+                extra_log_factors=extra, scope={}, active_platedims=[], all_platedims=self.all_platedims,
+                groupvarname2Kdim=self.groupvarname2Kdim,
+                varname2groupvarname=self._v2g(),
+                sampler=self.sampler, computation_strategy=computation_strategy, dimcache={})
         assert lp.dims == (), "every K and plate dim should have been eliminated"
         return lp.x
 

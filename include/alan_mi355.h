@@ -107,6 +107,12 @@ size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *desc);
  * 256-byte aligned, and stay alive until the stream has passed this call. */
 int alan_reduce(const alan_reduce_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* n <= 64 INDEPENDENT alan_reduce problems (no one reads another's output; none needs a workspace or carries timing
+ * events).  The small single-stage ones among them -- the per-variable log-prob producers of a plate
+ * (TorchDimDist.py:127-162 per variable, logpq.py:221-222), each a launch-latency-bound kernel of its own otherwise --
+ * go out first, up to 4 problems per kernel launch; the others follow as alan_reduce would launch them. */
+int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t n, void *stream);
+
 /* Backward of an ALAN_MODE_LSE call (with or without PLATE dims) with respect to EVERY factor in one pass over the
  * largest one -- what autograd derives from utils.py:218-220 + logpq.py:149:
  *     grad factor_f = sum_{dims not in f}  weight * exp(sum_f factor_f - lse)

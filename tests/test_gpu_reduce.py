@@ -1,6 +1,7 @@
 """GPU parity tests of the HIP contraction engine (through the C ABI) against the CPU oracle and
 the reference-generated golden fixtures.  Tolerances: fp32 results within 2e-5 relative / 2e-5
 absolute of the reference's own fp32 output (north_star: ELBO within 1e-4 relative); fp64 1e-10."""
+import ctypes
 import itertools
 import math
 
@@ -505,3 +506,56 @@ def test_normal_p_minus_q_single_launch(q_log_scale):
     Q3 = D.TorchDimDist(t.distributions.Normal, loc=PT(t.randn(M, Ev, generator=g).to(DEV).requires_grad_(True), (dm,)),
                         scale=PT(qraw.exp(), (dm,)))
     assert D.TorchDimDist.log_p_minus_q(P, Q3, x, ([dm], [dz]), own, math.log(K)) is None
+
+
+# ------------------------------------------------------------------ deferred small launches (alan_reduce_batch)
+def test_deferred_producers_go_out_as_one_launch_and_match_immediate_ones():
+    """Independent per-variable producers queued under native.deferring() / may_defer() and issued by
+    alan_reduce_batch (small ones as ONE multi-problem kernel, the big factor on its own) write bit-identical results
+    to the same launches issued one by one."""
+    from alan_amd.dims import Dim
+    g = t.Generator().manual_seed(11)
+    M, K, Ev = 300, 30, 18
+    dm, dz, dmu, dpsi, dn = Dim("plate_1", M), Dim("K_z", K), Dim("K_mu", K), Dim("K_psi", K), Dim("plate_2", 5)
+    da = Dim("a", 7)
+    r = lambda *s: t.randn(*s, generator=g).to(DEV)
+    z, mu, psi = r(M, K, Ev), r(K, Ev), r(K, Ev)
+    obs, logits = (t.rand(M, 5, generator=g) < 0.5).float().to(DEV), r(M, K, 5)
+    calls = [
+        lambda: E.normal_logprob_pq((mu, (dmu,)), ((t.zeros(Ev, device=DEV), ()), (t.ones(Ev, device=DEV), ()), False),
+                                    ((r(Ev), ()), (r(Ev), ()), True), (dmu,), affine=(1.0, -math.log(K))),
+        lambda: E.normal_logprob_pq((psi, (dpsi,)), ((t.zeros(Ev, device=DEV), ()), (t.ones(Ev, device=DEV), ()), False),
+                                    ((r(Ev), ()), (r(Ev), ()), True), (dpsi,), affine=(1.0, -math.log(K))),
+        lambda: E.normal_logprob((z, (dm, dz)), (mu, (dmu,)), (psi.exp(), (dpsi,)), (dm, dmu, dpsi, dz)),   # the big one
+        lambda: E.normal_logprob((z, (dm, dz)), (r(M, Ev), (dm,)), (r(M, Ev), (dm,)), (dm, dz), log_scale=True,
+                                 affine=(-1.0, -math.log(K))),
+        lambda: E.bernoulli_logprob((obs, (dm, dn)), (logits, (dm, dz, dn)), (dm, dz)),
+        lambda: E.normal_logprob((r(7, 3), (da,)), (r(3), ()), (t.ones(3, device=DEV), ()), (da,)),
+    ]
+    gen_state = g.get_state()
+    want = [c() for c in calls]
+    t.cuda.synchronize()
+    g.set_state(gen_state)
+    assert not N._PENDING
+    with t.no_grad(), N.deferring():
+        with N.may_defer():
+            got = [c() for c in calls]
+            assert len(N._PENDING) == len(calls)          # nothing launched yet
+        # a consumer flushes the queue before it reads
+        total, _ = E.reduce_factors([(got[3], (dm, dz)), (got[4], (dm, dz))], reduce=(dz,), plate=(dm,))
+        assert not N._PENDING
+    for a, b in zip(got, want):
+        assert t.equal(a, b)
+    ref, _ = E.reduce_factors([(want[3], (dm, dz)), (want[4], (dm, dz))], reduce=(dz,), plate=(dm,))
+    assert t.equal(total, ref)
+    # outside deferring(), or with gradients enabled, may_defer() is inert
+    with N.may_defer():
+        calls[0]()
+        assert not N._PENDING
+
+
+def test_reduce_batch_c_abi_orders_and_rejects():
+    L = N.lib()
+    assert L.alan_reduce_batch(None, 0, None) == -1
+    arr = (ctypes.POINTER(N.ReduceDesc) * 1)(ctypes.POINTER(N.ReduceDesc)())
+    assert L.alan_reduce_batch(arr, 1, None) == -1       # null descriptor
