@@ -20,7 +20,7 @@ from .moments import Marginals, RawMoment, CompoundMoment, mean, mean2, var, var
 from .contract import (reduce_Ks, collect_lps, logsumexp_sum, logsumexp_dims, logmeanexp_dims,
                        chain_logmmexp)
 
-from .training import GraphedStep
+from .training import GraphedStep, GraphedEval
 
 samplers = [CategoricalSampler, PermutationSampler]
 

@@ -53,3 +53,33 @@ class GraphedStep:
     def __call__(self):
         self.graph.replay()
         return self.elbo
+
+
+class GraphedEval:
+    """``ev = GraphedEval(problem, K); elbo = ev()``: ``problem.sample(K).elbo_nograd()`` with FRESH particles on every
+    call -- the quantity the reference's runner times per iteration (examples/basic_runner.py:86-97) -- captured once
+    as a HIP graph: sampling kernels (the generator's Philox state is registered with the graph), log-prob producers
+    and the contraction all replay on the device."""
+
+    def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3):
+        if problem.device.type != "cuda":
+            raise Exception("GraphedEval needs the Problem on the GPU")
+        self.problem, self.K, self.strategy = problem, K, computation_strategy
+        side = t.cuda.Stream()
+        side.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(side):
+            for _ in range(warmup):
+                self._iteration()
+        t.cuda.current_stream().wait_stream(side)
+        t.cuda.synchronize()
+        self.graph = t.cuda.CUDAGraph()
+        with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            self.elbo = self._iteration()
+
+    def _iteration(self):
+        with t.no_grad():
+            return self.problem.sample(self.K, reparam=False).elbo_nograd(self.strategy)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.elbo

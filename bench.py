@@ -341,6 +341,21 @@ def main():
         dt_se = (time.perf_counter() - t0) / 20
         out["sample_plus_elbo"] = {"ms_per_iter": dt_se * 1e3, "iters_per_s": 1 / dt_se,
                                    "launch": "eager (a fresh sample every iteration)"}
+        try:                                      # the same iteration captured once (alan_amd.GraphedEval)
+            import alan_amd as _alan
+            ev = _alan.GraphedEval(prob, K, strat)
+            for _ in range(3):
+                ev()
+            t.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                v_se = ev()
+            t.cuda.synchronize()
+            dt_g = (time.perf_counter() - t0) / 100
+            out["sample_plus_elbo"].update({"graph_ms_per_iter": dt_g * 1e3, "graph_iters_per_s": 1 / dt_g,
+                                            "graph_last_elbo": float(v_se)})
+        except Exception as e:
+            out["sample_plus_elbo"]["graph_error"] = f"{type(e).__name__}: {e}"
         # the optional fused plate step (dist.FUSE_PLATE_STEP: producer + log-sum-exp + plate sum in one launch, the
         # factor never materialised) -- off by default, so `value` and `roofline` above describe the default path
         from alan_amd import dist as _dist

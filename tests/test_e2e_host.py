@@ -204,3 +204,19 @@ def test_graphed_vi_step_does_not_depend_on_host_synchronisation():
 
     for a, b in zip(run(True), run(False)):
         assert t.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_graphed_eval_draws_fresh_particles_and_agrees_with_eager_in_distribution():
+    """GraphedEval = sample() + elbo_nograd() per replay (basic_runner.py:86-97 of the reference): every replay sees new
+    particles; its mean agrees with the mean of eagerly drawn evaluations."""
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda")
+    t.manual_seed(0)
+    ev = alan.GraphedEval(prob, 10)
+    vals = t.tensor([float(ev()) for _ in range(200)], dtype=t.float64)
+    assert len(set(vals.tolist())) > 150
+    eager = t.tensor([float(prob.sample(10, reparam=False).elbo_nograd(alan.no_checkpoint)) for _ in range(200)],
+                     dtype=t.float64)
+    se = float((vals.var() / 200 + eager.var() / 200).sqrt())
+    assert abs(float(vals.mean() - eager.mean())) < 5 * se + 1e-3 * abs(float(eager.mean())), (vals.mean(), eager.mean(), se)
