@@ -1,12 +1,13 @@
-// normal_outer kernel: register-blocked fast path of alan_reduce(mode = ALAN_MODE_NORMAL), the fused
-// PRODUCER of the big log-prob factor (replaces TorchDimDist.py:127-162 + utils.py:147-152 for
-// td.Normal when value, loc and scale carry DISJOINT first-class dims -- e.g. movielens
+// The outer-product Normal producer: fast paths of alan_reduce(mode = ALAN_MODE_NORMAL / NORMAL_LOGSCALE), the fused
+// PRODUCER of the big log-prob factor.  Two kernels: normal_mfma_kernel (matrix cores, the default while the factor
+// fits the Infinity Cache; further down) and normal_outer_kernel (vector unit, register-blocked; below).
+// Replaces TorchDimDist.py:127-162 + utils.py:147-152 for td.Normal when value, loc and scale carry DISJOINT first-class dims -- e.g. movielens
 //   z[plate_1, K_z, d] ~ Normal(mu_z[K_mu, d], exp(psi_z)[K_psi, d])  ->  F[plate_1, K_mu, K_psi, K_z]).
 //
 //   out[v, l, s] = -sum_e (value[v,e] - loc[l,e])^2 * (0.5 / scale[s,e]^2) - sum_e log scale[s,e] - E log sqrt(2 pi)
 //
 // (same arithmetic as torch.distributions.Normal.log_prob: no expanded square, so no cancellation.)
-// A thread owns one value row in registers and walks the (loc row, scale row) cross product; loc/scale
+// normal_outer_kernel: a thread owns one value row in registers and walks the (loc row, scale row) cross product; loc/scale
 // rows are workgroup-uniform, so they come from LDS as broadcast reads: ~1.4 issue slots per (output, e).
 // The event length is a template parameter (tables zero-padded to it): the LDS reads of a scale row are then
 // straight-line and issue back to back -- with run-time bounds every 16-byte read sat in its own basic block
