@@ -525,8 +525,38 @@ Dim creation order: under a Split, torchdim lowers movielens' ``z @ x`` to 19,00
 dot products (300 us at K=100), nested vmap to one batched GEMM (10 us)."""
 
 
+_PLAIN_EXP = {}      # code object -> (code object, bool)
+
+
+def _is_plain_exp(fn):
+    """Is ``fn`` exactly ``lambda v: v.exp()`` / ``torch.exp(v)`` (the usual way to write a positive scale,
+    e.g. movielens' ``lambda psi_z: psi_z.exp()``)?  Decided once per code object by symbolic tracing."""
+    code = getattr(fn, "__code__", None)
+    if code is None or code.co_argcount != 1 or getattr(fn, "__closure__", None):
+        return False
+    hit = _PLAIN_EXP.get(id(code))
+    if hit is not None and hit[0] is code:
+        return hit[1]
+    ok = False
+    try:
+        import torch.fx
+        nodes = list(torch.fx.symbolic_trace(fn).graph.nodes)
+        if len(nodes) == 3 and nodes[0].op == "placeholder" and nodes[2].op == "output":
+            n = nodes[1]
+            is_exp = (n.op == "call_method" and n.target == "exp") or (n.op == "call_function" and n.target is t.exp)
+            ok = bool(is_exp and tuple(n.args) == (nodes[0],) and not n.kwargs and nodes[2].args == (n,))
+    except Exception:
+        ok = False
+    _PLAIN_EXP[id(code)] = (code, ok)
+    return ok
+
+
 def call_model_lambda(fn, named_args, dimcache=None):
     vals = [v for _, v in named_args]
+    if len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_floating_point() and _is_plain_exp(fn):
+        # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
+        # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
+        return ExpPT(vals[0].x, vals[0].dims)
     if LAMBDA_BACKEND != "vmap" or not all(isinstance(v, PT) for v in vals):
         val = fn(*[_as_dim(v, n, dimcache) for n, v in named_args])
         if not is_tensor(val):

@@ -220,3 +220,25 @@ def test_graphed_eval_draws_fresh_particles_and_agrees_with_eager_in_distributio
                      dtype=t.float64)
     se = float((vals.var() / 200 + eager.var() / 200).sqrt())
     assert abs(float(vals.mean() - eager.mean())) < 5 * se + 1e-3 * abs(float(eager.mean())), (vals.mean(), eager.mean(), se)
+
+
+def test_plain_exp_lambdas_stay_lazy_and_mean_the_same():
+    """``lambda psi: psi.exp()`` (the usual positive-scale idiom) is recognised by symbolic tracing and kept as a lazy
+    ExpPT -- a fused Normal producer then takes the log-scale directly; anything else about the lambda is unchanged."""
+    from alan_amd import dist as D
+    from alan_amd.dims import PT, ExpPT, Dim
+    assert D._is_plain_exp(lambda psi_z: psi_z.exp()) and D._is_plain_exp(lambda v: t.exp(v))
+    two = 2.0
+    for fn in (lambda v: v.exp() * 2, lambda a, b: a.exp(), lambda v: v.exp().exp(), lambda v: (v * two).exp(),
+               lambda v: v.log()):
+        assert not D._is_plain_exp(fn)
+    d = Dim("K", 4)
+    x = PT(t.randn(4, 3), (d,))
+    lazy = D.call_model_lambda(lambda psi_z: psi_z.exp(), [("psi_z", x)])
+    assert isinstance(lazy, ExpPT) and not lazy.materialised and lazy.dims == (d,)
+    plain = D.call_model_lambda(lambda psi_z: psi_z.exp() + 0.0, [("psi_z", x)])
+    assert not isinstance(plain, ExpPT)
+    t.testing.assert_close(lazy.x, plain.x)
+    assert lazy.materialised
+    ints = PT(t.arange(4), (d,))
+    assert not isinstance(D.call_model_lambda(lambda v: v.exp(), [("v", ints)]), ExpPT)
