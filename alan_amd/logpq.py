@@ -247,19 +247,31 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
     # contributes log P - log Q as ONE launch (the first such one also carries the -log K); the others
     # contribute a log P factor and their log Q to the sum that reduce_logQ sees (Sampler.py:118-134 is
     # separable over variables whose log Q has no parent K, which is exactly when the fusion applies).
-    pqs = []
+    pqs, negqs = [], []          # launches that already carry "- log Q" (and, the first of them, "- log K")
     for var in prog_P:
         x = sample[var]
         assert isinstance(x, PT)
         if not isinstance(prog_P[var], Timeseries) and not isinstance(prog_Q[var], Timeseries):
             tP, tQ = prog_P[var].tdd(scope, dimcache), prog_Q[var].tdd(scope, dimcache)
+            logK_here = 0.0 if (pqs or negqs) else math.log(K)
             with N.may_defer():
-                pq = TorchDimDist.log_p_minus_q(tP, tQ, x, order, own, 0.0 if pqs else math.log(K))
+                pq = TorchDimDist.log_p_minus_q(tP, tQ, x, order, own, logK_here)
             if pq is not None:
                 pqs.append(pq)
                 continue
-            lp, Kinit_p = tP.log_prob_pt(x, dim_order=order), None
-            lq, Kinit_q = tQ.log_prob_pt(x, dim_order=order), None
+            with N.may_defer():                    # a factor of the plate's contraction and nothing else
+                lp = tP.log_prob_pt(x, dim_order=order)
+            Kinit_p = Kinit_q = None
+            if (set(x.ids) | set(tQ.all_arg_ids)) <= own:
+                # log Q on the group's own dims: reduce_logQ leaves it alone and is separable over such terms, so
+                # -(log Q [+ log K]) is a factor of its own, written by the producer (no adds, no negation pass)
+                with N.may_defer():
+                    nq = tQ.log_prob_pt(x, dim_order=order, affine=(-1.0, -logK_here, own))
+                assert set(nq.ids) <= own
+                negqs.append(nq)
+                logPs.append(lp)
+                continue
+            lq = tQ.log_prob_pt(x, dim_order=order)
         else:
             lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
                                                dimcache=dimcache)
@@ -277,11 +289,11 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         lq = sampler.reduce_logQ(total_logQ, active_platedims, Kdim)
         # -(log Q + log K) in one pass; every log P term stays its own factor (the contraction kernels add
         # factors on the fly, so pre-adding them would only cost extra launches)
-        neg_q = PT(t.sub(0.0 if pqs else -math.log(K), lq.x), lq.dims)
+        neg_q = PT(t.sub(0.0 if (pqs or negqs) else -math.log(K), lq.x), lq.dims)
     # every term stays its own factor: the contraction kernels add factors on the fly (up to 6 per launch; the
     # planner pre-adds the smallest ones only when a step would exceed that), so pre-adding here would only
     # cost launches
-    factors = [*logPs, *pqs] + ([neg_q] if neg_q is not None else [])
+    factors = [*logPs, *pqs, *negqs] + ([neg_q] if neg_q is not None else [])
 
     if Kinits:
         for k in init_Ks:
