@@ -305,7 +305,7 @@ def main():
                            "us_per_launch": ms * 1e3, "algorithmic_bytes": big, "launches_timed": len(sel),
                            "note": "literal size: 32 MB fits the 256 MiB Infinity Cache and ~1 wave of workgroups; "
                                    "see roofline_scaled for the bandwidth regime"}
-    res_prod = [(b, m) for mode, b, m in res if mode == native.MODE_NORMAL]
+    res_prod = [(b, m) for mode, b, m in res if mode in (native.MODE_NORMAL, native.MODE_NORMAL_LOGSCALE)]
     if res_prod:
         big = max(b for b, _ in res_prod)
         sel = [m for b, m in res_prod if b == big]
