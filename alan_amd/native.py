@@ -5,6 +5,7 @@ There is deliberately no fallback: if the shared library is missing, or a tensor
 HIP device, the call raises.  PyTorch is used only for device memory and the current stream.
 """
 import contextlib
+import threading
 import ctypes as C
 import os
 
@@ -175,39 +176,55 @@ _TIMER = [None]     # set by profiling.KernelTimer
 # anything else is launched, or at the end.  Stream order is unchanged, so this is invisible to every later alan
 # launch; it is NOT invisible to a torch op that reads a queued output -- hence the explicit ``may_defer()`` at the
 # call sites whose result only ever feeds another alan launch (logpq.py), and ``flush()`` for anyone in doubt.
-_PENDING = []            # [(desc, device, keepalive tensors)]
-_DEFER = [0, 0]          # nesting of deferring() / may_defer()
+class _Queue(threading.local):
+    """Per-thread state: evaluations running in different Python threads keep separate queues."""
+
+    def __init__(self):
+        self.pending = []        # [(desc, device, keepalive tensors)]
+        self.depth = [0, 0]      # nesting of deferring() / may_defer()
+
+
+_Q = _Queue()
 DEFER_SMALL_LAUNCHES = True
+
+
+def queue_active():
+    """Inside native.deferring() (one gradient-free evaluation)?"""
+    return _Q.depth[0] > 0
+
+
+def n_pending():
+    return len(_Q.pending)
 
 
 @contextlib.contextmanager
 def deferring():
-    _DEFER[0] += 1
+    _Q.depth[0] += 1
     try:
         yield
-        if _DEFER[0] == 1:
+        if _Q.depth[0] == 1:
             flush()
     finally:
-        _DEFER[0] -= 1
-        if _DEFER[0] == 0:
-            _PENDING.clear()          # (only non-empty after an exception)
+        _Q.depth[0] -= 1
+        if _Q.depth[0] == 0:
+            _Q.pending.clear()          # (only non-empty after an exception)
 
 
 @contextlib.contextmanager
 def may_defer():
-    _DEFER[1] += 1
+    _Q.depth[1] += 1
     try:
         yield
     finally:
-        _DEFER[1] -= 1
+        _Q.depth[1] -= 1
 
 
 def flush():
     """Issue every queued launch now (in order)."""
-    if not _PENDING:
+    if not _Q.pending:
         return
-    items = list(_PENDING)
-    _PENDING.clear()
+    items = list(_Q.pending)
+    _Q.pending.clear()
     L = lib()
     device = items[0][1]
     if len(items) == 1:
@@ -221,11 +238,11 @@ def flush():
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     L = lib()
-    if (DEFER_SMALL_LAUNCHES and _DEFER[0] and _DEFER[1] and _TIMER[0] is None and not t.is_grad_enabled()
+    if (DEFER_SMALL_LAUNCHES and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
-            and (not _PENDING or _PENDING[0][1] == device)):
-        _PENDING.append((desc, device, keepalive))
-        if len(_PENDING) >= 8:
+            and (not _Q.pending or _Q.pending[0][1] == device)):
+        _Q.pending.append((desc, device, keepalive))
+        if len(_Q.pending) >= 8:
             flush()
         return
     flush()
