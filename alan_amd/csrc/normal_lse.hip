@@ -6,14 +6,11 @@
 // and data-likelihood terms as the small factors, log-sum-exp over K_z, sum over plate_1
 // (TorchDimDist.py:127-162 + utils.py:147-152 + reduce_Ks.py:249-251 + utils.py:218-220 + logpq.py:149).
 // The factor F[plate_1, K_mu, K_psi, K_z] (32 MB at K=30, 1.2 GB at K=100) is never written or read: the kernel is
-// bound by its FMAs and LDS reads, not by HBM.
+// bound by its exps and MFMAs, not by HBM.
 //
-// Mapping: a half-wave (32 lanes) owns one (l, block of 32 scale rows) pair -- lane = scale row s, its
-// w[s,:] = 1/(2 scale^2) in registers -- and walks the plate elements of its chunk; per plate element the
-// workgroup stages value[m,:,:] in LDS, each half-wave turns it into d2[k,:] = (value[m,k,:] - loc[l,:])^2 in
-// its own LDS tile, then per k: 5 broadcast 16-byte reads + 20 FMAs + a one-exp online log-sum-exp update.
 // Per-chunk partial sums go to the workspace; a small second stage adds the chunks (no float atomics).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "plan.h"
@@ -23,119 +20,145 @@ namespace alan {
 struct NLDesc {
     const float *val, *loc, *scl;
     float *part;                      // [n_chunks][NL][NS]
-    int32_t M, NK, NL, NS, E, nsb, m_chunk, n_small, log_scale;
+    int32_t M, NK, NL, NS, E, m_chunk, n_small, log_scale;
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se;
     const float *small[4];
     int64_t small_sm[4], small_sk[4];
 };
 
-constexpr int NL_UNITS = 8;   // half-waves per workgroup
+// On the matrix cores: for one (plate element m, loc row l) the block F[m, l, :, :] is a GEMM over the event dim;
+// with v_mfma_f32_32x32x2_f32 computing D[i = k][j = s] = sum_e d2[(m,k), e] * w[s, e] the log-sum-exp over
+// k runs DOWN the accumulator registers of a lane (16 rows per lane + one exchange between the two half-waves), the
+// sum over m stays in a register, and nothing but out[l, s] partials is ever stored:
+//   A (one VGPR per step): d2 of this lane's k row, rebuilt per plate element with two VALU ops per event pair;
+//   B (one VGPR per step, held for the whole kernel): w of this lane's scale row;  C of the first MFMA: lg[s];
+//   one extra event slot carries the small factors: A = -sum_f small_f[m,k], B = 1.
+// A wave owns one (l, tile of 32 scale rows) pair and a chunk of the plate; k runs in tiles of 32 with an online
+// log-sum-exp across tiles; the value rows of the next tile are loaded while the current one is multiplied.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// SPL = scale rows per lane (lane's rows: s0, s0 + 32, ...): every broadcast read of the d2 tile feeds 4*SPL FMAs.
-template <int EMAX, int SPL>
-__global__ __launch_bounds__(256) void normal_lse_kernel(const NLDesc d) {
+template <int EH>       // MFMA steps: ceil((E + 1) / 2) -- the event dim plus the small-factor slot
+__global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     extern __shared__ __align__(16) float lds[];
-    constexpr int EP = EMAX;
-    const int tid = threadIdx.x, lane = tid & 31, u = tid >> 5;
+    constexpr int EP = 2 * EH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
     const int NK = d.NK, E = d.E, NS = d.NS;
     float *wt = lds;                                  // [NS][EP]   1/(2 scale^2), pads 0
-    float *lgt = wt + (size_t)NS * EP;                // [NS]       sum_e log scale + E log sqrt(2 pi)
-    float *mus = lgt + ((NS + 3) & ~3);               // [8][EP]    loc rows of the units
-    float *zs = mus + NL_UNITS * EP;                  // [NK][EP]   value[m,:,:], pads 0
-    float *hs = zs + (size_t)NK * EP;                 // [NK]       sum of the small factors at m
-    float *dds = hs + ((NK + 3) & ~3);                // [8][NK][EP]
-
-    const int q = blockIdx.x * NL_UNITS + u;          // (l, s-block) pair of this half-wave
-    const int l = q / d.nsb, sb = q - l * d.nsb;
-    const bool unit_ok = l < d.NL;
-    const int s0 = sb * (32 * SPL) + lane;           // this lane's scale rows: s0 + 32 j
-    const int lc = min(l, d.NL - 1);
-    const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
-
-    // ---- tables
+    float *lgs = wt + (size_t)NS * EP;                // [NS][EP]   log scale, pads 0
+    float *lgt = lgs + (size_t)NS * EP;               // [NS]       sum_e log scale + E log sqrt(2 pi)
+    const int nst = (NS + 31) >> 5, nkt = (NK + 31) >> 5;
+    const int q = blockIdx.x * 4 + wave;              // (l, scale tile) pair of this wave
+    const bool wave_ok = q < d.NL * nst;
+    const int l = wave_ok ? q / nst : 0, st = wave_ok ? q - l * nst : 0;
+    const int s = 32 * st + j;
+    const bool s_ok = s < NS;
+    const bool small_slot = (E & 1) == h;             // this lane's element of the last step is the small-factor slot
+    // everything this wave needs from global memory is requested before the tables are built: the loc row ...
+    float mreg[EH];
+#pragma unroll
+    for (int step = 0; step < EH; ++step)
+        mreg[step] = d.loc[(int64_t)l * d.l_sl + (int64_t)min(2 * step + h, E - 1) * d.l_se];
+    // ... and (below) the first tile; meanwhile the workgroup's tables, one scale element per thread and pass
     for (int i = tid; i < NS * EP; i += 256) {
         const int is = i / EP, e = i - is * EP;
-        float w = 0.f;
+        float w = 0.f, lg = 0.f;
         if (e < E) {
             const float x = d.scl[(int64_t)is * d.s_ss + (int64_t)e * d.s_se];
             w = d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x);
+            lg = d.log_scale ? x : logf(x);
         }
         wt[i] = w;
+        lgs[i] = lg;
     }
+    __syncthreads();
     for (int is = tid; is < NS; is += 256) {
         float a = 0.f;
-        for (int e = 0; e < E; ++e) {
-            const float x = d.scl[(int64_t)is * d.s_ss + (int64_t)e * d.s_se];
-            a += d.log_scale ? x : logf(x);
-        }
+#pragma unroll
+        for (int e = 0; e < EP; ++e) a += lgs[is * EP + e];
         lgt[is] = a + (float)E * 0.91893853320467274178f;
     }
-    if (lane < EP) mus[u * EP + lane] = (lane < E) ? d.loc[(int64_t)lc * d.l_sl + (int64_t)lane * d.l_se] : 0.f;
-    if (EP > 32 && lane + 32 < EP)
-        mus[u * EP + lane + 32] = (lane + 32 < E) ? d.loc[(int64_t)lc * d.l_sl + (int64_t)(lane + 32) * d.l_se] : 0.f;
     __syncthreads();
-    float4 w4[SPL][EMAX / 4];
-    float lgs[SPL];
+    if (!wave_ok) return;                             // (no barriers below)
+    float breg[EH];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-        const int sc = min(s0 + 32 * j, NS - 1);
-#pragma unroll
-        for (int qd = 0; qd < EMAX / 4; ++qd) w4[j][qd] = reinterpret_cast<const float4 *>(wt + (size_t)sc * EP)[qd];
-        lgs[j] = lgt[sc];
+    for (int step = 0; step < EH; ++step) {
+        const int e = 2 * step + h;
+        breg[step] = (s_ok && e < E) ? wt[(size_t)s * EP + e] : (s_ok && e == E) ? 1.f : 0.f;
+        mreg[step] = e < E ? mreg[step] : 0.f;
     }
-
-    float *dd = dds + (size_t)u * NK * EP;
-    float accm[SPL];
+    f32x16 cinit;
+    {
+        const float lg = s_ok ? lgt[s] : 0.f;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) accm[j] = 0.f;
-    for (int m = m0; m < m1; ++m) {
-        __syncthreads();                              // everyone is done with zs / hs / dds of the previous m
-        for (int i = tid; i < NK * EP; i += 256) {
-            const int k = i / EP, e = i - k * EP;
-            zs[i] = e < E ? d.val[(int64_t)m * d.v_sm + (int64_t)k * d.v_sk + (int64_t)e * d.v_se] : 0.f;
-        }
-        for (int k = tid; k < NK; k += 256) {
-            float h = 0.f;
-            for (int f = 0; f < d.n_small; ++f) h += d.small[f][(int64_t)m * d.small_sm[f] + (int64_t)k * d.small_sk[f]];
-            hs[k] = h;
-        }
-        __syncthreads();
-        for (int i = lane; i < NK * EP; i += 32) {    // this half-wave's d2 tile (pads: (0 - 0)^2 = 0)
-            const int e = i % EP;
-            const float df = zs[i] - mus[u * EP + e];
-            dd[i] = df * df;
-        }
-        __syncthreads();
-        float mx[SPL], sm[SPL];
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) mx[j] = -__builtin_huge_valf(), sm[j] = 0.f;
-        for (int k = 0; k < NK; ++k) {
-            const float4 *d4 = reinterpret_cast<const float4 *>(dd + (size_t)k * EP);
-            float4 dv[EMAX / 4];
-#pragma unroll
-            for (int qd = 0; qd < EMAX / 4; ++qd) dv[qd] = d4[qd];
-            const float hk = hs[k];
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int qd = 0; qd < EMAX / 4; ++qd) {
-                    acc = fmaf(dv[qd].x, w4[j][qd].x, acc);
-                    acc = fmaf(dv[qd].y, w4[j][qd].y, acc);
-                    acc = fmaf(dv[qd].z, w4[j][qd].z, acc);
-                    acc = fmaf(dv[qd].w, w4[j][qd].w, acc);
-                }
-                lse_push(mx[j], sm[j], (-acc - lgs[j]) + hk);     // (packed v_pk_fma_f32 over row pairs was slower)
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) accm[j] += lse_finish(mx[j], sm[j]);
+        for (int r = 0; r < 16; ++r) cinit[r] = lg;
     }
+    const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
+    const int n_tiles = (m1 - m0) * nkt;
+    // this lane's slice of tile t, RAW: value[m, k, 2 step + h] for k = 32 kt + j and the small factors at (m, k), from
+    // clamped (always valid) addresses, every load issued before anything waits; masks are applied where the values
+    // are used, one iteration later (selects next to the loads made the compiler branch around each pair of loads
+    // and wait for it on the spot)
+    auto load_tile = [&](int t, float (&x)[EH], float (&hs)[4]) {
+        const int m = m0 + t / nkt, kt_ = t - (t / nkt) * nkt;
+        const int k = min(32 * kt_ + j, NK - 1);
+        const float *vp = d.val + (int64_t)m * d.v_sm + (int64_t)k * d.v_sk;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-        const int s = s0 + 32 * j;
-        if (unit_ok && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[j];
+        for (int step = 0; step < EH; ++step) x[step] = vp[(int64_t)min(2 * step + h, E - 1) * d.v_se];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)                   // (the launcher points unused slots at valid memory, stride 0)
+            hs[f] = d.small[f][(int64_t)m * d.small_sm[f] + (int64_t)k * d.small_sk[f]];
+        asm volatile("" ::: "memory");
+    };
+    float zc[EH], zn[EH], hc[4], hn[4];
+    if (n_tiles > 0) load_tile(0, zc, hc);
+    float accm = 0.f, mn = __builtin_huge_valf(), sm = 0.f;
+    int kt = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        if (t + 1 < n_tiles) load_tile(t + 1, zn, hn);
+        // A operand.  No masks: pad events meet a zero in B; rows beyond NK (and plate elements' -inf small factors)
+        // put +inf into the small-factor slot, which makes their whole row of D +inf = a log-prob of -inf
+        const bool k_ok = 32 * kt + j < NK;
+        float a[EH];
+#pragma unroll
+        for (int step = 0; step < EH; ++step) {
+            const float df = zc[step] - mreg[step];
+            a[step] = df * df;
+        }
+        {   // the small-factor slot is element E = 2 (EH - 1) + (E & 1): always in the LAST step's register
+            float hsum = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) hsum += f < d.n_small ? hc[f] : 0.f;
+            if (small_slot) a[EH - 1] = k_ok ? -hsum : __builtin_huge_valf();
+        }
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], breg[0], cinit, 0, 0, 0);
+#pragma unroll
+        for (int step = 1; step < EH; ++step) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step], breg[step], acc, 0, 0, 0);
+        // acc[r] = -log-prob of row k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h: log-sum-exp down the registers
+        // (utils.py:218-220), kept on u = -value: running minimum mn = -max, sm = sum exp(mn - u)
+        float tmin = __builtin_huge_valf();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmin = fminf(tmin, acc[r]);
+        if (tmin < mn) {
+            sm *= __expf(tmin - mn);                  // (mn = +inf at the start: exp(-inf) = 0, and sm is 0 anyway)
+            mn = tmin;
+        }
+        if (mn != __builtin_huge_valf()) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += __expf(mn - acc[r]);
+        }
+        if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
+            float mx = -mn, mx2 = -__shfl_xor(mn, 32), sm2 = __shfl_xor(sm, 32);
+            lse_merge(mx, sm, mx2, sm2);
+            accm += lse_finish(mx, sm);
+            mn = __builtin_huge_valf(), sm = 0.f, kt = 0;
+        }
+#pragma unroll
+        for (int step = 0; step < EH; ++step) zc[step] = zn[step];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
+    if (h == 0 && s_ok) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm;
 }
 
 }  // namespace alan
@@ -145,7 +168,7 @@ using namespace alan;
 namespace {
 
 struct NLPlan {
-    int em = 0, nsb = 1, spl = 1, m_chunk = 1, n_chunks = 1;
+    int eh = 0, m_chunk = 1, n_chunks = 1;
     size_t lds = 0, part_bytes = 0;
     dim3 grid;
 };
@@ -157,25 +180,14 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     for (int f = 0; f < a.n_small; ++f)
         if (!a.small[f]) return ALAN_ERR_BAD_DESC;
     if (a.E > 32 || a.NK > 4096 || a.NS > 4096 || a.NL > (1 << 20) || a.M > (1 << 24)) return ALAN_ERR_UNSUPPORTED;
-    static const int kEmax[] = {4, 8, 12, 16, 20, 24, 28, 32};
-    for (int em : kEmax)
-        if (a.E <= em) {
-            p.em = em;
-            break;
-        }
-    // scale rows per lane: with one row per lane and > 32 rows every (m, l) pair would be walked by several
-    // half-waves, each rebuilding and re-reading the d2 tile (measured at K=100: 110 us per 38-user chunk against
-    // 49 + 32 us for the producer + rows kernels) -- block 2 or 4 rows per lane instead (65 us)
-    p.spl = a.NS <= 32 ? 1 : a.NS <= 64 ? 2 : 4;
-    if (a.NS > 128) return ALAN_ERR_UNSUPPORTED;
-    p.nsb = 1;
-    const int64_t gx = (a.NL * p.nsb + NL_UNITS - 1) / NL_UNITS;
-    int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, 2048 / std::max<int64_t>(1, gx)));
+    // a wave per (loc row, tile of 32 scale rows), 4 per workgroup; the plate in chunks so that ~4096 waves exist
+    p.eh = (int)(a.E + 2) / 2;
+    const int64_t nst = (a.NS + 31) / 32;
+    const int64_t gx = (a.NL * nst + 3) / 4;
+    int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, 1024 / std::max<int64_t>(1, gx)));
     p.m_chunk = (int)((a.M + nch - 1) / nch);
     p.n_chunks = (int)((a.M + p.m_chunk - 1) / p.m_chunk);
-    const size_t fl = (size_t)a.NS * p.em + ((a.NS + 3) & ~3) + (size_t)NL_UNITS * p.em + (size_t)a.NK * p.em +
-                      ((a.NK + 3) & ~3) + (size_t)NL_UNITS * a.NK * p.em + 8;
-    p.lds = fl * sizeof(float);
+    p.lds = ((size_t)a.NS * 4 * p.eh + a.NS + 8) * sizeof(float);
     if (p.lds > 150 * 1024) return ALAN_ERR_UNSUPPORTED;
     p.part_bytes = (size_t)p.n_chunks * a.NL * a.NS * sizeof(float);
     p.grid = dim3((uint32_t)gx, (uint32_t)p.n_chunks);
@@ -206,13 +218,14 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     d.scl = (const float *)a->scale;
     d.part = (float *)workspace;
     d.M = (int)a->M, d.NK = (int)a->NK, d.NL = (int)a->NL, d.NS = (int)a->NS, d.E = (int)a->E;
-    d.nsb = p.nsb, d.m_chunk = p.m_chunk, d.n_small = a->n_small, d.log_scale = a->log_scale;
+    d.m_chunk = p.m_chunk, d.n_small = a->n_small, d.log_scale = a->log_scale;
     d.v_sm = a->v_sm, d.v_sk = a->v_sk, d.v_se = a->v_se;
     d.l_sl = a->l_sl, d.l_se = a->l_se, d.s_ss = a->s_ss, d.s_se = a->s_se;
-    for (int f = 0; f < a->n_small; ++f) {
-        d.small[f] = (const float *)a->small[f];
-        d.small_sm[f] = a->small_sm[f];
-        d.small_sk[f] = a->small_sk[f];
+    for (int f = 0; f < 4; ++f) {
+        const bool used = f < a->n_small;
+        d.small[f] = used ? (const float *)a->small[f] : (const float *)a->value;    // (unused: any valid address)
+        d.small_sm[f] = used ? a->small_sm[f] : 0;
+        d.small_sk[f] = used ? a->small_sk[f] : 0;
     }
     auto launch = [&](auto kern) {
         if (p.lds > 64 * 1024)
@@ -222,24 +235,25 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         hipLaunchKernelGGL(kern, p.grid, dim3(256), p.lds, stream, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
-#define ALAN_NL_CASE(EM)                                                    \
-    case EM:                                                                \
-        rc = p.spl == 1 ? launch(normal_lse_kernel<EM, 1>)                  \
-             : p.spl == 2 ? launch(normal_lse_kernel<EM, 2>)                \
-                          : launch(normal_lse_kernel<EM, 4>);               \
-        break
-    switch (p.em) {
-        ALAN_NL_CASE(4);
-        ALAN_NL_CASE(8);
-        ALAN_NL_CASE(12);
-        ALAN_NL_CASE(16);
-        ALAN_NL_CASE(20);
-        ALAN_NL_CASE(24);
-        ALAN_NL_CASE(28);
-        default: rc = p.spl == 1 ? launch(normal_lse_kernel<32, 1>)
-                      : p.spl == 2 ? launch(normal_lse_kernel<32, 2>) : launch(normal_lse_kernel<32, 4>);
+    switch (p.eh) {
+        case 1: rc = launch(normal_lse_mfma_kernel<1>); break;
+        case 2: rc = launch(normal_lse_mfma_kernel<2>); break;
+        case 3: rc = launch(normal_lse_mfma_kernel<3>); break;
+        case 4: rc = launch(normal_lse_mfma_kernel<4>); break;
+        case 5: rc = launch(normal_lse_mfma_kernel<5>); break;
+        case 6: rc = launch(normal_lse_mfma_kernel<6>); break;
+        case 7: rc = launch(normal_lse_mfma_kernel<7>); break;
+        case 8: rc = launch(normal_lse_mfma_kernel<8>); break;
+        case 9: rc = launch(normal_lse_mfma_kernel<9>); break;
+        case 10: rc = launch(normal_lse_mfma_kernel<10>); break;
+        case 11: rc = launch(normal_lse_mfma_kernel<11>); break;
+        case 12: rc = launch(normal_lse_mfma_kernel<12>); break;
+        case 13: rc = launch(normal_lse_mfma_kernel<13>); break;
+        case 14: rc = launch(normal_lse_mfma_kernel<14>); break;
+        case 15: rc = launch(normal_lse_mfma_kernel<15>); break;
+        case 16: rc = launch(normal_lse_mfma_kernel<16>); break;
+        default: rc = launch(normal_lse_mfma_kernel<17>);
     }
-#undef ALAN_NL_CASE
     if (rc != ALAN_OK) return rc;
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
