@@ -184,7 +184,9 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     p.eh = (int)(a.E + 2) / 2;
     const int64_t nst = (a.NS + 31) / 32;
     const int64_t gx = (a.NL * nst + 3) / 4;
-    int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, 1024 / std::max<int64_t>(1, gx)));
+    int64_t target = 1024;                                                   // workgroups (x 4 waves)
+    if (const char *e = getenv("ALAN_NLSE_BLOCKS")) target = std::max(1, atoi(e));   // tuning knob
+    int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, target / std::max<int64_t>(1, gx)));
     p.m_chunk = (int)((a.M + nch - 1) / nch);
     p.n_chunks = (int)((a.M + p.m_chunk - 1) / p.m_chunk);
     p.lds = ((size_t)a.NS * 4 * p.eh + a.NS + 8) * sizeof(float);
