@@ -93,3 +93,31 @@ def test_movielens_elbo_with_the_fused_plate_step(fixture, monkeypatch):
     # with gradients to record the factor is materialised as before
     monkeypatch.setattr(E, "normal_lse", lambda *a, **k: pytest.fail("the fused kernel has no backward"))
     sample.elbo_rws(alan.no_checkpoint).backward()
+
+
+def test_fused_plate_step_fuzz_against_the_two_launch_route():
+    """Random shapes (every tile-edge case of the MFMA kernel: K and scale rows around multiples of 32, odd and even
+    event lengths up to 32, one plate element, one scale row, 0-4 small factors with broadcast strides, log-scale
+    or scale) against the producer + log-sum-exp + plate-sum route."""
+    import random
+    rnd = random.Random(7)
+    g = t.Generator().manual_seed(7)
+    sizes = [1, 2, 3, 5, 16, 31, 32, 33, 47, 63, 64, 65, 96, 100]
+    for it in range(40):
+        M, NK, NL, NS = rnd.choice([1, 2, 5, 9, 17]), rnd.choice(sizes), rnd.choice([1, 2, 7, 30]), rnd.choice(sizes)
+        Ev = rnd.choice([1, 2, 3, 4, 7, 8, 17, 18, 31, 32])
+        n_small, log_scale = rnd.randrange(5), rnd.random() < 0.5
+        pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)
+        z = t.randn(M, NK, Ev, generator=g).to(DEV)
+        mu = t.randn(NL, Ev, generator=g).to(DEV)
+        raw = (0.3 * t.randn(NS, Ev, generator=g)).to(DEV)
+        sc = raw if log_scale else raw.exp()
+        small_dims = [(pl, K), (K,), (pl,), (K, pl)]
+        smalls = [(t.randn(*[d.size for d in small_dims[i]], generator=g).to(DEV), small_dims[i]) for i in range(n_small)]
+        res = E.normal_lse((z, (pl, K)), (mu, (dl,)), (sc, (ds,)), smalls, pl, K, log_scale=log_scale)
+        assert res is not None, (M, NK, NL, NS, Ev, n_small)
+        out, odims = res
+        F = E.normal_logprob((z, (pl, K)), (mu, (dl,)), (sc, (ds,)), (pl, dl, ds, K), log_scale=log_scale)
+        two, tdims = E.reduce_factors([(F, (pl, dl, ds, K)), *smalls], reduce=(K,), plate=(pl,))
+        two = two if tdims[0] is dl else two.t()
+        t.testing.assert_close(out, two, rtol=3e-5, atol=3e-4, msg=lambda m: f"{(M, NK, NL, NS, Ev, n_small, log_scale)}: {m}")
