@@ -219,7 +219,8 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     int rc = canonicalise(d, keep_mask, red_mask, out, c);
     if (rc != ALAN_OK) return rc;
     const int compute = out.dtype;
-    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI;
+    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI ||
+                          mode == ALAN_MODE_PRODUCER_GRAD;
     const float out_scale = producer ? out.scale : 1.f;
     if (mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE) {
         rc = try_launch_normal_outer(c, mode == ALAN_MODE_NORMAL_LOGSCALE, out_scale, add_const, stream, ev);
@@ -257,11 +258,16 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
     }
     if (plate && d.mode != ALAN_MODE_LSE) return ALAN_ERR_BAD_DESC;
     if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM && d.mode != ALAN_MODE_WEXPSUM &&
-        d.mode != ALAN_MODE_NORMAL && d.mode != ALAN_MODE_BERNOULLI && d.mode != ALAN_MODE_NORMAL_LOGSCALE)
+        d.mode != ALAN_MODE_NORMAL && d.mode != ALAN_MODE_BERNOULLI && d.mode != ALAN_MODE_NORMAL_LOGSCALE &&
+        d.mode != ALAN_MODE_PRODUCER_GRAD)
         return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_NORMAL_LOGSCALE && d.n_factors != 3) return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_NORMAL && d.n_factors != 3 && d.n_factors != 6) return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_BERNOULLI && d.n_factors != 2) return ALAN_ERR_BAD_DESC;
+    if (d.mode == ALAN_MODE_PRODUCER_GRAD) {
+        const int kind = (int)d.factor[0].scale;
+        if (kind < 1 || kind > 4 || d.n_factors != (kind == 4 ? 3 : 4)) return ALAN_ERR_BAD_DESC;
+    }
     return ALAN_OK;
 }
 
@@ -274,7 +280,8 @@ static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunc
     if (mode == ALAN_MODE_LSE && red == 0) mode = ALAN_MODE_SUM;
     Canon c;
     if (canonicalise(d, keep, red, d.out, c) != ALAN_OK) return false;
-    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI;
+    const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI ||
+                          mode == ALAN_MODE_PRODUCER_GRAD;
     const float out_scale = producer ? d.out.scale : 1.f;
     if ((mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE) &&
         try_launch_normal_outer(c, mode == ALAN_MODE_NORMAL_LOGSCALE, out_scale, d.add_const, nullptr, EvPair(), true) !=

@@ -43,6 +43,27 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
             }
         }
         s += ok ? lp : T(0);
+    } else if (MODE == ALAN_MODE_PRODUCER_GRAD) {
+        // G * d log-prob / d (one argument); which argument is a launch-uniform switch (factor 0's scale field)
+        const int kind = (int)scale[0];
+        const T g = val[0];
+        T r;
+        if (kind == 4) {
+            const T xl = val[2];
+            const T sg = T(1) / (T(1) + Num<T>::exp_acc(-xl));             // d/dx [logsigmoid(x) - (1 - y) x] = y - sigmoid(x)
+            r = g * (val[1] - sg);
+        } else {
+            const T z = val[1] - val[2], sc = val[3];
+            const bool logsc = scale[3] == 2.f;
+            const T w = logsc ? Num<T>::exp_acc(T(-2) * sc) : T(1) / (sc * sc);  // 1 / scale^2
+            if (kind == 1)
+                r = -g * z * w;
+            else if (kind == 2)
+                r = g * z * w;
+            else
+                r = logsc ? g * (z * z * w - T(1)) : g * (z * z * w - T(1)) / sc;
+        }
+        s += ok ? r : T(0);
     } else if (MODE == ALAN_MODE_BERNOULLI) {
         // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
         // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
@@ -187,7 +208,8 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
     combine_lanes<T, MODE, BLOCK>(m, s, G);
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
-        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI)
+        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI ||
+            MODE == ALAN_MODE_PRODUCER_GRAD)
             v *= (T)d.out_scale;
         v += (T)d.add_const;
         store_as<T>(d.out, d.out_dtype, obase, v);
@@ -261,7 +283,8 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
     combine_lanes<T, MODE, BLOCK>(m, s, G);
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
-        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI)
+        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI ||
+            MODE == ALAN_MODE_PRODUCER_GRAD)
             v *= d.out_scale;
         d.out[obase] = v + d.add_const;
     }
@@ -307,6 +330,7 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
         case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL>(d, logG, block, bid); break;
         case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE>(d, logG, block, bid); break;
         case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
+        case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
         default: break;                                                    // (WEXPSUM is not batched)
     }
 }
@@ -406,6 +430,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
         case ALAN_MODE_NORMAL: launch_small_T<ALAN_MODE_NORMAL>(sd, gl, stream, ev); break;
         case ALAN_MODE_NORMAL_LOGSCALE: launch_small_T<ALAN_MODE_NORMAL_LOGSCALE>(sd, gl, stream, ev); break;
         case ALAN_MODE_BERNOULLI: launch_small_T<ALAN_MODE_BERNOULLI>(sd, gl, stream, ev); break;
+        case ALAN_MODE_PRODUCER_GRAD: launch_small_T<ALAN_MODE_PRODUCER_GRAD>(sd, gl, stream, ev); break;
         default: return ALAN_ERR_BAD_DESC;
     }
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
@@ -434,6 +459,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
         case ALAN_MODE_BERNOULLI: return launch_group_T<T, ALAN_MODE_BERNOULLI>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL_LOGSCALE: return launch_group_T<T, ALAN_MODE_NORMAL_LOGSCALE>(gd, gl, stream, ev); \
+        case ALAN_MODE_PRODUCER_GRAD: return launch_group_T<T, ALAN_MODE_PRODUCER_GRAD>(gd, gl, stream, ev); \
     }
     if (compute_dtype == ALAN_F32) {
         ALAN_DISPATCH(float)

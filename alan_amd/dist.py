@@ -75,6 +75,16 @@ class _FusedNormalLogProb(t.autograd.Function):
     def backward(ctx, G):
         vd, ld, sd, od, log_scale, affine = ctx.spec
         value, loc, scale = ctx.saved_tensors
+        ids = lambda ds: {id(d) for d in ds}
+        outer = OUTER_BACKWARD and not (ids(vd) & ids(ld)) and not (ids(vd) & ids(sd)) and not (ids(ld) & ids(sd)) \
+            and ids(od) == ids(vd) | ids(ld) | ids(sd)
+        if HIP_PRODUCER_BACKWARD and G.is_cuda and not outer:
+            from . import engine as E
+            from . import native as N
+            res = E.producer_grads(G, od, [(value, vd), (loc, ld), (scale, sd)], ctx.needs_input_grad[1:4],
+                                   (N.GRAD_VALUE, N.GRAD_LOC, N.GRAD_SCALE), log_scale=log_scale, scale=affine[0])
+            if res is not None:
+                return (None, *res)
         if affine[0] != 1.0:
             G = G * affine[0]
         raw_scale = scale
@@ -89,9 +99,7 @@ class _FusedNormalLogProb(t.autograd.Function):
         nev = value.ndim - len(vd)
         flat = lambda x, d: x.reshape(*x.shape[: len(d)], -1) if nev else x.unsqueeze(-1)
         v, l, s = flat(value.detach(), vd), flat(loc.detach(), ld), flat(scale.detach(), sd)
-        ids = lambda ds: {id(d) for d in ds}
-        if OUTER_BACKWARD and not (ids(vd) & ids(ld)) and not (ids(vd) & ids(sd)) and not (ids(ld) & ids(sd)) \
-                and ids(od) == ids(vd) | ids(ld) | ids(sd):
+        if outer:
             return (None, *_FusedNormalLogProb._backward_outer(ctx, G, v, l, s, value.shape, loc.shape,
                                                                 raw_scale.shape, log_scale))
         g, V, L, S = sub(od, False), sub(vd), sub(ld), sub(sd)
@@ -185,6 +193,13 @@ class _FusedBernoulliLogProb(t.autograd.Function):
         value, logits = ctx.saved_tensors
         if not ctx.needs_input_grad[2]:
             return None, None, None
+        if HIP_PRODUCER_BACKWARD and G.is_cuda:
+            from . import engine as E
+            from . import native as N
+            res = E.producer_grads(G, od, [(value, vd), (logits, ld)], (False, True), (0.0, N.GRAD_LOGITS),
+                                   scale=affine[0])
+            if res is not None:
+                return None, None, res[1]
         if affine[0] != 1.0:
             G = G * affine[0]
         dims, ids = pt_order((PT(value, vd), PT(logits, ld)))
@@ -215,6 +230,10 @@ FUSE_PLATE_STEP = False
 (alan_normal_lse: producer + log-sum-exp + plate sum, the factor never materialised) when the plate's contraction
 has that shape.  Off by default: the default path keeps the materialised factor and the HBM-bound reduce_Ks kernel
 that bench.py's roofline is measured on."""
+
+HIP_PRODUCER_BACKWARD = True
+"""Gradients of the (small) fused producers by alan_reduce mode PRODUCER_GRAD -- one multi-problem launch per
+producer -- instead of a dozen einsum / elementwise torch kernels each."""
 
 OUTER_BACKWARD = True
 """Use the two-GEMM backward of the Normal producer when value / loc / scale carry disjoint dims."""

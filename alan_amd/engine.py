@@ -340,6 +340,41 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
     return out, (dl[0], ds[0])
 
 
+def producer_grads(G, out_dims, args, wanted, kinds, log_scale=False, scale=1.0):
+    """Backward of a fused producer (alan_reduce mode PRODUCER_GRAD): ``args`` = the producer's arguments as (tensor,
+    leading first-class dims) pairs -- (value, loc, scale) or (value, logits) --, ``G`` the upstream gradient laid out
+    like ``out_dims``; returns the gradient of every argument i with wanted[i] (shaped like the argument), else None.
+    kinds[i] = N.GRAD_*.  The wanted gradients are independent problems: they leave as ONE multi-problem launch when
+    they are small (alan_reduce_batch).  Returns None when the shapes do not fit (broadcast event dims)."""
+    tok = _Tokens()
+    npos = max(x.ndim - len(d) for x, d in args)
+    facs = []
+    for x, d in args:
+        k = x.ndim - len(d)
+        keys = tok.many(d) + tuple(tok(("_e", npos - k + j)) for j in range(k))
+        facs.append((x.detach(), keys))
+    gfac = (G.detach(), tok.many(out_dims))
+    try:
+        sizes = _space([gfac, *facs])
+    except Exception:
+        return None                                  # a size-1 event dim broadcasting against a longer one
+    outs = [None] * len(args)
+    if t.is_grad_enabled():
+        return None                                  # (double backward: the torch formulas)
+    with N.deferring(), N.may_defer():
+        for i, ((x, keys), want) in enumerate(zip(facs, wanted)):
+            if not want:
+                continue
+            roles = {d: (N.KEEP if d in keys else N.REDUCE) for d in sizes}
+            out = t.empty([sizes[d] for d in keys], dtype=_result_dtype([G, *[y for y, _ in facs]]), device=G.device)
+            scales = [kinds[i]] + [1.0] * len(facs)
+            if log_scale and len(facs) == 3:
+                scales[3] = 2.0
+            _launch(N.MODE_PRODUCER_GRAD, [gfac, *facs], sizes, roles, out, keys, scales=scales, out_scale=float(scale))
+            outs[i] = out.to(args[i][0].dtype) if out.dtype != args[i][0].dtype else out
+    return outs
+
+
 def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):
     """log Bernoulli(value; logits=logits), summed like ``normal_logprob`` (alan_reduce mode BERNOULLI)."""
     return _produce(N.MODE_BERNOULLI, (value, logits), out_dims, affine)

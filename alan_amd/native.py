@@ -17,6 +17,8 @@ MAX_FACTORS = 6
 F32, F64 = 0, 1
 KEEP, REDUCE, PLATE = 0, 1, 2
 MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSCALE = 0, 1, 2, 3, 4, 5
+MODE_PRODUCER_GRAD = 6
+GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
 
 _STATUS = {
     -1: "bad descriptor",

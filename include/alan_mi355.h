@@ -70,8 +70,14 @@ typedef enum {
                               out = sum_R [ logsigmoid(logits) - (1 - value) * logits ]
                               (= -binary_cross_entropy_with_logits, what torch's Bernoulli.log_prob evaluates);
                               R = event/batch dims and, for a data-only plate, the plate dims (logpq.py:149) */
-    ALAN_MODE_NORMAL_LOGSCALE = 5 /* ALAN_MODE_NORMAL whose third factor is log(scale): the exp() transform of a
+    ALAN_MODE_NORMAL_LOGSCALE = 5, /* ALAN_MODE_NORMAL whose third factor is log(scale): the exp() transform of a
                               learned scale parameter (Param.py:18-25, transformation=t.exp) folded into the producer */
+    ALAN_MODE_PRODUCER_GRAD = 6 /* BACKWARD of a producer with respect to ONE of its arguments (what autograd derives
+                              from TorchDimDist.py:127-162): factors = (G, value, loc, scale) or (G, value, logits), G
+                              the upstream gradient laid out like the producer's output;  out = out.scale * sum_R
+                              G * d log-prob / d argument, KEEP = that argument's dims.  Which one: factor[0].scale =
+                              1: Normal d/d value, 2: d/d loc, 3: d/d scale (d/d log scale when factor[3].scale == 2),
+                              4: Bernoulli d/d logits */
 } alan_mode_t;
 /* Producer modes (NORMAL, NORMAL_LOGSCALE, BERNOULLI) write  out = out.scale * sum_R(log-prob) + add_const, so the
  * "-(log Q + log K)" of logpq.py:234-235 costs no extra pass; out.scale must be 1 in the other modes. */
