@@ -559,3 +559,62 @@ def test_reduce_batch_c_abi_orders_and_rejects():
     assert L.alan_reduce_batch(None, 0, None) == -1
     arr = (ctypes.POINTER(N.ReduceDesc) * 1)(ctypes.POINTER(N.ReduceDesc)())
     assert L.alan_reduce_batch(arr, 1, None) == -1       # null descriptor
+
+
+# ------------------------------------------------------------------ backward of the fused producers (PRODUCER_GRAD)
+def test_producer_grads_match_torch_distributions_autograd():
+    """alan_reduce mode PRODUCER_GRAD (d/d value, d/d loc, d/d scale or log scale of a Normal; d/d logits of a
+    Bernoulli) against autograd through torch.distributions on the materialised broadcast, over random dim
+    assignments: shared and private first-class dims, event or scalar parameters, fp32 and fp64, an affine output."""
+    import random
+    from alan_amd.dims import Dim
+    rnd = random.Random(3)
+    g = t.Generator().manual_seed(3)
+    pool = [Dim("a", 3), Dim("b", 4), Dim("c", 5), Dim("d", 2)]
+    has = lambda ds, d: any(x is d for x in ds)          # (Dim overloads ==)
+    for it in range(25):
+        dtype = t.float64 if it % 5 == 4 else t.float32
+        Ev = rnd.choice([1, 3, 7])
+        pick = lambda: tuple(d for d in pool if rnd.random() < 0.5)
+        vd, ld, sd = pick() or (pool[0],), pick(), pick()
+        od = tuple(d for d in pool if has(vd, d) or has(ld, d) or has(sd, d))
+        od = tuple(d for d in od if rnd.random() < 0.7) or od[:1]
+        mk = lambda ds, ev: t.randn(*[d.size for d in ds], *([Ev] if ev else []), generator=g, dtype=dtype).to(DEV)
+        value, loc = mk(vd, True), mk(ld, rnd.random() < 0.6)
+        raw = 0.3 * mk(sd, rnd.random() < 0.6)
+        log_scale, a = rnd.random() < 0.5, rnd.choice([1.0, -1.0, 0.5])
+        G = t.randn(*[d.size for d in od], generator=g, dtype=dtype).to(DEV)
+
+        def full(x, ds):          # broadcast over the whole pool, event last
+            idx = tuple(slice(None) if has(ds, d) else None for d in pool)
+            x = x if x.ndim > len(ds) else x.unsqueeze(-1)
+            return x[idx + (slice(None),)]
+
+        leaves = [x.clone().requires_grad_(True) for x in (value, loc, raw)]
+        sc = leaves[2].exp() if log_scale else leaves[2].exp().detach().requires_grad_(True)
+        lp = t.distributions.Normal(full(leaves[1], ld), full(sc, sd)).log_prob(full(leaves[0], vd)).sum(-1)
+        red = [i for i, d in enumerate(pool) if not has(od, d)]
+        lp = lp.sum(red) if red else lp
+        keep = [d for d in pool if has(od, d)]
+        lp = lp.reshape([d.size for d in keep])
+        perm = [[i for i, k in enumerate(keep) if k is d][0] for d in od]
+        want = t.autograd.grad(((a * lp).permute(perm) * G).sum(), [leaves[0], leaves[1], leaves[2] if log_scale else sc])
+        scale_arg = raw if log_scale else raw.exp()
+        with t.no_grad():
+            got = E.producer_grads(G, od, [(value, vd), (loc, ld), (scale_arg, sd)], (True, True, True),
+                                   (N.GRAD_VALUE, N.GRAD_LOC, N.GRAD_SCALE), log_scale=log_scale, scale=a)
+        assert got is not None
+        kw = dict(rtol=2e-4, atol=2e-4) if dtype == t.float32 else dict(rtol=1e-9, atol=1e-9)
+        for name, x, w in zip(("value", "loc", "scale"), got, want):
+            t.testing.assert_close(x, w.reshape(x.shape), msg=lambda m: f"case {it} d/d {name}: {m}", **kw)
+    # Bernoulli(logits)
+    dm, dk, dn = Dim("m", 6), Dim("k", 4), Dim("n", 5)
+    y = (t.rand(6, 5, generator=g) < 0.5).float().to(DEV)
+    x = t.randn(6, 4, 5, generator=g).to(DEV)
+    G = t.randn(6, 4, generator=g).to(DEV)
+    xl = x.clone().requires_grad_(True)
+    lp = t.distributions.Bernoulli(logits=xl).log_prob(y[:, None, :]).sum(-1)
+    (want,) = t.autograd.grad((-0.5 * lp * G).sum(), xl)
+    with t.no_grad():
+        got = E.producer_grads(G, (dm, dk), [(y, (dm, dn)), (x, (dm, dk, dn))], (False, True), (0.0, N.GRAD_LOGITS), scale=-0.5)
+    t.testing.assert_close(got[1], want, rtol=2e-5, atol=2e-5)
