@@ -122,3 +122,12 @@ def test_planner_empty_Ks():
     assert E.plan_elimination([("T", "K")], {"T": 10, "K": 3}, []) == []
     steps = E.plan_elimination([("T", "K"), ("K",)], {"T": 10, "K": 3}, [])
     assert steps == [((0, 1), ())]
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs():
+    """The driver's smoke() entry point (one small plate step and one chain, each checked against the oracle)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    importlib.import_module("__graft_entry__").smoke()
