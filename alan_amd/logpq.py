@@ -273,8 +273,22 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
                 continue
             lq = tQ.log_prob_pt(x, dim_order=order)
         else:
-            lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
-                                               dimcache=dimcache)
+            with N.may_defer():                    # (the transition factor only ever feeds the plate's contraction)
+                lp, Kinit_p = prog_P[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
+                                                   dimcache=dimcache)
+            tQ = None if isinstance(prog_Q[var], Timeseries) else prog_Q[var].tdd(scope, dimcache)
+            if tQ is not None and (set(x.ids) | set(tQ.all_arg_ids)) <= own:
+                # an ordinary distribution as the timeseries' approximate posterior, on the group's own dims: its
+                # -(log Q [+ log K]) is a producer-written factor, as above
+                logK_here = 0.0 if (pqs or negqs) else math.log(K)
+                with N.may_defer():
+                    nq = tQ.log_prob_pt(x, dim_order=order, affine=(-1.0, -logK_here, own))
+                assert set(nq.ids) <= own
+                negqs.append(nq)
+                logPs.append(lp)
+                if Kinit_p is not None:
+                    Kinits.append(Kinit_p)
+                continue
             lq, Kinit_q = prog_Q[var].log_prob(x, scope=scope, T_dim=T_dim, K_dim=Kdim, dim_order=order,
                                                dimcache=dimcache)
         if Kinit_q is not None:
