@@ -12,6 +12,7 @@
 // top-down, one launch per round.  At T=1000, K=30 the whole input is 3.6 MB: this path is latency-bound.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -23,6 +24,24 @@ template <typename T>
 struct alignas(4 * sizeof(T)) Vec4 {
     T x, y, z, w;
 };
+
+// Further terms of the chain's input: the factors of a timeseries plate are ADDED into one [T, K, K] tensor before the
+// chain (reduce_Ks with no K to sum, logpq.py:128) -- here the first round adds them on load instead (strides may be
+// 0: a factor without the K_init dim).  n = 0 on every later round.
+template <typename T>
+struct ChainAdd {
+    const T *p[2];
+    int64_t sB[2], sT[2], sR[2], sC[2];
+    int32_t n;
+};
+
+template <typename T>
+__device__ __forceinline__ T chain_in(const T *ms, int64_t off, const ChainAdd<T> &ad, int64_t b, int64_t t, int i, int j) {
+    T v = ms[off];
+    if (ad.n > 0) v += ad.p[0][b * ad.sB[0] + t * ad.sT[0] + i * ad.sR[0] + j * ad.sC[0]];
+    if (ad.n > 1) v += ad.p[1][b * ad.sB[1] + t * ad.sT[1] + i * ad.sR[1] + j * ad.sC[1]];
+    return v;
+}
 
 template <typename T>
 __device__ __forceinline__ void lds_max(T *addr, T v) {   // ds_max_f32 / ds_max_f64: NaN-ignoring, like fmax
@@ -42,7 +61,7 @@ __device__ __forceinline__ void lds_max(T *addr, T v) {   // ds_max_f32 / ds_max
 template <typename T, int ME, int NT>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
     const T *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int T_total, int seg_len, int K,
-    T *out, T *vec_out) {
+    T *out, T *vec_out, const ChainAdd<T> ad) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // blockIdx.y = which chain of the batch (timeseries plates nested under other plate / K dims: the reference's
     // lp.order(T, K_init, K_curr) leaves those as torchdim batch dims of the matmuls, logpq.py:133-135)
@@ -69,11 +88,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
     // P <- matrix t0, C <- matrix t0+1 (log space), maxima by atomics
     for (int e = tid; e < KK; e += CHAIN_THREADS) {
         const int i = e / K, j = e - i * K;
-        const T v = ms[(int64_t)t0 * sT + i * sRow + j * sCol];
+        const T v = chain_in(ms, (int64_t)t0 * sT + i * sRow + j * sCol, ad, (int64_t)blockIdx.y, (int64_t)t0, i, j);
         P[i * PS + j] = v;
         lds_max(&pm[i], v);
         if (t0 + 1 < t1) {
-            const T c = ms[(int64_t)(t0 + 1) * sT + i * sRow + j * sCol];
+            const T c = chain_in(ms, (int64_t)(t0 + 1) * sT + i * sRow + j * sCol, ad, (int64_t)blockIdx.y, (int64_t)(t0 + 1), i, j);
             C[i * KP + j] = c;
             lds_max(&cm[j], c);
         }
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_segment_kernel(
                 const int e = tid + q * CHAIN_THREADS;
                 if (e < KK) {
                     const int i = e / K, j = e - i * K;
-                    creg[q] = ms[(int64_t)tt * sT + i * sRow + j * sCol];
+                    creg[q] = chain_in(ms, (int64_t)tt * sT + i * sRow + j * sCol, ad, (int64_t)blockIdx.y, (int64_t)tt, i, j);
                 }
             }
         }
@@ -200,7 +219,7 @@ constexpr int TREE_THREADS = 1024;
 template <typename T>
 __global__ __launch_bounds__(TREE_THREADS) void chain_tree_kernel(
     const T *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_in, int K, int rounds,
-    T *out1, T *out2, T *out3, int n1, int n2, int n3, T *vec_out) {
+    T *out1, T *out2, T *out3, int n1, int n2, int n3, T *vec_out, const ChainAdd<T> ad) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int KP = (K + 3) & ~3, NJG = KP >> 2, PS = KP + 4, KK = K * K;
     const int SLOT = KP * PS + KP * KP + 2 * KP;        // P [KP][PS], C [KP][KP], row maxima of P, column maxima of C
@@ -227,12 +246,12 @@ __global__ __launch_bounds__(TREE_THREADS) void chain_tree_kernel(
         for (int e = gt; e < KK; e += 256) {
             const int i = e / K, j = e - i * K;
             if (a < m) {
-                const T v = ms[(int64_t)(seg * W + a) * sT + i * sRow + j * sCol];
+                const T v = chain_in(ms, (int64_t)(seg * W + a) * sT + i * sRow + j * sCol, ad, b, (int64_t)(seg * W + a), i, j);
                 P[i * PS + j] = v;
                 lds_max(&pm[i], v);
             }
             if (a + 1 < m) {
-                const T c = ms[(int64_t)(seg * W + a + 1) * sT + i * sRow + j * sCol];
+                const T c = chain_in(ms, (int64_t)(seg * W + a + 1) * sT + i * sRow + j * sCol, ad, b, (int64_t)(seg * W + a + 1), i, j);
                 C[i * KP + j] = c;
                 lds_max(&cm[j], c);
             }
@@ -341,7 +360,19 @@ static TreeLayout tree_layout(int64_t B, int64_t T, int64_t K, size_t elt) {
 
 template <typename T>
 static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
-                     int64_t sCol, void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream) {
+                     int64_t sCol, void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream,
+                     const void *const *more = nullptr, const int64_t *more_strides = nullptr, int n_more = 0) {
+    ChainAdd<T> ad0, none;
+    std::memset(&ad0, 0, sizeof(ad0));
+    std::memset(&none, 0, sizeof(none));
+    if (n_more < 0 || n_more > 2) return ALAN_ERR_UNSUPPORTED;
+    for (int q = 0; q < n_more; ++q) {
+        if (!more || !more[q] || !more_strides) return ALAN_ERR_BAD_DESC;
+        ad0.p[q] = (const T *)more[q];
+        ad0.sB[q] = more_strides[4 * q], ad0.sT[q] = more_strides[4 * q + 1];
+        ad0.sR[q] = more_strides[4 * q + 2], ad0.sC[q] = more_strides[4 * q + 3];
+    }
+    ad0.n = n_more;
     const size_t KP = (size_t)((K + 3) & ~3);
     const size_t smem = (KP * (KP + 4) + KP * KP + 4 * KP) * sizeof(T);
     if (K > 100 || smem > 160 * 1024) return ALAN_ERR_UNSUPPORTED;
@@ -369,7 +400,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             const bool last = r + rounds == tl.L;
             hipLaunchKernelGGL(tk, dim3((uint32_t)nseg, (uint32_t)B), dim3(TREE_THREADS), 8 * slot, stream, src, cB, cT,
                                cR, cC, (int)tl.n[r], (int)K, rounds, o[0], o[1], o[2], nn[0], nn[1], nn[2],
-                               last ? (T *)out_vec : (T *)nullptr);
+                               last ? (T *)out_vec : (T *)nullptr, r == 0 ? ad0 : none);
             if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
             r += rounds;
             src = o[rounds - 1];
@@ -382,7 +413,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         for (int r = 1; r <= tl.L; ++r) {
             T *dst = (T *)((char *)ws + tl.off[r]);
             hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
-                               cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr);
+                               cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr,
+                               r == 1 ? ad0 : none);
             if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
             src = dst;
             cB = tl.n[r] * K * K;
@@ -555,6 +587,22 @@ extern "C" int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_
     if (dtype == ALAN_F64)
         return chain_run<double>(ms, B, T, K, sB, sT, sRow, sCol, out_chain, out_vec, workspace, workspace_bytes,
                                  (hipStream_t)stream);
+    return ALAN_ERR_BAD_DESC;
+}
+
+extern "C" int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
+                                         int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
+                                         void *workspace, size_t workspace_bytes, void *stream) {
+    if (!terms || !strides || n_terms < 1 || n_terms > 3 || !terms[0] || B < 1 || T < 1 || K < 1 ||
+        (!out_chain && !out_vec))
+        return ALAN_ERR_BAD_DESC;
+    if (T >= (1ll << 31) || B > 65535) return ALAN_ERR_UNSUPPORTED;
+    if (dtype == ALAN_F32)
+        return chain_run<float>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
+                                workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1);
+    if (dtype == ALAN_F64)
+        return chain_run<double>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
+                                 workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1);
     return ALAN_ERR_BAD_DESC;
 }
 

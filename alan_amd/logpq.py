@@ -104,6 +104,39 @@ def _fused_plate_step(lps, Ks, plate):
     return None if res is None else PT(*res)
 
 
+def _chain_of_terms(lps, Ks, core):
+    """A timeseries plate with no K of its own to sum: its factors are only ADDED into the chain's [T, K_init, K]
+    input (reduce_Ks with Ks = [], logpq.py:128) -- the chain's first round can add them on load (no launch, no
+    3.6 MB tensor written and read back at T=1000, K=30).  Gradient-free, <= 3 factors, at most one batch dim."""
+    if Ks or t.is_grad_enabled() or not 1 <= len(lps) <= 3 or N._TIMER[0] is not None:
+        return None
+    if any(lp.n_pos for lp in lps) or any(isinstance(lp, LazyNormalPT) for lp in lps):
+        return None
+    xs = [lp.x for lp in lps]
+    if not all(x.is_cuda and x.dtype == xs[0].dtype for x in xs) or xs[0].dtype not in (t.float32, t.float64):
+        return None
+    K = core[1].size
+    from .contract import CHAIN_KERNEL_MAX_K
+    if core[2].size != K or K > CHAIN_KERNEL_MAX_K.get(xs[0].dtype, 0):
+        return None
+    core_ids = [id(d) for d in core]
+    batch = []
+    for lp in lps:
+        for d in lp.dims:
+            if id(d) not in core_ids and all(d is not b for b in batch):
+                batch.append(d)
+    if len(batch) > 1 or not all(any(lp.has(c) for lp in lps) for c in core):
+        return None
+    ids = [id(d) for d in (*batch, *core)]
+    shape = [d.size for d in (*batch, *core)]
+    terms = []
+    for lp in lps:
+        x = pt_align(lp, ids).expand(shape)                     # stride 0 where the factor lacks a dim
+        terms.append(x if batch else x.unsqueeze(0))
+    vec = N.chain_logmmexp_terms(terms)
+    return PT(vec if batch else vec[0], (*batch, core[1]))
+
+
 def _contract(lps, Ks, plate=()):
     fused = _fused_plate_step(lps, Ks, plate)
     if fused is not None:
@@ -191,10 +224,13 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         # timeseries plate (logpq.py:131-143): eliminate the ordinary Ks, then the chain over T
         assert len(K_inits) == 1 and len(K_currs) == 1
         assert prev_lpq is None, "a timeseries plate cannot be split"
+        core = (platedim, K_inits[0], K_currs[0])
+        fast = _chain_of_terms(lps, Ks, core)
+        if fast is not None:
+            return fast
         lp = _contract(lps, Ks)
         # lp.order(T, K_init, K_curr) (logpq.py:133): every other dim -- enclosing plates, Ks of parents in higher
         # plates -- stays a batch dim of the chain
-        core = (platedim, K_inits[0], K_currs[0])
         assert all(lp.has(d) for d in core)
         batch = tuple(d for d in lp.dims if not any(d is c for c in core))
         ms = pt_align(lp, tuple(id(d) for d in (*batch, *core)))

@@ -116,6 +116,10 @@ def lib():
         L.alan_chain_logmmexp_batched.restype = C.c_int
         L.alan_chain_logmmexp_batched.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 7), C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_chain_logmmexp_terms.restype = C.c_int
+        L.alan_chain_logmmexp_terms.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
+                                                C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
         L.alan_chain_backward_batched_workspace_bytes.restype = C.c_size_t
         L.alan_chain_backward_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp_backward_batched.restype = C.c_int
@@ -131,7 +135,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_batch", "a
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
-           "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched",
+           "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_abi_version", "alan_build_target")
 
@@ -317,6 +321,31 @@ def chain_logmmexp(ms, want_chain=False):
     if not batched:
         return vec[0], (chain[0] if want_chain else None), tree
     return vec, chain, tree
+
+
+def chain_logmmexp_terms(terms):
+    """logsumexp(chain_logmmexp(sum of terms), -1) with the sum taken on load: ``terms`` = up to 3 device tensors
+    [B,T,K,K] (expanded / stride-0 views welcome).  -> vec [B,K]."""
+    L = lib()
+    flush()
+    assert 1 <= len(terms) <= 3
+    B, T, K, K2 = terms[0].shape
+    assert K == K2 and all(x.shape == terms[0].shape and x.dtype == terms[0].dtype for x in terms)
+    for x in terms:
+        require_device(x, "timeseries factor")
+    if B > CHAIN_MAX_BATCH:
+        raise NativeError(f"alan_chain_logmmexp_terms: at most {CHAIN_MAX_BATCH} chains per call, got {B}")
+    code = dtype_code(terms[0].dtype)
+    device = terms[0].device
+    vec = t.empty(B, K, dtype=terms[0].dtype, device=device)
+    nbytes = L.alan_chain_batched_workspace_bytes(B, T, K, code)
+    tree = t.empty(max(nbytes, 1), dtype=t.uint8, device=device)
+    ptrs = (C.c_void_p * len(terms))(*[x.data_ptr() for x in terms])
+    strides = (C.c_int64 * (4 * len(terms)))(*[s for x in terms for s in x.stride()])
+    rc = L.alan_chain_logmmexp_terms(ptrs, strides, len(terms), code, B, T, K, None, vec.data_ptr(), tree.data_ptr(),
+                                     nbytes, current_stream(device))
+    check(rc, "alan_chain_logmmexp_terms")
+    return vec
 
 
 def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):

@@ -190,6 +190,14 @@ int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_
                                 int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
                                 void *out_chain, void *out_vec,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* The forward with the chain's input given as the SUM of up to 3 terms -- the factors of a timeseries plate, which
+ * the reference adds into one [T, K_init, K] tensor first (reduce_Ks with no K to sum, logpq.py:128): the first round
+ * adds them on load.  terms[i] is [B, T, K, K] with element strides strides[4 i .. 4 i + 3] = (sB, sT, sRow, sCol), 0
+ * where a term lacks a dim.  Workspace as alan_chain_batched_workspace_bytes.  (No backward of its own: with
+ * gradients to record, add the factors first.) */
+int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
+                              int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
+                              void *workspace, size_t workspace_bytes, void *stream);
 size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                          int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,

@@ -87,3 +87,22 @@ def test_large_K_batch_goes_through_the_matvec_scan():
     want, _ = _oracle(ms)
     t.testing.assert_close(got.cpu().double(), want, rtol=2e-5, atol=1e-4)
     assert chain_logmmexp(ms[:, :, :3, :3].to(DEV)).shape == (B, 3, 3)
+
+
+@pytest.mark.parametrize("B,T,K,dtype", [(1, 7, 5, t.float32), (3, 40, 30, t.float32), (2, 9, 40, t.float64), (1, 1, 3, t.float32)])
+def test_chain_of_terms_adds_the_factors_on_load(B, T, K, dtype):
+    """alan_chain_logmmexp_terms: the chain of a SUM of up to three factors (a timeseries plate's transition factor
+    [T,K_init,K], its -(log Q + log K) [T,K] and a likelihood [T,K], the latter two without the K_init dim: stride 0)
+    against adding them first."""
+    g = t.Generator().manual_seed(B + T + K)
+    a = _ms(B, T, K, dtype, 5).to(DEV)
+    b = t.randn(B, T, 1, K, generator=g, dtype=t.float64).to(dtype).to(DEV)
+    c = t.randn(1, T, 1, K, generator=g, dtype=t.float64).to(dtype).to(DEV)
+    shape = (B, T, K, K)
+    for terms in ([a], [a, b.expand(shape)], [a, b.expand(shape), c.expand(shape)]):
+        got = N.chain_logmmexp_terms(terms)
+        want, _ = _oracle(sum(x.cpu().double() for x in terms))
+        kw = dict(rtol=2e-5, atol=2e-5 * (1 + T ** 0.5)) if dtype == t.float32 else dict(rtol=1e-11, atol=1e-10)
+        t.testing.assert_close(got.cpu().double(), want, **kw)
+    one, _, _ = N.chain_logmmexp(a)
+    assert t.equal(N.chain_logmmexp_terms([a]), one)                       # one term = the plain entry point
