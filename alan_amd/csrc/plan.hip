@@ -271,10 +271,46 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
     return ALAN_OK;
 }
 
+// A log-sum-exp / sum with FEW outputs over a HUGE reduce space of several dims (a whole factor reduced to a handful of
+// values) would be one workgroup per output walking millions of strided elements.  Two launches instead: the largest
+// reduce dim is kept by the first (outputs x that dim: plenty of parallelism, short reductions), reduced by the second.
+// (log-sum-exp of log-sum-exps is the log-sum-exp; the reference's +eps enters once per stage: 1e-7 relative.)
+static int peel_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint32_t plate) {
+    if (plate || (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM) || d.lse_out.data || d.ev_start || d.ev_stop) return -1;
+    double n_out = 1, n_red = 1;
+    int nred = 0, best = -1;
+    for (int i = 0; i < d.ndim; ++i) {
+        if (((keep >> i) & 1)) n_out *= (double)d.size[i];
+        if (((red >> i) & 1) && d.size[i] > 1) {
+            n_red *= (double)d.size[i];
+            ++nred;
+            if (best < 0 || d.size[i] > d.size[best]) best = i;
+        }
+    }
+    if (nred < 2 || n_out > 256 || n_red < 65536) return -1;
+    if (n_out * (double)d.size[best] > (double)(1 << 24)) return -1;
+    return best;
+}
+
+static void peel_layout(const alan_reduce_desc_t &d, uint32_t keep, int p, alan_tensor_t &v, int64_t &numel) {
+    std::memset(&v, 0, sizeof(v));
+    int64_t st = 1;
+    for (int i = d.ndim - 1; i >= 0; --i)
+        if ((keep >> i) & 1) {
+            v.stride[i] = d.size[i] > 1 ? st : 0;
+            st *= d.size[i];
+        }
+    v.stride[p] = st;
+    numel = st * d.size[p];
+    v.dtype = d.out.dtype;
+    v.scale = 1.f;
+}
+
 // alan_reduce_batch: is this problem one launch of the small kernel?  Fills what that launch needs.
 static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
     uint32_t keep, red, plate;
     if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
+    if (peel_dim(d, keep, red, plate) >= 0) return false;
     mode = d.mode;
     if (mode == ALAN_MODE_WEXPSUM) return false;
     if (mode == ALAN_MODE_LSE && red == 0) mode = ALAN_MODE_SUM;
@@ -344,6 +380,15 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
+    {
+        const int p = peel_dim(*d, keep, red, plate);
+        if (p >= 0) {
+            alan_tensor_t v;
+            int64_t numel;
+            peel_layout(*d, keep, p, v, numel);
+            return ((size_t)numel * dtype_bytes(v.dtype) + 255) & ~(size_t)255;
+        }
+    }
     if (!plate || !red) return 0;
     {
         Canon c;
@@ -371,6 +416,31 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,
         // followed by the plate sum if any.
         return run_single(*d, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream, ev);
+    }
+    {
+        const int p = peel_dim(*d, keep, red, plate);
+        if (p >= 0) {
+            alan_tensor_t v;
+            int64_t numel;
+            peel_layout(*d, keep, p, v, numel);
+            if (!workspace || workspace_bytes < (size_t)numel * dtype_bytes(v.dtype)) return ALAN_ERR_WORKSPACE;
+            v.data = workspace;
+            rc = run_single(*d, keep | (1u << p), red & ~(1u << p), d->mode, v, 0.0, stream);
+            if (rc != ALAN_OK) return rc;
+            alan_reduce_desc_t s2;
+            std::memset(&s2, 0, sizeof(s2));
+            s2.mode = d->mode;
+            s2.ndim = d->ndim;
+            for (int i = 0; i < d->ndim; ++i) {
+                const bool k = (keep >> i) & 1;
+                s2.size[i] = (k || i == p) ? d->size[i] : 1;
+                s2.role[i] = i == p ? ALAN_REDUCE : ALAN_KEEP;
+            }
+            s2.n_factors = 1;
+            s2.factor[0] = v;
+            s2.out = d->out;
+            return run_single(s2, keep, 1u << p, d->mode, d->out, d->add_const, stream);
+        }
     }
     if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream, ev);
 

@@ -153,7 +153,12 @@ class _FusedNormalLogProb(t.autograd.Function):
                         if rows % b == 0), 1)
             D2 = (D * D).view(rows // blk, blk, E)
             S2 = _sum_leading(t.bmm(Gp.view(rows // blk, blk, nS).transpose(1, 2), D2).view(rows // blk, nS * E)).view(nS, E)
-            S0 = _sum_leading(Gp).unsqueeze(-1)                         # [nS, 1]
+            # <G> over everything but the scale dims: one alan_reduce (which takes few-outputs / huge-reduce sums in
+            # two launches), laid out like the scale rows
+            from . import engine as E
+            sd_ids = {id(d) for d in sd}
+            s0, s0d = E.reduce_factors([(G.detach(), od)], plate=tuple(d for d in od if id(d) not in sd_ids))
+            S0 = pt_align(PT(s0, s0d), tuple(id(d) for d in sd)).reshape(nS, 1)
             gs = w2 * S2 - S0 if log_scale else (w2 * S2 - S0) / s2
             gs = gs.reshape(s_shape)
         return gv, gl, gs

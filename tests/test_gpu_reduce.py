@@ -618,3 +618,27 @@ def test_producer_grads_match_torch_distributions_autograd():
     with t.no_grad():
         got = E.producer_grads(G, (dm, dk), [(y, (dm, dn)), (x, (dm, dk, dn))], (False, True), (0.0, N.GRAD_LOGITS), scale=-0.5)
     t.testing.assert_close(got[1], want, rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------ few outputs over a huge reduce space
+@pytest.mark.parametrize("shape,keys,reduce,dtype", [
+    ((300, 30, 30, 30), ("m", "a", "b", "z"), ("m", "a", "z"), t.float32),
+    ((64, 64, 64), ("a", "b", "c"), ("a", "b", "c"), t.float32),
+    ((50, 40, 30, 7), ("m", "a", "b", "k"), ("m", "a", "b"), t.float64),
+    ((4096, 33), ("r", "c"), ("r", "c"), t.float32)])
+def test_few_outputs_over_a_huge_reduce_space_take_two_launches_and_agree(shape, keys, reduce, dtype):
+    """logsumexp_dims / sums of a whole factor down to a handful of values (alan_reduce peels the largest reduce dim
+    into a first launch): against the oracle, with a second broadcast factor, in both modes."""
+    g = t.Generator().manual_seed(sum(shape))
+    x = (-0.5 * t.randn(*shape, generator=g, dtype=t.float64) ** 2 - 0.9).to(dtype)
+    small_keys = tuple(k for k in keys if k not in reduce) or (keys[-1],)
+    y = t.randn(*[shape[keys.index(k)] for k in small_keys], generator=g, dtype=t.float64).to(dtype)
+    facs = [(x.to(DEV), keys), (y.to(DEV), small_keys)]
+    got, gd = E.reduce_factors(facs, reduce=reduce)
+    want = orc.align(orc.reduce_Ks([(x.double(), keys), (y.double(), small_keys)], reduce), tuple(gd))
+    kw = dict(rtol=2e-5, atol=2e-5) if dtype == t.float32 else dict(rtol=1e-10, atol=1e-10)
+    t.testing.assert_close(got.cpu().double(), want, **kw)
+    s_got, sd = E.reduce_factors([(x.to(DEV), keys)], plate=reduce)
+    s_want = x.double().sum([keys.index(k) for k in reduce])
+    t.testing.assert_close(s_got.cpu().double().reshape(s_want.shape), s_want, rtol=2e-5 if dtype == t.float32 else 1e-10,
+                           atol=1e-3 if dtype == t.float32 else 1e-8)
