@@ -306,11 +306,47 @@ static void peel_layout(const alan_reduce_desc_t &d, uint32_t keep, int p, alan_
     v.scale = 1.f;
 }
 
+// The same situation with ONE long reduce dim (a column sum of a tall matrix): view the dim as [C, N / C] (a free
+// descriptor slot permitting, N having a divisor of the right size) and let peel_dim() take it from there.
+static bool split_long_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint32_t plate,
+                           alan_reduce_desc_t &out) {
+    if (plate || (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM) || d.lse_out.data || d.ev_start || d.ev_stop) return false;
+    if (d.ndim >= MAXD) return false;
+    double n_out = 1;
+    int p = -1, nred = 0;
+    for (int i = 0; i < d.ndim; ++i) {
+        if ((keep >> i) & 1) n_out *= (double)d.size[i];
+        if (((red >> i) & 1) && d.size[i] > 1) p = i, ++nred;
+    }
+    if (nred != 1 || n_out > 256 || d.size[p] < 65536) return false;
+    const int64_t N = d.size[p];
+    int64_t C = 0;
+    for (int64_t c = std::min<int64_t>(1024, N / 64); c >= 16; --c)
+        if (N % c == 0) {
+            C = c;
+            break;
+        }
+    if (!C) return false;
+    out = d;
+    const int q = d.ndim;
+    out.ndim = d.ndim + 1;
+    out.size[q] = C;
+    out.role[q] = ALAN_REDUCE;
+    out.size[p] = N / C;
+    for (int f = 0; f < d.n_factors; ++f) out.factor[f].stride[q] = d.factor[f].stride[p] * (N / C);
+    out.out.stride[q] = 0;
+    return true;
+}
+
 // alan_reduce_batch: is this problem one launch of the small kernel?  Fills what that launch needs.
 static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
     uint32_t keep, red, plate;
     if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
     if (peel_dim(d, keep, red, plate) >= 0) return false;
+    {
+        alan_reduce_desc_t d2;
+        if (split_long_dim(d, keep, red, plate, d2)) return false;
+    }
     mode = d.mode;
     if (mode == ALAN_MODE_WEXPSUM) return false;
     if (mode == ALAN_MODE_LSE && red == 0) mode = ALAN_MODE_SUM;
@@ -381,6 +417,10 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
     {
+        alan_reduce_desc_t d2;
+        if (split_long_dim(*d, keep, red, plate, d2)) return alan_reduce_workspace_bytes(&d2);
+    }
+    {
         const int p = peel_dim(*d, keep, red, plate);
         if (p >= 0) {
             alan_tensor_t v;
@@ -416,6 +456,10 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,
         // followed by the plate sum if any.
         return run_single(*d, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream, ev);
+    }
+    {
+        alan_reduce_desc_t d2;
+        if (split_long_dim(*d, keep, red, plate, d2)) return alan_reduce(&d2, workspace, workspace_bytes, stream_);
     }
     {
         const int p = peel_dim(*d, keep, red, plate);
