@@ -69,7 +69,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // 16-byte loads in fl
 // staging registers are dead during the reduction, the kernel fits 5 workgroups per CU and the whole
 // grid is resident in a single round.
 template <int MODE, int LOGG, bool VEC2, bool ROT, bool GEN, bool PF, bool SHORT>
-__global__ __launch_bounds__(256, (PF || GEN) ? 4 : 5) void rows_kernel(const RowsDesc d) {
+__global__ __launch_bounds__(256, 4) void rows_kernel(const RowsDesc d) {
     extern __shared__ __align__(16) float lds[];
     constexpr int G = 1 << LOGG;
     constexpr int NS = SHORT ? 8 : 16;   // float2 slots per lane: a lane holds <= 32 (SHORT: 16) row elements
