@@ -151,7 +151,10 @@ class Sample:
             return self._elbo(self._pt_detached, None, computation_strategy)
 
     def _graphed(self, computation_strategy):
-        key = id(computation_strategy)
+        from . import dist as D
+        from . import native as N
+        # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
+        key = (id(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND, N.DEFER_SMALL_LAUNCHES)
         cache = self.__dict__.setdefault("_graphs", {})
         if key not in cache:
             cache[key] = _GraphedELBO(self, computation_strategy)

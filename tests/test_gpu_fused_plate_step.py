@@ -121,3 +121,19 @@ def test_fused_plate_step_fuzz_against_the_two_launch_route():
         two, tdims = E.reduce_factors([(F, (pl, dl, ds, K)), *smalls], reduce=(K,), plate=(pl,))
         two = two if tdims[0] is dl else two.t()
         t.testing.assert_close(out, two, rtol=3e-5, atol=3e-4, msg=lambda m: f"{(M, NK, NL, NS, Ev, n_small, log_scale)}: {m}")
+
+
+def test_a_captured_graph_is_not_reused_under_other_routing_switches(monkeypatch):
+    fx = load_golden("e2e_movielens_K3.pt")
+    if fx["data"]["obs"][0].dtype != t.float32:
+        fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})
+    prob = models.BUILDERS["movielens"](fx).to(DEV)
+    sample = models.sample_from_fixture(prob, fx, DEV)
+    a = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
+    calls = []
+    real = E.normal_lse
+    monkeypatch.setattr(E, "normal_lse", lambda *x, **k: (calls.append(1), real(*x, **k))[1])
+    monkeypatch.setattr(D, "FUSE_PLATE_STEP", True)
+    b = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))         # a NEW capture, through the fused kernel
+    assert len(calls) >= 1 and abs(a - b) <= 1e-6 * abs(a)
+    assert len(sample._graphs) == 2
