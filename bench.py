@@ -312,6 +312,8 @@ def main():
         out["producer"] = {"kernel": "alan::normal_mfma_kernel (fused Normal log-prob producer of F: v_mfma_f32_32x32x2_f32 over "
                                      "the event dim, store-bound)",
                            "us_per_launch": sum(sel) / len(sel) * 1e3, "bytes_written": big,
+                           "achieved_write_GBps": big / (sum(sel) / len(sel)) / 1e6,
+                           "write_floor_us": 6.6 if K == 30 else None,      # plain fill of the same bytes (tools/readfloor.hip)
                            "launches_timed": len(sel)}
     if not args.no_extras:
         # BASELINE config C4 in the same run, under the same key at every N: movielens K=100,
