@@ -57,3 +57,38 @@ def test_sharded_split_world2_on_gpu():
         assert abs(r["elbo"] - r["ref"]) <= 1e-4 * abs(r["ref"]) + 1e-5, r
         assert r["grad_err"] < 5e-2, r
     assert res[0]["elbo"] == res[1]["elbo"]
+
+
+@pytest.mark.gpu
+def test_sharded_split_with_its_rccl_all_reduce_captures_into_a_graph(monkeypatch):
+    """One rank on one GPU (a 1-rank "nccl" group, Split.sharded forced on): the sharded evaluation -- queued producer
+    launches flushed before the collective, the RCCL all-reduce itself -- gives the unsharded value eagerly and as a
+    captured, replayed HIP graph.  (The multi-rank arithmetic is covered on the CPU with gloo above.)"""
+    import os
+    import torch as t
+    import torch.distributed as dist
+    import alan_amd as alan
+    from alan_amd import split as S
+    import models
+    from conftest import load_golden
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=t.device("cuda", 0))
+    except Exception as e:                                   # no RCCL on this box: nothing to pin here
+        pytest.skip(f"cannot create a 1-rank nccl group: {e}")
+    try:
+        monkeypatch.setattr(S.Split, "sharded", lambda self: self.shard)
+        fx = load_golden("e2e_movielens_K10.pt")
+        prob = models.BUILDERS["movielens"](fx).to("cuda")
+        sample = models.sample_from_fixture(prob, fx, "cuda")
+        ref = float(sample.elbo_nograd(alan.no_checkpoint))
+        strat = alan.Split("plate_1", 38, shard=True)
+        eager = float(sample.elbo_nograd(strat))
+        g1 = float(sample.elbo_nograd(strat, graph=True))
+        g2 = float(sample.elbo_nograd(strat, graph=True))
+        assert abs(eager - ref) <= 1e-6 * abs(ref)
+        assert g1 == g2 and abs(g1 - eager) <= 1e-6 * abs(eager)
+    finally:
+        dist.destroy_process_group()
