@@ -287,7 +287,8 @@ static int peel_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, ui
             if (best < 0 || d.size[i] > d.size[best]) best = i;
         }
     }
-    if (nred < 2 || n_out > 256 || n_red < 65536) return -1;
+    if (nred < 2) return -1;
+    if (!(n_out <= 256 && n_red >= 65536) && !(n_out <= 2048 && n_red >= 4096 && n_out * n_red >= (double)(1 << 21))) return -1;
     if (n_out * (double)d.size[best] > (double)(1 << 24)) return -1;
     return best;
 }
@@ -318,7 +319,11 @@ static bool split_long_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t 
         if ((keep >> i) & 1) n_out *= (double)d.size[i];
         if (((red >> i) & 1) && d.size[i] > 1) p = i, ++nred;
     }
-    if (nred != 1 || n_out > 256 || d.size[p] < 65536) return false;
+    // few outputs over one long dim: up to 2048 outputs when the dim is >= 4096 long and the problem >= 2 Mi elements
+    if (nred != 1) return false;
+    const bool tall = n_out <= 256 && d.size[p] >= 65536;
+    const bool wide = n_out <= 2048 && d.size[p] >= 4096 && n_out * (double)d.size[p] >= (double)(1 << 21);
+    if (!tall && !wide) return false;
     const int64_t N = d.size[p];
     int64_t C = 0;
     for (int64_t c = std::min<int64_t>(1024, N / 64); c >= 16; --c)

@@ -144,7 +144,9 @@ class _FusedNormalLogProb(t.autograd.Function):
             if need_v:
                 gv = (-T.sum(1)).reshape(v_shape)
             if need_l:
-                gl = _sum_leading(T.view(nV, nL * E)).reshape(l_shape)
+                from . import engine as E_
+                gsum, gd = E_.reduce_factors([(T, ("v", "l", "e"))], plate=("v",))    # two launches (long dim split)
+                gl = (gsum if gd == ("l", "e") else gsum.t()).reshape(l_shape)
         if need_s:
             # [nS, E] = Gp^T @ d^2 with K = n_value * n_loc (270,000 at movielens K=30): a batched product over row
             # blocks, then the blocks summed by alan_reduce (no K = 270,000 GEMM, no multi-block torch reduction)

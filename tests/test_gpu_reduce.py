@@ -627,7 +627,8 @@ def test_producer_grads_match_torch_distributions_autograd():
     ((50, 40, 30, 7), ("m", "a", "b", "k"), ("m", "a", "b"), t.float64),
     ((4096, 33), ("r", "c"), ("r", "c"), t.float32),
     ((270000, 30), ("r", "c"), ("r",), t.float32), ((65536 * 3,), ("r",), ("r",), t.float32),
-    ((100003, 5), ("r", "c"), ("r",), t.float32)])      # (a prime length: no split, one workgroup per output)
+    ((100003, 5), ("r", "c"), ("r",), t.float32),       # (a prime length: no split, one workgroup per output)
+    ((9000, 540), ("r", "c"), ("r",), t.float32), ((64, 70, 600), ("a", "b", "c"), ("a", "b"), t.float32)])
 def test_few_outputs_over_a_huge_reduce_space_take_two_launches_and_agree(shape, keys, reduce, dtype):
     """logsumexp_dims / sums of a whole factor down to a handful of values (alan_reduce peels the largest reduce dim
     into a first launch): against the oracle, with a second broadcast factor, in both modes."""
