@@ -358,6 +358,28 @@ def main():
                                             "graph_last_elbo": float(v_se)})
         except Exception as e:
             out["sample_plus_elbo"]["graph_error"] = f"{type(e).__name__}: {e}"
+        # row a10 (the path's backward) in production use: a whole training iteration -- sample -> elbo_vi | elbo_rws ->
+        # backward -> Adam, the loop of examples/basic_runner.py:81-112 -- captured once and replayed
+        try:
+            import alan_amd as _alan
+            tr = {}
+            for mode in ("vi", "rws"):
+                p_tr = build_problem("cuda")
+                params = list(p_tr.parameters()) if mode == "vi" else list(p_tr.Q.parameters())
+                opt = t.optim.Adam(params, lr=1e-2, capturable=True, maximize=(mode == "rws"))
+                step = _alan.GraphedStep(p_tr, K, opt, method=mode)
+                for _ in range(5):
+                    step()
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    v_tr = step()
+                t.cuda.synchronize()
+                tr[mode] = {"ms_per_iter": (time.perf_counter() - t0) / 50 * 1e3, "last_elbo": float(v_tr)}
+                del step, opt, p_tr
+            out["training_iteration"] = tr
+        except Exception as e:
+            out["training_iteration"] = {"error": f"{type(e).__name__}: {e}"}
         # the optional fused plate step (dist.FUSE_PLATE_STEP: producer + log-sum-exp + plate sum in one launch, the
         # factor never materialised) -- off by default, so `value` and `roofline` above describe the default path
         from alan_amd import dist as _dist
