@@ -645,3 +645,47 @@ def test_few_outputs_over_a_huge_reduce_space_take_two_launches_and_agree(shape,
     s_want = x.double().sum([keys.index(k) for k in reduce])
     t.testing.assert_close(s_got.cpu().double().reshape(s_want.shape), s_want, rtol=2e-5 if dtype == t.float32 else 1e-10,
                            atol=1e-3 if dtype == t.float32 else 1e-8)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_large_few_output_reductions_fuzz(seed):
+    """Random 2-8 Mi element problems with few outputs (the two-launch peel / long-dim split of alan_reduce, and its
+    neighbours that stay single-launch): random dims, roles, permuted storage, a second broadcast factor, log-sum-exp
+    and sum, against torch in fp64 on the device."""
+    import random
+    rng = random.Random(100 + seed)
+    g = t.Generator().manual_seed(100 + seed)
+    nd = rng.randint(2, 4)
+    names = ["a", "b", "c", "d"][:nd]
+    target = rng.choice([2, 4, 8]) * (1 << 20)
+    sizes = [rng.choice([2, 3, 5, 8, 30, 64, 100]) for _ in range(nd - 1)]
+    rest = 1
+    for s_ in sizes:
+        rest *= s_
+    sizes.insert(rng.randrange(nd), max(2, target // rest))
+    keep = [n for n, s_ in zip(names, sizes) if s_ <= 64 and rng.random() < 0.4]
+    keep_sz = 1
+    for n in keep:
+        keep_sz *= sizes[names.index(n)]
+    if keep_sz > 4096:
+        keep = keep[:1]
+    red = tuple(n for n in names if n not in keep)
+    x = (-0.5 * t.randn(*sizes, generator=g) ** 2 - 0.9).to(DEV)
+    perm = list(range(nd))
+    rng.shuffle(perm)
+    inv = [perm.index(i) for i in range(nd)]
+    x = x.permute(*perm).contiguous().permute(*inv)                     # same values, shuffled storage order
+    small = tuple(n for n in names if rng.random() < 0.5) or (names[0],)
+    y = t.randn(*[sizes[names.index(n)] for n in small], generator=g).to(DEV)
+    facs = [(x, tuple(names)), (y, small)]
+    got, gd = E.reduce_factors(facs, reduce=red)
+    full = x.double() + y.double()[tuple(slice(None) if n in small else None for n in names)]
+    axes = [names.index(n) for n in red]
+    want = t.logsumexp(full, axes) if axes else full
+    kd = [n for n in names if n not in red]
+    want = want.permute([kd.index(n) for n in gd]) if len(kd) > 1 else want
+    t.testing.assert_close(got.double(), want, rtol=3e-5, atol=3e-5, msg=lambda m_: f"{sizes} keep {keep}: {m_}")
+    s_got, sd = E.reduce_factors([(x, tuple(names))], plate=red)
+    s_want = x.double().sum(axes) if axes else x.double()
+    s_want = s_want.permute([kd.index(n) for n in sd]) if len(kd) > 1 else s_want
+    t.testing.assert_close(s_got.double(), s_want, rtol=3e-5, atol=2e-2 * (target / (1 << 21)) ** 0.5)
