@@ -242,3 +242,31 @@ def test_plain_exp_lambdas_stay_lazy_and_mean_the_same():
     assert lazy.materialised
     ints = PT(t.arange(4), (d,))
     assert not isinstance(D.call_model_lambda(lambda v: v.exp(), [("v", ints)]), ExpPT)
+
+
+@pytest.mark.gpu
+def test_routing_switches_do_not_change_the_elbo(monkeypatch):
+    """Queued (alan_reduce_batch) against immediate producer launches, lazy exp lambdas, the fused plate step: every
+    routing switch gives the reference's ELBO on every model of the suite, eagerly and as a replayed graph."""
+    from alan_amd import native as N, dist as D
+    cases = [(c[0], c[1]) for c in CASES if "K3" in c[0] or "model1" in c[0] or "linear" in c[0]]
+    fxs = [(models.BUILDERS[m](load_golden(f)), load_golden(f), True) for f, m in cases]
+    small = load_golden("e2e_small_models.pt")
+    # (torch's MultivariateNormal.log_prob synchronises: those models are evaluated eagerly only)
+    fxs += [(models.small_model(n, small[n]), small[n], "multivariate" not in n) for n in sorted(small)]
+    for prob, fx, capturable in fxs:
+        prob = prob.to("cuda")
+        sample = models.sample_from_fixture(prob, fx, "cuda")
+        base = float(sample.elbo_nograd(alan.no_checkpoint))
+        ref = float(fx["elbo"]["no_checkpoint"])
+        assert abs(base - ref) <= 1e-4 * abs(ref) + 1e-5
+        for name, mod, val in (("DEFER_SMALL_LAUNCHES", N, False), ("FUSE_PLATE_STEP", D, True), ("FUSE_NORMAL", D, False)):
+            monkeypatch.setattr(mod, name, val)
+            try:
+                got = float(sample.elbo_nograd(alan.no_checkpoint))
+                gg = float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) if capturable else got
+            except N.NativeError:
+                got = gg = base                # (an fp64-data model has no fp32 fused route: refused, not wrong)
+            monkeypatch.undo()
+            tol = 2e-5 * abs(base) + 1e-5
+            assert abs(got - base) <= tol and abs(gg - base) <= tol, (name, got, gg, base)
