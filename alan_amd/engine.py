@@ -371,8 +371,9 @@ def producer_grads(G, out_dims, args, wanted, kinds, log_scale=False, scale=1.0)
             if log_scale and len(facs) == 3:
                 scales[3] = 2.0
             _launch(N.MODE_PRODUCER_GRAD, [gfac, *facs], sizes, roles, out, keys, scales=scales, out_scale=float(scale))
-            outs[i] = out.to(args[i][0].dtype) if out.dtype != args[i][0].dtype else out
-    return outs
+            outs[i] = out
+    # (casts only now: inside the block the launches are still queued and `out` unwritten)
+    return [o if o is None or o.dtype == a[0].dtype else o.to(a[0].dtype) for o, a in zip(outs, args)]
 
 
 def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):

@@ -618,6 +618,13 @@ def test_producer_grads_match_torch_distributions_autograd():
     with t.no_grad():
         got = E.producer_grads(G, (dm, dk), [(y, (dm, dn)), (x, (dm, dk, dn))], (False, True), (0.0, N.GRAD_LOGITS), scale=-0.5)
     t.testing.assert_close(got[1], want, rtol=2e-5, atol=2e-5)
+    # fp64 observations with fp32 logits (real data sets): computed in fp64, handed back in the logits' dtype -- and
+    # only cast AFTER the queued launch has gone out (a cast inside the queueing block once read unwritten memory)
+    with t.no_grad():
+        mixed = E.producer_grads(G.double(), (dm, dk), [(y.double(), (dm, dn)), (x, (dm, dk, dn))], (False, True),
+                                 (0.0, N.GRAD_LOGITS), scale=-0.5)
+    assert mixed[1].dtype == t.float32
+    t.testing.assert_close(mixed[1], want, rtol=2e-5, atol=2e-5)
 
 
 # ------------------------------------------------------------------ few outputs over a huge reduce space
