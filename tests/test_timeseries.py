@@ -228,3 +228,34 @@ def test_nested_timeseries_hip_equals_oracle_on_the_same_sample_and_has_gradient
         t.testing.assert_close(p1.grad.cpu(), p2.grad, rtol=2e-3, atol=2e-4 * scale, msg=lambda m: f"{n1}: {m}")
         grads += 1
     assert grads >= 4
+
+
+@pytest.mark.gpu
+def test_nested_timeseries_vi_gradients_fused_against_torch_distributions():
+    """elbo_vi on the nested timeseries model with learnable Q: gradients through the fused producers (+ their HIP
+    gradients), the batched chain and its tree backward against the same evaluation with the producers on
+    torch.distributions.  Same seed, same reparameterised particles."""
+    from alan_amd import dist as D
+
+    def grads(fused):
+        old = D.FUSE_NORMAL
+        D.FUSE_NORMAL = fused
+        try:
+            prob, _ = nested_problem(12, opt=True)
+            prob.to("cuda")
+            t.manual_seed(4)
+            t.cuda.manual_seed_all(4)
+            sample = prob.sample(8, reparam=True)
+            elbo = sample.elbo_vi(alan.no_checkpoint)
+            elbo.backward()
+            return float(elbo.detach()), {n: p.grad.detach().cpu().double().clone() for n, p in prob.Q.named_parameters()}
+        finally:
+            D.FUSE_NORMAL = old
+
+    e1, g1 = grads(True)
+    e0, g0 = grads(False)
+    assert abs(e1 - e0) <= 2e-5 * abs(e0) + 1e-4
+    assert len(g0) >= 4
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g1[n], g0[n], rtol=5e-3, atol=5e-4 * scale, msg=lambda m: f"{n}: {m}")
