@@ -346,3 +346,25 @@ def test_vi_gradients_agree_across_computation_strategies():
         for n in g0:
             scale = float(g0[n].abs().max()) + 1e-6
             t.testing.assert_close(g1[n], g0[n], rtol=2e-3, atol=2e-4 * scale, msg=lambda m: f"{type(strat).__name__} {n}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,model", [("e2e_movielens_K3.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown"),
+                                           ("e2e_model1.pt", "model1")])
+def test_all_fp64_problem_matches_the_reference_more_closely(fixture, model):
+    """``problem.double()`` with fp64 particles: every launch takes the fp64 kernels (no MFMA / rows fast paths); the
+    ELBO agrees with the reference's to 1e-7 relative -- tighter than the fp32 run -- eagerly and as a replayed graph."""
+    from alan_amd.dims import PT
+    fx = load_golden(fixture)
+    prob = models.BUILDERS[model](fx).to("cuda").double()
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+
+    def dbl(tree):
+        return {k: (dbl(v) if isinstance(v, dict) else PT(v.x.double(), v.dims)) for k, v in tree.items()}
+
+    sample._pt_detached = dbl(sample._pt_detached)
+    ref = float(fx["elbo"]["no_checkpoint"])
+    got = sample.elbo_nograd(alan.no_checkpoint)
+    assert got.dtype == t.float64
+    assert abs(float(got) - ref) <= 2e-7 * abs(ref) + 1e-6, (float(got), ref)
+    assert float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) == float(got)
