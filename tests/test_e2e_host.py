@@ -290,9 +290,10 @@ def test_routing_switches_do_not_change_the_elbo(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("double", [False, True], ids=["f32", "f64"])
 @pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown"),
                                            ("e2e_model1.pt", "model1")])
-def test_vi_gradients_hip_backward_against_torch_distributions_autograd(fixture, model, monkeypatch):
+def test_vi_gradients_hip_backward_against_torch_distributions_autograd(fixture, model, double, monkeypatch):
     """elbo_vi on a reparameterised sample: gradients of every parameter through the HIP path's backward (one-pass rows
     backward, producer gradients by alan_reduce, the outer-product producer's GEMM backward) against the same
     evaluation with the fused producers switched off, i.e. autograd through torch.distributions on the materialised
@@ -304,6 +305,8 @@ def test_vi_gradients_hip_backward_against_torch_distributions_autograd(fixture,
     def grads(fused):
         monkeypatch.setattr(D, "FUSE_NORMAL", fused)
         prob = models.BUILDERS[model](fx).to("cuda")
+        if double:
+            prob = prob.double()
         t.manual_seed(11)
         t.cuda.manual_seed_all(11)
         sample = prob.sample(K, reparam=True)
@@ -319,7 +322,8 @@ def test_vi_gradients_hip_backward_against_torch_distributions_autograd(fixture,
     assert set(g1) == set(g0) and len(g1) >= 2
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
-        t.testing.assert_close(g1[n], g0[n], rtol=5e-3, atol=5e-4 * scale, msg=lambda m: f"{n}: {m}")
+        kw = dict(rtol=1e-7, atol=1e-8 * scale) if double else dict(rtol=5e-3, atol=5e-4 * scale)
+        t.testing.assert_close(g1[n], g0[n], msg=lambda m: f"{n}: {m}", **kw)
 
 
 @pytest.mark.gpu
