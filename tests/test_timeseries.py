@@ -259,3 +259,22 @@ def test_nested_timeseries_vi_gradients_fused_against_torch_distributions():
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
         t.testing.assert_close(g1[n], g0[n], rtol=5e-3, atol=5e-4 * scale, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.gpu
+def test_timeseries_fp64_matches_the_oracle_to_rounding():
+    """The Kalman model in fp64 (T = 300, K = 30): chain_tree_kernel<double>, the chain's terms added on load, the fp64
+    producers -- against the CPU oracle backend on the same particles, to 1e-10 relative."""
+    from oracle import backend
+    prob, _ = kalman_problem(300)
+    prob.to("cuda").double()
+    t.manual_seed(6)
+    sample = prob.sample(30, reparam=False)
+    gpu = sample.elbo_nograd(alan.no_checkpoint)
+    assert gpu.dtype == t.float64
+    cpu_prob, _ = kalman_problem(300)
+    cpu_prob.double()
+    with backend.installed():
+        cpu = float(_same_sample_on_cpu(sample, cpu_prob, 30).elbo_nograd(alan.no_checkpoint))
+    assert abs(float(gpu) - cpu) <= 1e-10 * abs(cpu) + 1e-9, (float(gpu), cpu)
+    assert float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) == float(gpu)
