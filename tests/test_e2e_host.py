@@ -220,6 +220,12 @@ def test_graphed_eval_draws_fresh_particles_and_agrees_with_eager_in_distributio
                      dtype=t.float64)
     se = float((vals.var() / 200 + eager.var() / 200).sqrt())
     assert abs(float(vals.mean() - eager.mean())) < 5 * se + 1e-3 * abs(float(eager.mean())), (vals.mean(), eager.mean(), se)
+    # under a Split strategy too (chunk loop, stacked sum: all inside the captured graph)
+    ev2 = alan.GraphedEval(prob, 10, alan.Split("plate_1", 38))
+    v2 = t.tensor([float(ev2()) for _ in range(200)], dtype=t.float64)
+    se2 = float((v2.var() / 200 + eager.var() / 200).sqrt())
+    assert len(set(v2.tolist())) > 150
+    assert abs(float(v2.mean() - eager.mean())) < 5 * se2 + 1e-3 * abs(float(eager.mean()))
 
 
 def test_plain_exp_lambdas_stay_lazy_and_mean_the_same():
