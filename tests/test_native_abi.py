@@ -131,3 +131,26 @@ def test_graft_entry_smoke_runs():
     import sys
     sys.path.insert(0, ROOT)
     importlib.import_module("__graft_entry__").smoke()
+
+
+def test_new_entry_points_reject_malformed_arguments_without_touching_the_gpu():
+    L = N.lib()
+    assert L.alan_reduce_batch(None, 0, None) == -1
+    one = (ctypes.POINTER(N.ReduceDesc) * 1)(ctypes.POINTER(N.ReduceDesc)())
+    assert L.alan_reduce_batch(one, 1, None) == -1                        # a null descriptor in the list
+    assert L.alan_chain_logmmexp_terms(None, None, 1, N.F32, 1, 4, 3, None, None, None, 0, None) == -1
+    ptrs = (ctypes.c_void_p * 1)(None)
+    st = (ctypes.c_int64 * 4)(0, 9, 3, 1)
+    assert L.alan_chain_logmmexp_terms(ptrs, st, 1, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # null term
+    assert L.alan_chain_logmmexp_terms(ptrs, st, 4, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # > 3 terms
+    assert L.alan_chain_logmmexp_batched(None, N.F32, 2, 4, 3, 36, 9, 3, 1, None, None, None, 0, None) == -1
+    assert L.alan_chain_logmmexp_backward_batched(None, N.F32, 2, 4, 3, 36, 9, 3, 1, None, None, None, None, None, None,
+                                                  0, None) == -1
+    assert L.alan_normal_lse(None, None, 0, None) == -1
+    assert L.alan_normal_lse_workspace_bytes(None) == 0
+    assert L.alan_chain_batched_workspace_bytes(0, 4, 3, N.F32) == 0
+    d = N.ReduceDesc()
+    d.mode = N.MODE_PRODUCER_GRAD                 # which gradient? factor[0].scale must say (1..4)
+    d.ndim, d.n_factors = 1, 4
+    d.size[0], d.role[0] = 4, N.KEEP
+    assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
