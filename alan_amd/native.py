@@ -192,6 +192,7 @@ class _Queue(threading.local):
 
 _Q = _Queue()
 DEFER_SMALL_LAUNCHES = True
+_POISON_QUEUED = os.environ.get("ALAN_AMD_POISON_QUEUED") == "1"   # fill queued launches' outputs with NaN until they run
 
 
 def queue_active():
@@ -247,6 +248,8 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     if (DEFER_SMALL_LAUNCHES and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
             and (not _Q.pending or _Q.pending[0][1] == device)):
+        if _POISON_QUEUED and len(keepalive) > 1 and keepalive[1] is not None:
+            keepalive[1].fill_(float("nan"))       # debugging aid: a premature read of a queued output shows up as NaN
         _Q.pending.append((desc, device, keepalive))
         if len(_Q.pending) >= 8:
             flush()
