@@ -267,7 +267,9 @@ def test_routing_switches_do_not_change_the_elbo(monkeypatch):
         base = float(sample.elbo_nograd(alan.no_checkpoint))
         ref = float(fx["elbo"]["no_checkpoint"])
         assert abs(base - ref) <= 1e-4 * abs(ref) + 1e-5
-        for name, mod, val in (("DEFER_SMALL_LAUNCHES", N, False), ("FUSE_PLATE_STEP", D, True), ("FUSE_NORMAL", D, False)):
+        # (_POISON_QUEUED: outputs of queued launches hold NaN until the launch runs -- a premature read would surface)
+        for name, mod, val in (("DEFER_SMALL_LAUNCHES", N, False), ("FUSE_PLATE_STEP", D, True), ("FUSE_NORMAL", D, False),
+                               ("_POISON_QUEUED", N, True)):
             monkeypatch.setattr(mod, name, val)
             try:
                 got = float(sample.elbo_nograd(alan.no_checkpoint))
@@ -284,7 +286,7 @@ def test_routing_switches_do_not_change_the_elbo(monkeypatch):
         sample = models.sample_from_fixture(prob, fx, "cuda")
         for strat, key in ((splits[f], "split"), (alan.checkpoint, "checkpoint")):
             ref = float(fx["elbo"][key])
-            for name, mod, val in (("DEFER_SMALL_LAUNCHES", N, False), ("FUSE_PLATE_STEP", D, True)):
+            for name, mod, val in (("DEFER_SMALL_LAUNCHES", N, False), ("FUSE_PLATE_STEP", D, True), ("_POISON_QUEUED", N, True)):
                 monkeypatch.setattr(mod, name, val)
                 try:
                     got = float(sample.elbo_nograd(strat))
