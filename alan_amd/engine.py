@@ -415,9 +415,11 @@ def plan_elimination(dimsets, sizes, Ks):
                     grp = sorted(set(grp) | set(g2))
                     changed = True
         if len(grp) > N.MAX_FACTORS - 1:
-            # too many factors for one launch: pre-add the smallest ones (plain broadcast sum)
+            # too many factors for one launch: pre-add the smallest ones (plain broadcast sum), at most MAX_FACTORS of
+            # them per step -- the loop comes back here until the group fits (with gradients every variable of a
+            # Group contributes log P and -log Q separately: 6 Normals on one K are 12 factors)
             grp_sorted = sorted(grp, key=lambda i: math.prod(sizes[d] for d in live[i]))
-            pre = grp_sorted[: len(grp) - (N.MAX_FACTORS - 2)]
+            pre = grp_sorted[: min(N.MAX_FACTORS, len(grp) - (N.MAX_FACTORS - 2))]
             steps.append((tuple(pre), ()))
             live[nxt] = set().union(*[live[i] for i in pre])
             for i in pre:

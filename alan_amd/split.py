@@ -54,15 +54,36 @@ def chunk_sizes(orig_size, split_size):
     return sizes
 
 
+MERGE_CHUNKS = True
+"""A rank evaluates its block of consecutive Split chunks as ONE contiguous slice of the plate (one set of launches)
+instead of looping over them.  The reference chunks a plate to bound memory on a 24 GB card (docs/source/downstream/
+computation_strategy.rst:12-22, examples/run_movielens.sh); the sum over chunks (logpq.py:151-153) is the plate sum
+of the union, so the result is the same up to fp re-association, and on 288 GB of HBM the whole movielens K=100
+plate (a 1.2 GB factor, when it is materialised at all) fits many times over.  ``Split(..., merge=False)`` -- or this
+switch -- restores the reference's per-chunk loop."""
+
+
+def rank_block(n_chunks, world, rank):
+    """Contiguous block of chunk indices for ``rank`` (balanced to within one chunk)."""
+    base, extra = divmod(n_chunks, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
 class Split:
     """``computation_strategy=Split(platename, split_size)``; ``shard=True`` distributes the chunks over
-    the ranks of ``group`` (default: the world group) -- see module docstring."""
+    the ranks of ``group`` (default: the world group) -- see module docstring.  ``merge`` (default: the module
+    switch MERGE_CHUNKS): evaluate a rank's consecutive chunks as one slice."""
 
-    def __init__(self, platename, split_size, shard=False, group=None):
+    def __init__(self, platename, split_size, shard=False, group=None, merge=None):
         assert isinstance(platename, str)
         assert isinstance(split_size, int)
         self.platename, self.split_size = platename, split_size
         self.shard, self.group = bool(shard), group
+        self.merge = merge
+
+    def merging(self):
+        return MERGE_CHUNKS if self.merge is None else bool(self.merge)
 
     def split_args(self, name, sample, inputs_params, extra_log_factors, data, all_platedims):
         whole = dict(sample=sample, inputs_params=inputs_params, extra_log_factors=extra_log_factors,
@@ -71,6 +92,12 @@ class Split:
             return [whole]
         orig = all_platedims[self.platename]
         sizes = chunk_sizes(orig.size, self.split_size)
+        if self.merging():
+            if not self.sharded():
+                return [whole]                       # one rank: its block is the whole plate
+            world = dist.get_world_size(self.group)
+            self._check_ranks(len(sizes), world)
+            sizes = [sum(sizes[i] for i in rank_block(len(sizes), world, r)) for r in range(world)]
         new_dims = [Dim(f"{self.platename}_split_{i}", s) for i, s in enumerate(sizes)]
 
         def split_tree(tree):
@@ -107,12 +134,14 @@ class Split:
     def my_chunks(self, n_chunks):
         """Contiguous block of chunk indices for this rank (balanced to within one chunk)."""
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        self._check_ranks(n_chunks, world)
+        return rank_block(n_chunks, world, rank)
+
+    @staticmethod
+    def _check_ranks(n_chunks, world):
         if n_chunks < world:
             raise Exception(f"Split produces {n_chunks} chunks but there are {world} ranks; choose a smaller "
                             "split_size so that every rank gets at least one chunk")
-        base, extra = divmod(n_chunks, world)
-        start = rank * base + min(rank, extra)
-        return range(start, start + base + (1 if rank < extra else 0))
 
 
 class _AllReduceSum(t.autograd.Function):

@@ -112,10 +112,19 @@ def draw(prob, K, seed=1):
     return prob.sample(K, reparam=False)
 
 
+def shard_split_size(M, world):
+    """Largest split_size whose chunking of the plate (Split.py:84-95) has at least one chunk per rank."""
+    from alan_amd.split import chunk_sizes
+    size = max(1, math.ceil(M / world))
+    while size > 1 and (size >= M or len(chunk_sizes(M, size)) < world):
+        size -= 1
+    return size
+
+
 def strategy_for(world, K, M=M_USERS):
     import alan_amd as alan
     if world > 1:
-        return alan.Split("plate_1", math.ceil(M / world), shard=True)
+        return alan.Split("plate_1", shard_split_size(M, world), shard=True)
     if K >= 100:
         return alan.Split("plate_1", 38)        # reference launch line: examples/run_movielens.sh
     return alan.no_checkpoint
@@ -228,6 +237,22 @@ def roofline_scaled(K, scale=64, iters=20):
             "algorithmic_bytes": algo, "workload": f"S-ML plate step, K={K}, M={M} (300x{scale})"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as CHILD processes -- one per GPU, RCCL
+    rendezvous on 127.0.0.1 -- before this process has touched the GPU, relay rank 0's JSON line, exit with the
+    launcher's code.  (Nothing is re-exec'ed: this parent never initialises HIP.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,6 +264,8 @@ def main():
                     help="launch every kernel from Python each step instead of replaying a HIP graph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))         # (before any torch.cuda call in this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -248,7 +275,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=t.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr "
+                         f"127.0.0.1 bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus {args.gpus}`")
 
     from alan_amd import native
     from alan_amd.profiling import KernelTimer

@@ -17,6 +17,11 @@ def oracle_launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_o
     from oracle import alan_oracle as orc
     from alan_amd import native as N
     space = tuple(sizes)
+    # the library's descriptor limits (include/alan_mi355.h): the checker refuses what the product would refuse
+    if len(space) > N.MAX_DIMS:
+        raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
+    if len(factors) > N.MAX_FACTORS:
+        raise N.NativeError(f"alan_amd: {len(factors)} factors in one contraction step (max {N.MAX_FACTORS})")
     dtype = out.dtype
     x = 0
     for i, (f, dims) in enumerate(factors):

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rank, world, port, fixture, model, platename, split_size, out_path, device="cpu"):
+def run(rank, world, port, fixture, model, platename, split_size, out_path, device="cpu", merge=None):
     import torch as t
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,7 +22,7 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path, devi
         fx = load_golden(fixture)
         prob = models.BUILDERS[model](fx).to(device)
         sample = models.sample_from_fixture(prob, fx, device)
-        strat = alan.Split(platename, split_size, shard=True)
+        strat = alan.Split(platename, split_size, shard=True, merge=merge)
         import contextlib
         # CPU ranks: test-only oracle backend; GPU ranks: the real HIP library (gloo moves the partials)
         with (backend.installed() if device == "cpu" else contextlib.nullcontext()):

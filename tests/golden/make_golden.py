@@ -17,6 +17,9 @@ What is captured:
                      floors most entries: results then depend on the tree's bracketing, and autograd differentiates
                      through the floor.  Includes batches of chains (torchdim batch dims, logpq.py:133-139).
   e2e_*.pt           sample tree + data + params + ELBO under no_checkpoint / checkpoint / Split
+  e2e_wide_group.pt  a Group of seven Normal latents (more factors on one K than one launch takes)
+  e2e_movielens_K30.pt, e2e_bus_breakdown_K30.pt, e2e_movielens_K100_split38.pt
+                     the same at the BASELINE.json sizes (C2, C3, C4): `make_golden.py baseline_sizes`
 
 This-container-only accommodations (none touches the hot path's arithmetic):
   * ``opt_einsum`` stand-in (see _planner_standin/): elimination ORDER only.
@@ -333,7 +336,7 @@ def named_flat(d):
     return {k: (v.rename(None).detach().clone(), tuple(v.names)) for k, v in d.items()}
 
 
-def capture_problem(tag, problem, K, strategies, seed, keep_calls=True, record_strategy=None):
+def capture_problem(tag, problem, K, strategies, seed, keep_calls=True, record_strategy=None, rws_grads=True):
     t.manual_seed(seed)
     sample = problem.sample(K, True)
     rec = dict(
@@ -357,7 +360,7 @@ def capture_problem(tag, problem, K, strategies, seed, keep_calls=True, record_s
         rec["elbo"][sname] = e.detach().clone()
     # gradients of the ELBO (detached sample, i.e. elbo_rws) wrt Q's raw optimisable parameters
     opt = problem.Q._opt_params
-    if len(opt.keys):
+    if rws_grads and len(opt.keys):
         for p in opt.parameters():
             p.grad = None
         sample.elbo_rws(alan.no_checkpoint).backward()
@@ -449,7 +452,54 @@ def gen_models():
     save("seam_recorded.pt", recorded)
 
 
+def gen_wide_group():
+    """A Group of seven Normal latents over one child plate (a model of ours, written against the reference's API):
+    with gradients each variable contributes log P and -log Q as separate factors of ONE K -- more factors than a
+    single alan_reduce launch takes, so the planner has to pre-add.  The reference evaluates it like any other."""
+    n = 7
+    names = [f"g{i}" for i in range(n)]
+    g = t.Generator().manual_seed(77)
+    data = {"d": t.randn(5, generator=g).refine_names("p")}
+    mean = eval("lambda " + ", ".join(names) + ": " + " + ".join(f"{0.5 + 0.25 * i} * {v}" for i, v in enumerate(names)))
+    P = alan.Plate(**{v: alan.Normal(0.1 * i, 1.0 + 0.1 * i) for i, v in enumerate(names)},
+                   p=alan.Plate(d=alan.Normal(mean, 1.5)))
+    Q = alan.Plate(grp=alan.Group(**{v: alan.Normal(alan.OptParam(0.2 * i - 0.5), alan.OptParam(0.05 * i - 0.1, transformation=t.exp))
+                                     for i, v in enumerate(names)}),
+                   p=alan.Plate(d=alan.Data()))
+    sizes = {"p": 5}
+    prob = alan.Problem(alan.BoundPlate(P, sizes), alan.BoundPlate(Q, sizes), data)
+    strat = {"no_checkpoint": alan.no_checkpoint, "checkpoint": alan.checkpoint, "split": alan.Split("p", 2)}
+    rec, _ = capture_problem("wide_group", prob, 4, strat, 707, keep_calls=False)
+    save("e2e_wide_group.pt", rec)
+
+
+def gen_baseline_sizes():
+    """The BASELINE.json configurations at their literal sizes (SURVEY section 6 timed the reference on exactly these):
+    C2 movielens K=30, C4 movielens K=100 under Split('plate_1', 38) (the reference's unsplit K=100 evaluation would
+    materialise a 21.6 GB [K,K,K,300,18] broadcast: only the Split run is recorded), C3 bus_breakdown K=30.
+    reduce_Ks calls are not recorded here (the K=30 factor alone is 32 MB)."""
+    for mod, sub, splits in [("movielens", "movielens", ("plate_1", 38)),
+                             ("bus_breakdown", "bus_breakdown", ("plate_ID", 40))]:
+        mdir = os.path.join(REF, "examples", "models", sub)
+        sys.path.insert(0, mdir)
+        m = importlib.import_module(mod)
+        prob, *_ = m._load_and_generate_problem("cpu", "opt", run=0, data_dir=os.path.join(mdir, "data") + "/")
+        strat = {"no_checkpoint": alan.no_checkpoint, "checkpoint": alan.checkpoint, "split": alan.Split(*splits)}
+        rec, _ = capture_problem(mod, prob, 30, strat, 230, keep_calls=False)
+        save(f"e2e_{mod}_K30.pt", rec)
+        if mod == "movielens":
+            rec, _ = capture_problem(mod, prob, 100, {"split": alan.Split(*splits)}, 2100, keep_calls=False,
+                                     record_strategy="none", rws_grads=False)
+            save(f"e2e_{mod}_K100_split38.pt", rec)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["wide_group"]:
+        gen_wide_group()
+        sys.exit(0)
+    if sys.argv[1:] == ["baseline_sizes"]:        # one group of fixtures only (the others are not regenerated)
+        gen_baseline_sizes()
+        sys.exit(0)
     if sys.argv[1:] == ["chain_peaked"]:          # one fixture only (the others are not regenerated)
         gen_chain_peaked()
         sys.exit(0)
@@ -458,3 +508,5 @@ if __name__ == "__main__":
     gen_chain()
     gen_chain_peaked()
     gen_models()
+    gen_wide_group()
+    gen_baseline_sizes()

@@ -139,7 +139,25 @@ def bus_breakdown(fx):
     return prob
 
 
+def wide_group(fx):
+    """Seven Normal latents in ONE Group over a child plate (tests/golden/make_golden.py:gen_wide_group): under
+    elbo_vi / elbo_rws that is 14 factors on one K, more than a single alan_reduce launch takes."""
+    n = 7
+    names = [f"g{i}" for i in range(n)]
+    mean = eval("lambda " + ", ".join(names) + ": " + " + ".join(f"{0.5 + 0.25 * i} * {v}" for i, v in enumerate(names)))
+    P = Plate(**{v: Normal(0.1 * i, 1.0 + 0.1 * i) for i, v in enumerate(names)}, p=Plate(d=Normal(mean, 1.5)))
+    Q = Plate(grp=Group(**{v: Normal(OptParam(0.2 * i - 0.5), OptParam(0.05 * i - 0.1, transformation=t.exp))
+                           for i, v in enumerate(names)}),
+              p=Plate(d=Data()))
+    sizes = fx["platesizes"]
+    Qb = BoundPlate(Q, sizes)
+    prob = Problem(BoundPlate(P, sizes), Qb, {"d": _named(fx["data"]["d"])})
+    _load_opt(Qb, fx["Q_inputs_params"])
+    return prob
+
+
 BUILDERS = {
+    "wide_group": wide_group,
     "linear_gaussian": linear_gaussian,
     "linear_gaussian_latents": linear_gaussian_latents,
     "model1": model1,

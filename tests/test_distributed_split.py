@@ -20,16 +20,17 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("merge", [True, False], ids=["merged", "chunked"])
 @pytest.mark.parametrize("fixture,model,plate,size", [
     ("e2e_linear_gaussian_latents.pt", "linear_gaussian_latents", "T", 3),     # chunks [3,3,2,2] -> 2+2
     ("e2e_movielens_K3.pt", "movielens", "plate_1", 150),                      # one chunk per rank
     ("e2e_model1.pt", "model1", "p1", 2),                                      # nested plates, Opt params
 ])
-def test_sharded_split_world2(fixture, model, plate, size):
+def test_sharded_split_world2(fixture, model, plate, size, merge):
     world = 2
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "res")
-        mp.spawn(dist_worker.run, args=(world, _free_port(), fixture, model, plate, size, out),
+        mp.spawn(dist_worker.run, args=(world, _free_port(), fixture, model, plate, size, out, "cpu", merge),
                  nprocs=world, join=True)
         res = [t.load(f"{out}.{r}") for r in range(world)]
     # every rank ends with the same, full-plate ELBO == the reference's Split value

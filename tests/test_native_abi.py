@@ -118,6 +118,18 @@ def test_planner_chain_is_pairwise_not_joint():
     assert sorted(eliminated) == ["K1", "K2", "K3", "K4"]
 
 
+@pytest.mark.parametrize("n", list(range(2, 26)))
+def test_planner_never_exceeds_the_launch_factor_limit(n):
+    """n factors on one K (a Group of n/2 variables under elbo_vi: log P and -log Q each): every step, pre-adds
+    included, takes at most MAX_FACTORS factors, LSE steps one fewer (their backward appends the saved lse)."""
+    steps = E.plan_elimination([("K",)] * (n - 1) + [("K", "p")], {"K": 10, "p": 4}, ["K"])
+    used = [i for ids, _ in steps for i in ids]
+    assert sorted(used) == list(range(len(used)))                 # every factor and intermediate consumed once
+    for ids, now in steps:
+        assert len(ids) <= (N.MAX_FACTORS - 1 if now else N.MAX_FACTORS)
+    assert [now for _, now in steps if now] == [("K",)]
+
+
 def test_planner_empty_Ks():
     assert E.plan_elimination([("T", "K")], {"T": 10, "K": 3}, []) == []
     steps = E.plan_elimination([("T", "K"), ("K",)], {"T": 10, "K": 3}, [])
