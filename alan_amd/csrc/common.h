@@ -3,9 +3,18 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "alan_mi355.h"
 
 namespace alan {
+
+// A tuning / ablation knob from the environment, read ONCE per process (a `static const` at the use site): launch
+// paths never call getenv again, and a later setenv() cannot change the library's behaviour under a running caller.
+constexpr int ENV_UNSET = -2147483647 - 1;
+inline int env_knob(const char *name) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : ENV_UNSET;
+}
 
 constexpr int MAXD = ALAN_MAX_DIMS;
 constexpr int MAXF = ALAN_MAX_FACTORS;

@@ -350,7 +350,8 @@ static void launch_normal_mfma(int nst, dim3 grid, hipStream_t stream, const EvP
 
 // d is filled except for l_chunk.  Declines (false) outside E <= 32, NS <= 128.
 static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const EvPair &ev) {
-    static const bool off = getenv("ALAN_NORMAL_MFMA") && atoi(getenv("ALAN_NORMAL_MFMA")) == 0;   // ablation knob
+    static const int mfma_knob = env_knob("ALAN_NORMAL_MFMA");                                   // ablation knob
+    const bool off = mfma_knob == 0;
     if (off || d.E > 32 || d.NS > 128) return false;
     {   // lanes address the output by a 32-bit element offset from a wave-uniform base
         int64_t span = (int64_t)(d.NL - 1) * d.l_os + (int64_t)(d.NS - 1) * d.s_os;
@@ -359,7 +360,7 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
         d.out_bytes = (uint32_t)((span + 1) * 4);
         // beyond the 256 MiB Infinity Cache the factor streams to HBM, where this kernel's 2 x 128-byte runs per store
         // reach 2.3 TB/s against the vector kernel's 3.0 (K=100 unsplit, 1.2 GB); inside it, 4.2 against 2.9
-        static const bool force = getenv("ALAN_NORMAL_MFMA") && atoi(getenv("ALAN_NORMAL_MFMA")) == 2;
+        const bool force = mfma_knob == 2;
         if (d.out_bytes > (224u << 20) && !force) return false;
         for (int k = 0; k < d.nv; ++k)
             if (d.v_os[k] < 0) return false;
@@ -371,7 +372,8 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
     // 512 slots ran two rounds: 25 us of MFMA phase for 11 us of MFMAs.)
     const uint32_t slots = 256u * (nst == 4 ? 2u : nst == 2 ? 3u : 4u);
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, slots / std::max(1u, gx)));
-    if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
+    static const int gy_knob = env_knob("ALAN_NORMAL_GY");                                   // tuning knob
+    if (gy_knob != ENV_UNSET) gy = std::min<uint32_t>(d.NL, std::max(1, gy_knob));
     d.l_chunk = (d.NL + gy - 1) / gy;
     gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
     const dim3 grid(gx, gy);
@@ -448,7 +450,8 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
     d.out_scale = out_scale;
     d.add_const = (float)add_const;
 #ifdef ALAN_ABLATE
-    if (const char *e = getenv("ALAN_NORMAL_ABLATE")) d.dbg = atoi(e);
+    static const int ablate_knob = env_knob("ALAN_NORMAL_ABLATE");
+    if (ablate_knob != ENV_UNSET) d.dbg = ablate_knob;
 #endif
     if (try_normal_mfma(d, NV, stream, ev)) return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     {   // value rows contiguous in row-index order?  (voff(r) = r * E)
@@ -458,19 +461,22 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
             contig = contig && d.v_vs[k] == run;
             run *= d.vdiv[k].d;
         }
-        if (const char *e = getenv("ALAN_NORMAL_STAGE")) contig = contig && atoi(e) != 0;   // tuning knob
+        static const int stage_knob = env_knob("ALAN_NORMAL_STAGE");                        // tuning knob
+        if (stage_knob != ENV_UNSET) contig = contig && stage_knob != 0;
         d.rows_contig = contig ? 1 : 0;
     }
 
     // two value rows per thread once that still leaves >= 512 workgroups
     int R = (NV * (int64_t)d.NL >= 512ll * 512) ? 2 : 1;
-    if (const char *e = getenv("ALAN_NORMAL_R")) R = atoi(e) == 2 ? 2 : 1;   // tuning knob
+    static const int r_knob = env_knob("ALAN_NORMAL_R");                      // tuning knob
+    if (r_knob != ENV_UNSET) R = r_knob == 2 ? 2 : 1;
     const uint32_t gx = (uint32_t)((NV + 256 * R - 1) / (256 * R));
     // enough workgroups to fill the chip: split the loc rows over grid.y, one loc row per workgroup when the
     // grid allows (K=30: 25 us with gy = NL, 310 us with gy = 1).  Measured budget at K=30, R=2 (HIP events,
     // 4.7 us of which is the event floor): tables + value staging 3.6 us, FMAs/LDS 4-6 us, stores of F 6 us.
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 16384 / std::max(1u, gx)));
-    if (const char *e = getenv("ALAN_NORMAL_GY")) gy = std::min<uint32_t>(d.NL, std::max(1, atoi(e)));   // tuning knob
+    static const int gy_knob = env_knob("ALAN_NORMAL_GY");                                   // tuning knob
+    if (gy_knob != ENV_UNSET) gy = std::min<uint32_t>(d.NL, std::max(1, gy_knob));
     d.l_chunk = (d.NL + gy - 1) / gy;
     gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
     size_t lds_f = 2 * (size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep;

@@ -20,11 +20,18 @@ namespace alan {
 struct NLDesc {
     const float *val, *loc, *scl;
     float *part;                      // [n_chunks][NL][NS]
+    float *lse;                       // optional [M][NL][NS]: the per-plate-element log-sum-exp (the backward's input)
     int32_t M, NK, NL, NS, E, m_chunk, n_small, log_scale;
+    int32_t small_f64;                // bit f: small factor f is fp64 (converted on load)
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se;
-    const float *small[4];
+    const void *small[4];
     int64_t small_sm[4], small_sk[4];
 };
+
+// small factor f at element offset off (fp32, or fp64 converted on load: the likelihood of fp64 observations)
+__device__ __forceinline__ float nl_small(const void *p, int64_t off, bool f64) {
+    return f64 ? (float)((const double *)p)[off] : ((const float *)p)[off];
+}
 
 // On the matrix cores: for one (plate element m, loc row l) the block F[m, l, :, :] is a GEMM over the event dim;
 // with v_mfma_f32_32x32x2_f32 computing D[i = k][j = s] = sum_e d2[(m,k), e] * w[s, e] the log-sum-exp over
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         for (int step = 0; step < EH; ++step) x[step] = vp[(int64_t)min(2 * step + h, E - 1) * d.v_se];
 #pragma unroll
         for (int f = 0; f < 4; ++f)                   // (the launcher points unused slots at valid memory, stride 0)
-            hs[f] = d.small[f][(int64_t)m * d.small_sm[f] + (int64_t)k * d.small_sk[f]];
+            hs[f] = nl_small(d.small[f], (int64_t)m * d.small_sm[f] + (int64_t)k * d.small_sk[f], (d.small_f64 >> f) & 1);
         asm volatile("" ::: "memory");
     };
     float zc[EH], zn[EH], hc[4], hn[4];
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
             float mx = -mn, mx2 = -__shfl_xor(mn, 32), sm2 = __shfl_xor(sm, 32);
             lse_merge(mx, sm, mx2, sm2);
-            accm += lse_finish(mx, sm);
+            const float lse_m = lse_finish(mx, sm);
+            accm += lse_m;
+            if (d.lse && h == 0 && s_ok) d.lse[((int64_t)(m0 + t / nkt) * d.NL + l) * NS + s] = lse_m;
             mn = __builtin_huge_valf(), sm = 0.f, kt = 0;
         }
 #pragma unroll
@@ -177,15 +186,19 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     if (!a.value || !a.loc || !a.scale || !a.out) return ALAN_ERR_BAD_DESC;
     if (a.M < 1 || a.NK < 1 || a.NL < 1 || a.NS < 1 || a.E < 1) return ALAN_ERR_BAD_DESC;
     if (a.n_small < 0 || a.n_small > 4) return ALAN_ERR_BAD_DESC;
-    for (int f = 0; f < a.n_small; ++f)
+    for (int f = 0; f < a.n_small; ++f) {
         if (!a.small[f]) return ALAN_ERR_BAD_DESC;
+        if (a.small_dtype[f] != ALAN_F32 && a.small_dtype[f] != ALAN_F64) return ALAN_ERR_BAD_DESC;
+    }
+    if (a.out_dtype != ALAN_F32 && a.out_dtype != ALAN_F64) return ALAN_ERR_BAD_DESC;
     if (a.E > 32 || a.NK > 4096 || a.NS > 4096 || a.NL > (1 << 20) || a.M > (1 << 24)) return ALAN_ERR_UNSUPPORTED;
     // a wave per (loc row, tile of 32 scale rows), 4 per workgroup; the plate in chunks so that ~4096 waves exist
     p.eh = (int)(a.E + 2) / 2;
     const int64_t nst = (a.NS + 31) / 32;
     const int64_t gx = (a.NL * nst + 3) / 4;
     int64_t target = 1024;                                                   // workgroups (x 4 waves)
-    if (const char *e = getenv("ALAN_NLSE_BLOCKS")) target = std::max(1, atoi(e));   // tuning knob
+    static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
+    if (blocks_knob != ENV_UNSET) target = std::max(1, blocks_knob);
     int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, target / std::max<int64_t>(1, gx)));
     p.m_chunk = (int)((a.M + nch - 1) / nch);
     p.n_chunks = (int)((a.M + p.m_chunk - 1) / p.m_chunk);
@@ -219,13 +232,15 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     d.loc = (const float *)a->loc;
     d.scl = (const float *)a->scale;
     d.part = (float *)workspace;
+    d.lse = (float *)a->lse_out;
     d.M = (int)a->M, d.NK = (int)a->NK, d.NL = (int)a->NL, d.NS = (int)a->NS, d.E = (int)a->E;
     d.m_chunk = p.m_chunk, d.n_small = a->n_small, d.log_scale = a->log_scale;
     d.v_sm = a->v_sm, d.v_sk = a->v_sk, d.v_se = a->v_se;
     d.l_sl = a->l_sl, d.l_se = a->l_se, d.s_ss = a->s_ss, d.s_se = a->s_se;
     for (int f = 0; f < 4; ++f) {
         const bool used = f < a->n_small;
-        d.small[f] = used ? (const float *)a->small[f] : (const float *)a->value;    // (unused: any valid address)
+        d.small[f] = used ? a->small[f] : a->value;                                  // (unused: any valid address)
+        if (used && a->small_dtype[f] == ALAN_F64) d.small_f64 |= 1 << f;
         d.small_sm[f] = used ? a->small_sm[f] : 0;
         d.small_sk[f] = used ? a->small_sk[f] : 0;
     }
@@ -268,7 +283,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     s2.w.p = nullptr;
     s2.l.p = nullptr;
     s2.o.p = a->out;
-    s2.o.dtype = ALAN_F32;
+    s2.o.dtype = a->out_dtype;
     s2.o.scale = 1.f;
     for (int j = 0; j < MAXD; ++j) s2.f[0].ks[j] = s2.f[0].rs[j] = s2.o.ks[j] = 0;
     s2.nk = 0, s2.nr = 0, s2.n_out = 1, s2.n_red = 1;
@@ -290,7 +305,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     s2.keep_contig = true;
     GroupDesc gd;
     GroupLaunch gl;
-    rc = plan_group(s2, ALAN_F32, a->add_const, gd, gl);
+    rc = plan_group(s2, a->out_dtype, a->add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
     rc = try_launch_small(s2, gd, gl, ALAN_MODE_SUM, ALAN_F32, stream, EvPair());
     if (rc == ALAN_ERR_UNSUPPORTED) rc = launch_group(gd, gl, ALAN_MODE_SUM, ALAN_F32, stream);

@@ -371,6 +371,29 @@ int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype
     if (c.n_out * c.n_red > (1ll << 22)) return ALAN_ERR_UNSUPPORTED;   // big problems are not launch-bound
     if (mode == ALAN_MODE_WEXPSUM && (!c.w.p || c.w.dtype != ALAN_F32)) return ALAN_ERR_UNSUPPORTED;
     const int64_t lim = (1ll << 31) - 1;
+    // the kernel accumulates element offsets in int32: besides each stride, the LARGEST reachable offset of every
+    // tensor -- sum of (size - 1) * |stride| -- must fit (a small strided view into a tensor of > 2^31 elements, e.g. a
+    // slice of a K=100 factor, does not: it goes to the int64 group kernel instead)
+    auto reach_ok = [&](const KTensor &x, bool reduce_dims) {
+        int64_t reach = 0;
+        for (int j = 0; j < c.nk; ++j) {
+            const int64_t st = x.ks[j] < 0 ? -x.ks[j] : x.ks[j];
+            if (st > lim) return false;
+            reach += (c.ksize[j] - 1) * st;
+            if (reach > lim) return false;
+        }
+        for (int j = 0; reduce_dims && j < c.nr; ++j) {
+            const int64_t st = x.rs[j] < 0 ? -x.rs[j] : x.rs[j];
+            if (st > lim) return false;
+            reach += (c.rsize[j] - 1) * st;
+            if (reach > lim) return false;
+        }
+        return true;
+    };
+    for (int f = 0; f < c.nf; ++f)
+        if (!reach_ok(c.f[f], true)) return ALAN_ERR_UNSUPPORTED;
+    if (mode == ALAN_MODE_WEXPSUM && !reach_ok(c.w, true)) return ALAN_ERR_UNSUPPORTED;
+    if (!reach_ok(c.o, false)) return ALAN_ERR_UNSUPPORTED;
     std::memset(&sd, 0, sizeof(sd));
     for (int k = 0; k < SMALL_NK; ++k) sd.kdiv[k] = make_fastdiv(1);
     for (int k = 0; k < SMALL_NR; ++k) sd.rdiv[k] = make_fastdiv(1);

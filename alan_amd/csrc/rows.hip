@@ -369,16 +369,19 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.P = nplate ? (uint32_t)c.ksize[0] : 1u;
     rp.NO = (uint32_t)(c.n_out / rp.P);
     rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
-    if (const char *e = getenv("ALAN_ROWS_LOGG")) rp.logG = std::max(rp.logG, std::min(3, atoi(e)));  // tuning knob
+    static const int logg_knob = env_knob("ALAN_ROWS_LOGG");                                           // tuning knob
+    if (logg_knob != ENV_UNSET) rp.logG = std::max(rp.logG, std::min(3, logg_knob));
     rp.rot = gcd_i((int)L, 64) >= 16;
     if (rp.rot) while ((1 << rp.logG) > L / 4) --rp.logG;   // (the quad rotation wraps once per step)
     int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
-    if (const char *e = getenv("ALAN_ROWS_RBMAX")) rbmax = std::max(1, std::min(rbmax, atoi(e)));  // tuning knob
+    static const int rbmax_knob = env_knob("ALAN_ROWS_RBMAX");                                      // tuning knob
+    if (rbmax_knob != ENV_UNSET) rbmax = std::max(1, std::min(rbmax, rbmax_knob));
     rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
     rp.RB = (int)((rp.NO + rp.n_windows - 1) / rp.n_windows);
     rp.threads = 256;
     uint32_t target_blocks = 4096;
-    if (const char *e = getenv("ALAN_ROWS_BLOCKS")) target_blocks = (uint32_t)std::max(1, atoi(e));   // tuning knob
+    static const int blocks_knob = env_knob("ALAN_ROWS_BLOCKS");                                       // tuning knob
+    if (blocks_knob != ENV_UNSET) target_blocks = (uint32_t)std::max(1, blocks_knob);
     uint32_t nch = std::max(1u, std::min(rp.P, target_blocks / std::max(1u, rp.n_windows)));
     rp.p_chunk = (rp.P + nch - 1) / nch;
     rp.n_chunks = (rp.P + rp.p_chunk - 1) / rp.p_chunk;
@@ -450,7 +453,8 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     d.l_ps = k0 ? c.l.ks[0] : 0;
     d.add_const = two_stage ? 0.f : (float)add_const;
 #ifdef ALAN_ABLATE
-    if (const char *e = getenv("ALAN_ROWS_ABLATE")) d.dbg = atoi(e);
+    static const int ablate_knob = env_knob("ALAN_ROWS_ABLATE");
+    if (ablate_knob != ENV_UNSET) d.dbg = ablate_knob;
 #endif
 
     const dim3 grid(rp.n_windows, rp.n_chunks);

@@ -184,10 +184,12 @@ class LazyNormalPT(PT):
     tensor of a hierarchical model), not computed yet: ``.x`` produces it (alan_reduce mode NORMAL) the first time
     anyone asks, but the plate recursion can hand the ingredients to the fused plate-step kernel instead
     (engine.normal_lse) and never materialise it."""
-    __slots__ = ("value", "loc", "scale", "log_scale", "_val")
+    __slots__ = ("value", "loc", "scale", "log_scale", "grad", "_val")
 
-    def __init__(self, value, loc, scale, log_scale, dims):
-        self.value, self.loc, self.scale, self.log_scale = value, loc, scale, log_scale
+    def __init__(self, value, loc, scale, log_scale, dims, grad=False):
+        """``scale`` holds log(scale) when ``log_scale``.  ``grad``: the arguments are attached to the autograd graph
+        (elbo_vi / elbo_rws): materialising then goes through the producer's autograd function."""
+        self.value, self.loc, self.scale, self.log_scale, self.grad = value, loc, scale, log_scale, grad
         self._val = None
         self.dims = tuple(dims)
         self.ids = tuple(id(d) for d in self.dims)
@@ -195,9 +197,14 @@ class LazyNormalPT(PT):
     @property
     def x(self):
         if self._val is None:
-            from . import engine as E
-            self._val = E.normal_logprob((self.value.x, self.value.dims), (self.loc.x, self.loc.dims),
-                                         (self.scale.x, self.scale.dims), self.dims, log_scale=self.log_scale)
+            if self.grad:
+                from .dist import _FusedNormalLogProb
+                spec = (self.value.dims, self.loc.dims, self.scale.dims, self.dims, self.log_scale, (1.0, 0.0))
+                self._val = _FusedNormalLogProb.apply(spec, self.value.x, self.loc.x, self.scale.x)
+            else:
+                from . import engine as E
+                self._val = E.normal_logprob((self.value.x, self.value.dims), (self.loc.x, self.loc.dims),
+                                             (self.scale.x, self.scale.dims), self.dims, log_scale=self.log_scale)
         return self._val
 
     @property

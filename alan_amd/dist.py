@@ -254,11 +254,12 @@ class _FusedBernoulliLogProb(t.autograd.Function):
 FUSE_NORMAL = True
 """Route Normal / Bernoulli(logits) log-probs on the GPU to the fused HIP producer kernels."""
 
-FUSE_PLATE_STEP = False
-"""Gradient-free evaluations hand a Normal factor on disjoint dims to the fused plate-step kernel
-(alan_normal_lse: producer + log-sum-exp + plate sum, the factor never materialised) when the plate's contraction
-has that shape.  Off by default: the default path keeps the materialised factor and the HBM-bound reduce_Ks kernel
-that bench.py's roofline is measured on."""
+FUSE_PLATE_STEP = True
+"""A Normal factor on disjoint dims (the [plate, K, K, K] tensor of a hierarchical model) goes to the fused
+plate-step kernel (alan_normal_lse: producer + log-sum-exp + plate sum in one launch, the factor never materialised;
+with gradients, alan_normal_lse_backward) when the plate's contraction has that shape.  Off: the factor is
+materialised by the producer kernel and streamed by the HBM-bound reduce_Ks kernel (rows.hip) -- the route every other
+shape takes."""
 
 HIP_PRODUCER_BACKWARD = True
 """Gradients of the (small) fused producers by alan_reduce mode PRODUCER_GRAD -- one multi-problem launch per
@@ -349,12 +350,15 @@ class TorchDimDist:
             sx = scale.raw if lazy else scale.x
             nograd = not (t.is_grad_enabled() and (x.x.requires_grad or loc.x.requires_grad or sx.requires_grad))
             vi, li, si = set(x.ids), set(loc.ids), set(scale.ids)
-            if FUSE_PLATE_STEP and nograd and ab == (1.0, 0.0) and not drop and li and si \
+            if FUSE_PLATE_STEP and ab == (1.0, 0.0) and not drop and li and si \
                     and not (vi & li) and not (vi & si) and not (li & si):
                 # the big K-cross-product factor: leave it unevaluated -- the plate recursion may fuse it into the
-                # log-sum-exp + plate sum that consumes it (logpq._contract); anyone else reading .x gets it made
-                return LazyNormalPT(PT(x.x.detach(), x.dims), PT(loc.x.detach(), loc.dims),
-                                    PT(sx.detach(), scale.dims), lazy, out_dims)
+                # log-sum-exp + plate sum that consumes it (logpq._contract: alan_normal_lse, and with gradients to
+                # record its one-pass backward); anyone else reading .x gets it made
+                if nograd:
+                    return LazyNormalPT(PT(x.x.detach(), x.dims), PT(loc.x.detach(), loc.dims),
+                                        PT(sx.detach(), scale.dims), lazy, out_dims)
+                return LazyNormalPT(PT(x.x, x.dims), PT(loc.x, loc.dims), PT(sx, scale.dims), lazy, out_dims, grad=True)
             if nograd:
                 from . import engine as E           # nothing to record: skip the autograd.Function round trip
                 return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.x.detach(), loc.dims), (sx.detach(), scale.dims),

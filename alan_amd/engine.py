@@ -298,46 +298,167 @@ def normal_logprob_pq(value, p, q, out_dims, affine=(1.0, 0.0)):
     return _produce(N.MODE_NORMAL, (value, pl, ps, value, ql, qs), out_dims, affine, scales)
 
 
-def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
-    """out[l, s] = sum_plate LSE_K( log N(value[plate,K,:]; loc[l,:], scale[s,:]) + sum small[plate,K] ) in one
-    launch, the [plate, l, s, K] factor never materialised (alan_normal_lse).  value = (tensor, (two dims: the plate
-    and K, any order)); loc / scale = (tensor, (one dim,)); smalls = [(tensor, dims within {plate, K})].
-    Returns (out, (loc dim, scale dim)) or None when the library declines."""
-    N.flush()          # consumers read what queued producer launches write (native.deferring)
+def _normal_lse_args(value, loc, scale, smalls, plate, K):
+    """Shape / stride bookkeeping shared by the fused plate step and its backward.  -> dict or None (not this path)."""
     (xv, dv), (xl, dl), (xs, ds) = value, loc, scale
     tensors = [xv, xl, xs, *[x for x, _ in smalls]]
-    if not all(x.is_cuda and x.dtype == t.float32 for x in tensors) or len(smalls) > 4:
+    if not all(x.is_cuda for x in tensors) or len(smalls) > 4:
+        return None
+    if not all(x.dtype == t.float32 for x in (xv, xl, xs)) or \
+            not all(x.dtype in (t.float32, t.float64) for x, _ in smalls):
         return None
     if len(dv) != 2 or len(dl) != 1 or len(ds) != 1:
         return None
     nev = xv.ndim - 2
+    if xl.ndim - 1 != nev or xs.ndim - 1 != nev:
+        return None
     if nev == 0:
         xv, xl, xs = xv.unsqueeze(-1), xl.unsqueeze(-1), xs.unsqueeze(-1)
     elif nev > 1:
+        if xv.shape[2:] != xl.shape[1:] or xv.shape[2:] != xs.shape[1:]:
+            return None
         xv, xl, xs = xv.flatten(2), xl.flatten(1), xs.flatten(1)
     if not (xv.shape[-1] == xl.shape[-1] == xs.shape[-1]):
         return None                                   # broadcasting event shapes: not this path
     ip = 0 if dv[0] is plate else 1
     if dv[ip] is not plate or dv[1 - ip] is not K:
         return None
-    d = N.NormalLseDesc()
+    sm = []
+    for x, dims in smalls:
+        if x.ndim != len(dims) or any(id(dd) not in (id(plate), id(K)) for dd in dims):
+            return None
+        st = {id(dd): (x.stride(j) if x.shape[j] > 1 else 0) for j, dd in enumerate(dims)}
+        sm.append((x, st.get(id(plate), 0), st.get(id(K), 0)))
+    return dict(xv=xv, xl=xl, xs=xs, ip=ip, smalls=sm, dl=dl[0], ds=ds[0])
+
+
+def _normal_lse_desc(a, log_scale, d=None):
+    d = d if d is not None else N.NormalLseDesc()
+    xv, xl, xs, ip = a["xv"], a["xl"], a["xs"], a["ip"]
     d.value, d.v_sm, d.v_sk, d.v_se = xv.data_ptr(), xv.stride(ip), xv.stride(1 - ip), xv.stride(2)
     d.loc, d.l_sl, d.l_se = xl.data_ptr(), xl.stride(0), xl.stride(1)
     d.scale, d.s_ss, d.s_se = xs.data_ptr(), xs.stride(0), xs.stride(1)
-    d.log_scale, d.n_small = int(bool(log_scale)), len(smalls)
-    for i, (x, dims) in enumerate(smalls):
-        st = {id(dd): (x.stride(j) if x.shape[j] > 1 else 0) for j, dd in enumerate(dims)}
-        if any(id(dd) not in (id(plate), id(K)) for dd in dims):
-            return None
-        d.small[i], d.small_sm[i], d.small_sk[i] = x.data_ptr(), st.get(id(plate), 0), st.get(id(K), 0)
+    d.log_scale, d.n_small = int(bool(log_scale)), len(a["smalls"])
+    for i, (x, s_m, s_k) in enumerate(a["smalls"]):
+        d.small[i], d.small_sm[i], d.small_sk[i], d.small_dtype[i] = x.data_ptr(), s_m, s_k, N.dtype_code(x.dtype)
     d.M, d.NK, d.NL, d.NS, d.E = xv.shape[ip], xv.shape[1 - ip], xl.shape[0], xs.shape[0], xv.shape[2]
-    out = t.empty(xl.shape[0], xs.shape[0], dtype=t.float32, device=xv.device)
-    d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
-    keep = (xv, xl, xs)                               # (the reshaped views stay alive until the launch is queued)
-    if not N.run_normal_lse(d, xv.device):
+    return d
+
+
+def _normal_lse_forward(a, log_scale, want_lse):
+    """One alan_normal_lse launch.  -> (out [NL, NS], lse [M, NL, NS] or None), or None when the library declines."""
+    d = _normal_lse_desc(a, log_scale)
+    device = a["xv"].device
+    dtype = t.float64 if any(x.dtype == t.float64 for x, _, _ in a["smalls"]) else t.float32
+    out = t.empty(d.NL, d.NS, dtype=dtype, device=device)
+    d.out, d.o_sl, d.o_ss, d.out_dtype, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), N.dtype_code(dtype), 0.0
+    lse = t.empty(d.M, d.NL, d.NS, dtype=t.float32, device=device) if want_lse else None
+    d.lse_out = lse.data_ptr() if want_lse else None
+    if not N.run_normal_lse(d, device):
         return None
-    del keep
-    return out, (dl[0], ds[0])
+    return out, lse
+
+
+class _NormalLse(t.autograd.Function):
+    """The fused plate step (alan_normal_lse) with its one-pass backward (alan_normal_lse_backward): the
+    [plate, l, s, K] factor exists neither in the forward nor in the backward."""
+
+    @staticmethod
+    def forward(ctx, spec, value, loc, scale, *smalls):
+        vd, ld, sd, small_dims, plate, K, log_scale = spec
+        a = _normal_lse_args((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd),
+                             [(x.detach(), d) for x, d in zip(smalls, small_dims)], plate, K)
+        res = _normal_lse_forward(a, log_scale, True) if a is not None else None
+        if res is None:
+            raise N.NativeError("alan_normal_lse declined a shape normal_lse_supported() accepted")
+        out, lse = res
+        ctx.spec = spec
+        ctx.save_for_backward(value, loc, scale, lse, *smalls)
+        return out
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, G):
+        vd, ld, sd, small_dims, plate, K, log_scale = ctx.spec
+        value, loc, scale, lse, *smalls = ctx.saved_tensors
+        a = _normal_lse_args((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd),
+                             [(x.detach(), d) for x, d in zip(smalls, small_dims)], plate, K)
+        need_v, need_l, need_s = ctx.needs_input_grad[1:4]
+        need_small = list(ctx.needs_input_grad[4:])
+        bd = N.NormalLseBackwardDesc()
+        _normal_lse_desc(a, log_scale, bd.fwd)
+        device = value.device
+        M, NK, NL, NS, E = bd.fwd.M, bd.fwd.NK, bd.fwd.NL, bd.fwd.NS, bd.fwd.E
+        Gc = G.detach().to(t.float32).contiguous()
+        bd.lse, bd.grad_out, bd.g_sl, bd.g_ss = lse.data_ptr(), Gc.data_ptr(), Gc.stride(0), Gc.stride(1)
+        gv = t.empty(M, NK, E, dtype=t.float32, device=device) if need_v else None
+        gls = t.empty(NL * E + NS * E, dtype=t.float32, device=device) if (need_l or need_s) else None
+        gsm = t.empty(M, NK, dtype=t.float32, device=device) if any(need_small) else None
+        bd.grad_value = gv.data_ptr() if need_v else None
+        bd.grad_loc = gls.data_ptr() if need_l else None
+        bd.grad_scale = gls[NL * E:].data_ptr() if need_s else None
+        bd.grad_small = gsm.data_ptr() if gsm is not None else None
+        if not N.run_normal_lse_backward(bd, device):
+            raise N.NativeError("alan_normal_lse_backward declined the shape its forward accepted")
+        grads = [None, None, None]
+        if need_v:
+            g = gv if a["ip"] == 0 else gv.transpose(0, 1)
+            grads[0] = g.reshape(value.shape)
+        if need_l:
+            grads[1] = gls[: NL * E].view(loc.shape)
+        if need_s:
+            grads[2] = gls[NL * E:].view(scale.shape)
+        out_small = []
+        for x, dims, need in zip(smalls, small_dims, need_small):
+            if not need:
+                out_small.append(None)
+                continue
+            # d small_f = d (sum of smalls) summed over the dims (and broadcast size-1 axes) that factor lacks
+            g = gsm                                                       # [plate, K]
+            axes = {id(plate): 0, id(K): 1}
+            have = [axes[id(dd)] for dd in dims]
+            drop = [ax for ax in (0, 1) if ax not in have]
+            if drop:
+                g = g.sum(drop)
+            if len(have) == 2 and have[0] > have[1]:
+                g = g.t()
+            for j, n in enumerate(x.shape):
+                if n == 1 and g.shape[j] != 1:
+                    g = g.sum(j, keepdim=True)
+            out_small.append(g.to(x.dtype))
+        return (None, *grads, *out_small)
+
+
+def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
+    """out[l, s] = sum_plate LSE_K( log N(value[plate,K,:]; loc[l,:], scale[s,:]) + sum small[plate,K] ) in one
+    launch, the [plate, l, s, K] factor never materialised (alan_normal_lse).  value = (tensor, (two dims: the plate
+    and K, any order)); loc / scale = (tensor, (one dim,)); smalls = [(tensor, dims within {plate, K})].
+    Differentiable in every argument (alan_normal_lse_backward).  Returns (out, (loc dim, scale dim)) or None when
+    the library declines."""
+    N.flush()          # consumers read what queued producer launches write (native.deferring)
+    a = _normal_lse_args(value, loc, scale, smalls, plate, K)
+    if a is None:
+        return None
+    tensors = [value[0], loc[0], scale[0], *[x for x, _ in smalls]]
+    if t.is_grad_enabled() and any(x.requires_grad for x in tensors):
+        d = _normal_lse_desc(a, log_scale)
+        d.out = d.value                                  # (planning only: any non-null pointer)
+        L = N.lib()
+        import ctypes as C
+        bd = N.NormalLseBackwardDesc()
+        _normal_lse_desc(a, log_scale, bd.fwd)
+        bd.lse = bd.grad_out = bd.grad_small = bd.fwd.value
+        if L.alan_normal_lse_workspace_bytes(C.byref(d)) == 0 or \
+                L.alan_normal_lse_backward_workspace_bytes(C.byref(bd)) == 0:
+            return None                                  # forward or backward would decline: the materialised route
+        spec = (tuple(value[1]), tuple(loc[1]), tuple(scale[1]), tuple(tuple(d_) for _, d_ in smalls), plate, K,
+                bool(log_scale))
+        out = _NormalLse.apply(spec, value[0], loc[0], scale[0], *[x for x, _ in smalls])
+        return out, (a["dl"], a["ds"])
+    res = _normal_lse_forward(a, log_scale, False)
+    if res is None:
+        return None
+    return res[0], (a["dl"], a["ds"])
 
 
 def producer_grads(G, out_dims, args, wanted, kinds, log_scale=False, scale=1.0):

@@ -96,8 +96,6 @@ def _fused_plate_step(lps, Ks, plate):
             continue
         if lp.n_pos or not set(lp.ids) <= {id(pl), id(K)}:
             return None
-        if t.is_grad_enabled() and lp.x.requires_grad:
-            return None                 # (elbo_rws: log Q carries the gradient) the fused kernel has no backward
         smalls.append((lp.x, lp.dims))
     res = E.normal_lse((z.value.x, z.value.dims), (z.loc.x, z.loc.dims), (z.scale.x, z.scale.dims), smalls, pl, K,
                        log_scale=z.log_scale)

@@ -70,8 +70,17 @@ class NormalLseDesc(C.Structure):
                 ("scale", C.c_void_p), ("s_ss", C.c_int64), ("s_se", C.c_int64),
                 ("log_scale", C.c_int32), ("n_small", C.c_int32),
                 ("small", C.c_void_p * 4), ("small_sm", C.c_int64 * 4), ("small_sk", C.c_int64 * 4),
+                ("small_dtype", C.c_int32 * 4),
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
-                ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64), ("add_const", C.c_double)]
+                ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64), ("out_dtype", C.c_int32),
+                ("lse_out", C.c_void_p), ("add_const", C.c_double)]
+
+
+class NormalLseBackwardDesc(C.Structure):
+    _fields_ = [("fwd", NormalLseDesc), ("lse", C.c_void_p),
+                ("grad_out", C.c_void_p), ("g_sl", C.c_int64), ("g_ss", C.c_int64),
+                ("grad_value", C.c_void_p), ("grad_loc", C.c_void_p), ("grad_scale", C.c_void_p),
+                ("grad_small", C.c_void_p)]
 
 
 _lib = None
@@ -101,6 +110,10 @@ def lib():
         L.alan_normal_lse.argtypes = [C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_workspace_bytes.restype = C.c_size_t
         L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
+        L.alan_normal_lse_backward.restype = C.c_int
+        L.alan_normal_lse_backward.argtypes = [C.POINTER(NormalLseBackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_normal_lse_backward_workspace_bytes.restype = C.c_size_t
+        L.alan_normal_lse_backward_workspace_bytes.argtypes = [C.POINTER(NormalLseBackwardDesc)]
         L.alan_chain_workspace_bytes.restype = C.c_size_t
         L.alan_chain_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp.restype = C.c_int
@@ -133,6 +146,7 @@ def lib():
 
 EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
+           "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
@@ -294,6 +308,22 @@ def run_normal_lse(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse")
+    return True
+
+
+def run_normal_lse_backward(desc, device):
+    """Every gradient of the fused plate step in one pass (alan_normal_lse_backward).  False when the library
+    declines the shape."""
+    L = lib()
+    flush()
+    nbytes = L.alan_normal_lse_backward_workspace_bytes(C.byref(desc))
+    if nbytes == 0:
+        return False
+    ws = t.empty(nbytes, dtype=t.uint8, device=device)
+    rc = L.alan_normal_lse_backward(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc, "alan_normal_lse_backward")
     return True
 
 

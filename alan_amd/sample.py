@@ -24,7 +24,7 @@ class _GraphedELBO:
     """One captured elbo_nograd evaluation (HIP graph), replayed on call."""
 
     def __init__(self, sample, strategy):
-        self.strategy = strategy          # keep alive: the cache key is its id()
+        self.strategy = strategy
         from . import native as N
         timer, N._TIMER[0] = N._TIMER[0], None       # event records must not be captured
         try:
@@ -45,6 +45,18 @@ class _GraphedELBO:
     def __call__(self):
         self.graph.replay()
         return self.out.clone()
+
+
+def strategy_key(strategy):
+    """What a captured evaluation depends on in a computation strategy, by VALUE (two equal Split objects share a
+    graph; an object re-created at a recycled address cannot alias a different one)."""
+    from .split import Split, rank_block
+    if isinstance(strategy, Split):
+        sharded = strategy.sharded()
+        import torch.distributed as dist
+        where = (dist.get_world_size(strategy.group), dist.get_rank(strategy.group), id(strategy.group)) if sharded else ()
+        return ("Split", strategy.platename, strategy.split_size, sharded, strategy.merging(), where)
+    return (type(strategy).__name__,)
 
 
 def _dim_tree(tree):
@@ -154,7 +166,8 @@ class Sample:
         from . import dist as D
         from . import native as N
         # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
-        key = (id(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND, N.DEFER_SMALL_LAUNCHES)
+        key = (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
+               N.DEFER_SMALL_LAUNCHES)
         cache = self.__dict__.setdefault("_graphs", {})
         if key not in cache:
             cache[key] = _GraphedELBO(self, computation_strategy)

@@ -51,8 +51,10 @@ class GraphedStep:
         return elbo.detach()
 
     def __call__(self):
+        """Replay one iteration; returns a COPY of the ELBO (the graph's own output buffer is overwritten by the next
+        replay, so ``[step() for _ in range(n)]`` holds n different values)."""
         self.graph.replay()
-        return self.elbo
+        return self.elbo.clone()
 
 
 class GraphedEval:
@@ -81,5 +83,6 @@ class GraphedEval:
             return self.problem.sample(self.K, reparam=False).elbo_nograd(self.strategy)
 
     def __call__(self):
+        """Replay; returns a COPY of the ELBO (see GraphedStep.__call__)."""
         self.graph.replay()
-        return self.elbo
+        return self.elbo.clone()

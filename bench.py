@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--K", type=int, default=30)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / scaled roofline / K sweep")
+    ap.add_argument("--c4-only", action="store_true", help="of the extras, only the C4 (movielens K=100) figure")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python each step instead of replaying a HIP graph")
     args = ap.parse_args()
@@ -360,7 +361,7 @@ def main():
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
         t.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.c4_only:
         out["roofline_scaled"] = roofline_scaled(K)
         # sample() + elbo per iteration, as examples/basic_runner.py:86-97 of the reference counts it (eager)
         for _ in range(3):
@@ -413,14 +414,15 @@ def main():
         # the optional fused plate step (dist.FUSE_PLATE_STEP: producer + log-sum-exp + plate sum in one launch, the
         # factor never materialised) -- off by default, so `value` and `roofline` above describe the default path
         from alan_amd import dist as _dist
-        _dist.FUSE_PLATE_STEP = True
+        _dist.FUSE_PLATE_STEP = False
         try:
             sf = draw(prob, K)
             d_f, v_f = timed_evals(sf, strat, args.steps, args.warmup, world, graph=use_graph)
-            out["fused_plate_step"] = {"evals_per_s": args.steps / d_f, "us_per_eval": d_f / args.steps * 1e6,
-                                       "elbo": v_f, "default": False}
+            out["materialised_route"] = {"evals_per_s": args.steps / d_f, "us_per_eval": d_f / args.steps * 1e6,
+                                         "elbo": v_f, "default": False,
+                                         "what": "dist.FUSE_PLATE_STEP = False: producer kernel writes F, rows kernel reads it"}
         finally:
-            _dist.FUSE_PLATE_STEP = False
+            _dist.FUSE_PLATE_STEP = True
         out["cpu_baseline"] = cpu_baseline(K, sample, elbo)
         sweep = {}
         for k2 in (3, 10, 100):

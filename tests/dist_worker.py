@@ -7,12 +7,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(rank, world, port, fixture, model, platename, split_size, out_path, device="cpu", merge=None):
+def run(rank, world, port, fixture, model, platename, split_size, out_path, device="cpu", merge=None, backend_name="gloo"):
     import torch as t
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend_name == "nccl":                 # one GPU per rank, RCCL carries the partials (the production layout)
+        device = f"cuda:{rank}"
+        t.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=t.device(device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import alan_amd as alan
         import models
@@ -30,6 +36,9 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path, devi
             n_chunks = len(alan.split.chunk_sizes(prob.all_platedims[platename].size, split_size))
             mine = list(strat.my_chunks(n_chunks))
             val = sample.elbo_nograd(strat)
+            graphed = None
+            if backend_name == "nccl":         # the sharded evaluation, collective included, as a replayed HIP graph
+                graphed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(3)]
             # gradients flow through the all-reduce; AVERAGING them over ranks (the DDP convention)
             # gives exactly the gradient of the unsharded ELBO
             lp = sample.elbo_rws(strat)
@@ -42,7 +51,7 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path, devi
                 gsum.append(g / world)
             ref_val = sample.elbo_rws(alan.Split(platename, split_size))      # sequential Split, this rank alone
             ref_grads = t.autograd.grad(ref_val, params, allow_unused=True) if params else []
-        t.save({"rank": rank, "elbo": float(val), "chunks": mine, "ref": float(fx["elbo"]["split"]),
+        t.save({"rank": rank, "elbo": float(val), "chunks": mine, "ref": float(fx["elbo"]["split"]), "graphed": graphed,
                 "elbo_seq": float(ref_val),
                 "grad_err": max([float((a - (t.zeros_like(a) if b is None else b)).abs().max())
                                  for a, b in zip(gsum, ref_grads)] or [0.0])},

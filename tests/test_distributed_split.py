@@ -61,6 +61,48 @@ def test_sharded_split_world2_on_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("merge", [True, False], ids=["merged", "chunked"])
+def test_sharded_split_two_rccl_ranks(merge):
+    """Two ranks, one GPU each, backend "nccl" (= RCCL over xGMI): the production layout of the sharded Split.  Every
+    rank ends with the reference's full-plate ELBO -- eagerly and as a replayed HIP graph that contains the
+    all-reduce -- and rank-averaged gradients equal the unsharded ones.  Needs two GPUs; skipped on a one-GPU box."""
+    if t.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU node); the arithmetic is covered with gloo above")
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res")
+        mp.spawn(dist_worker.run, args=(world, _free_port(), "e2e_movielens_K10.pt", "movielens", "plate_1", 38,
+                                        out, "cuda", merge, "nccl"), nprocs=world, join=True)
+        res = [t.load(f"{out}.{r}") for r in range(world)]
+    for r in res:
+        assert abs(r["elbo"] - r["ref"]) <= 1e-4 * abs(r["ref"]) + 1e-5, r
+        assert abs(r["elbo"] - r["elbo_seq"]) <= 1e-5 * abs(r["elbo_seq"]) + 1e-5
+        assert all(abs(g - r["elbo"]) <= 1e-6 * abs(r["elbo"]) for g in r["graphed"]), r
+        assert r["grad_err"] < 5e-2, r
+    assert res[0]["elbo"] == res[1]["elbo"]
+    all_chunks = sorted(c for r in res for c in r["chunks"])
+    assert all_chunks == list(range(len(all_chunks)))
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts two child ranks itself (before touching the GPU) and
+    prints rank 0's JSON line with the C4 figure.  Needs two GPUs."""
+    if t.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--c4-only"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "c4_movielens_K100" in line
+
+
+@pytest.mark.gpu
 def test_sharded_split_with_its_rccl_all_reduce_captures_into_a_graph(monkeypatch):
     """One rank on one GPU (a 1-rank "nccl" group, Split.sharded forced on): the sharded evaluation -- queued producer
     launches flushed before the collective, the RCCL all-reduce itself -- gives the unsharded value eagerly and as a

@@ -74,15 +74,18 @@ def test_movielens_elbo_with_the_fused_plate_step(fixture, monkeypatch):
         fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})     # the fused kernel is fp32
     prob = models.BUILDERS["movielens"](fx).to(DEV)
     sample = models.sample_from_fixture(prob, fx, DEV)
-    base = {n: float(sample.elbo_nograd(s)) for n, s in (("no", alan.no_checkpoint), ("split", alan.Split("plate_1", 38)))}
+    monkeypatch.setattr(D, "FUSE_PLATE_STEP", False)
+    base = {n: float(sample.elbo_nograd(s)) for n, s in (("no", alan.no_checkpoint), ("split", alan.Split("plate_1", 38, merge=False)))}
     calls = []
     real = E.normal_lse
     monkeypatch.setattr(E, "normal_lse", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     monkeypatch.setattr(D, "FUSE_PLATE_STEP", True)
     fused = float(sample.elbo_nograd(alan.no_checkpoint))
     assert len(calls) == 1
-    fused_split = float(sample.elbo_nograd(alan.Split("plate_1", 38)))
+    fused_split = float(sample.elbo_nograd(alan.Split("plate_1", 38, merge=False)))
     assert len(calls) == 1 + 8
+    fused_merged = float(sample.elbo_nograd(alan.Split("plate_1", 38)))       # the rank's chunks as one slice
+    assert len(calls) == 1 + 8 + 1 and abs(fused_merged - base["no"]) <= 1e-6 * abs(base["no"])
     graph = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
     graph2 = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
     ref = float(fx["elbo"]["no_checkpoint"])
@@ -90,9 +93,10 @@ def test_movielens_elbo_with_the_fused_plate_step(fixture, monkeypatch):
     assert abs(fused_split - base["split"]) <= 1e-6 * abs(base["split"])
     assert graph == graph2 and abs(graph - fused) <= 1e-6 * abs(fused)
     assert abs(fused - ref) <= 1e-4 * abs(ref) + 1e-5
-    # with gradients to record the factor is materialised as before
-    monkeypatch.setattr(E, "normal_lse", lambda *a, **k: pytest.fail("the fused kernel has no backward"))
+    # with gradients to record the fused kernel is used too (its backward: alan_normal_lse_backward)
+    n = len(calls)
     sample.elbo_rws(alan.no_checkpoint).backward()
+    assert len(calls) == n + 1
 
 
 def test_fused_plate_step_fuzz_against_the_two_launch_route():
@@ -129,6 +133,7 @@ def test_a_captured_graph_is_not_reused_under_other_routing_switches(monkeypatch
         fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})
     prob = models.BUILDERS["movielens"](fx).to(DEV)
     sample = models.sample_from_fixture(prob, fx, DEV)
+    monkeypatch.setattr(D, "FUSE_PLATE_STEP", False)
     a = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
     calls = []
     real = E.normal_lse
@@ -137,3 +142,133 @@ def test_a_captured_graph_is_not_reused_under_other_routing_switches(monkeypatch
     b = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))         # a NEW capture, through the fused kernel
     assert len(calls) >= 1 and abs(a - b) <= 1e-6 * abs(a)
     assert len(sample._graphs) == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the backward: alan_normal_lse_backward
+def _torch_reference(z, mu, raw, smalls, log_scale, G, dtype=t.float64):
+    """fp64 autograd through torch.distributions on the materialised [M, NL, NS, NK] broadcast (CPU)."""
+    z, mu, raw = (x.detach().cpu().to(dtype).requires_grad_(True) for x in (z, mu, raw))
+    sm = [x.detach().cpu().to(dtype).requires_grad_(True) for x, _ in smalls]
+    sigma = raw.exp() if log_scale else raw
+    lp = t.distributions.Normal(mu[None, :, None, None, :], sigma[None, None, :, None, :]).log_prob(
+        z[:, None, None, :, :]).sum(-1)                                     # [M, NL, NS, NK]
+    tot = lp
+    for x, (_, (_, kind)) in zip(sm, smalls):
+        view = {"mk": x[:, None, None, :] if x.ndim == 2 else None, "k": x[None, None, None, :] if x.ndim == 1 else None,
+                "m": x[:, None, None, None] if x.ndim == 1 else None, "km": x.t()[:, None, None, :] if x.ndim == 2 else None}[kind]
+        tot = tot + view
+    mx = tot.amax(-1, keepdim=True)
+    out = ((tot - mx).exp().sum(-1) + t.finfo(t.float32).eps).log() + mx.squeeze(-1)      # utils.py:218-220 (fp32 eps)
+    out = out.sum(0)                                                                       # logpq.py:149
+    grads = t.autograd.grad((out * G.detach().cpu().to(dtype)).sum(), [z, mu, raw, *sm])
+    return out, grads
+
+
+SHAPES = [(300, 30, 30, 30, 18, 2, True), (38, 100, 100, 100, 18, 2, True), (7, 5, 4, 3, 3, 0, False),
+          (11, 33, 9, 70, 20, 1, True), (5, 8, 40, 31, 1, 3, True), (3, 64, 2, 32, 31, 4, False),
+          (4, 16, 5, 128, 9, 1, False), (6, 10, 7, 50, 18, 2, True), (9, 97, 3, 33, 17, 2, False),
+          (2, 130, 2, 5, 30, 0, True), (1, 1, 1, 1, 1, 1, False), (40, 30, 30, 30, 18, 2, True)]
+
+
+@pytest.mark.parametrize("M,NK,NL,NS,Ev,n_small,log_scale", SHAPES)
+def test_fused_plate_step_backward_against_fp64_autograd(M, NK, NL, NS, Ev, n_small, log_scale):
+    """Every gradient of the fused plate step (value, loc, scale / log-scale, each small factor incl. broadcast ones)
+    against fp64 autograd through torch.distributions on the materialised broadcast, with a random upstream gradient
+    of mixed sign."""
+    g = t.Generator().manual_seed(M * 7 + NK + NS)
+    pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)
+    z = t.randn(M, NK, Ev, generator=g)
+    mu = t.randn(NL, Ev, generator=g)
+    raw = 0.3 * t.randn(NS, Ev, generator=g)
+    if not log_scale:
+        raw = raw.exp()
+    kinds = [((pl, K), "mk"), ((K,), "k"), ((pl,), "m"), ((K, pl), "km")]
+    smalls = []
+    for i in range(n_small):
+        dims, kind = kinds[i]
+        smalls.append((t.randn(*[d.size for d in dims], generator=g), (dims, kind)))
+    G = t.randn(NL, NS, generator=g)
+    ref_out, ref = _torch_reference(z, mu, raw, smalls, log_scale, G)
+    dev = [x.to(DEV).requires_grad_(True) for x in (z, mu, raw)]
+    dsm = [x.to(DEV).requires_grad_(True) for x, _ in smalls]
+    res = E.normal_lse((dev[0], (pl, K)), (dev[1], (dl,)), (dev[2], (ds,)), [(x, d[0]) for x, (_, d) in zip(dsm, smalls)],
+                       pl, K, log_scale=log_scale)
+    assert res is not None
+    out, odims = res
+    t.testing.assert_close(out.detach().cpu().double(), ref_out, rtol=3e-5, atol=3e-4 * max(1.0, M / 30))
+    grads = t.autograd.grad((out * G.to(DEV)).sum(), [*dev, *dsm])
+    names = ["value", "loc", "scale", *[f"small{i}" for i in range(n_small)]]
+    for n, a, b in zip(names, grads, ref):
+        assert a.shape == b.shape, n
+        scale = float(b.abs().max()) + 1e-6
+        t.testing.assert_close(a.cpu().double(), b, rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")
+
+
+def test_fused_plate_step_backward_small_only_and_partial_needs():
+    """elbo_rws-like: only a small factor carries a gradient (the small-only kernel); and each single argument alone."""
+    g = t.Generator().manual_seed(3)
+    M, NK, NL, NS, Ev = 23, 30, 30, 30, 18
+    pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)
+    z, mu, raw = t.randn(M, NK, Ev, generator=g), t.randn(NL, Ev, generator=g), 0.3 * t.randn(NS, Ev, generator=g)
+    smalls = [(t.randn(M, NK, generator=g), ((pl, K), "mk")), (t.randn(M, NK, generator=g), ((pl, K), "mk"))]
+    G = t.randn(NL, NS, generator=g)
+    _, ref = _torch_reference(z, mu, raw, smalls, True, G)
+    for which in range(5):
+        ts = [x.to(DEV) for x in (z, mu, raw, smalls[0][0], smalls[1][0])]
+        ts[which].requires_grad_(True)
+        out, _ = E.normal_lse((ts[0], (pl, K)), (ts[1], (dl,)), (ts[2], (ds,)), [(ts[3], (pl, K)), (ts[4], (pl, K))], pl, K,
+                              log_scale=True)
+        (got,) = t.autograd.grad((out * G.to(DEV)).sum(), [ts[which]])
+        scale = float(ref[which].abs().max()) + 1e-6
+        t.testing.assert_close(got.cpu().double(), ref[which], rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"arg {which}: {m_}")
+
+
+def test_fused_plate_step_backward_layouts_and_fp64_small():
+    """value stored [K, plate, event] (dims in the other order), strided loc / scale, an fp64 small factor (the
+    likelihood of fp64 observations: output and its gradient are fp64)."""
+    g = t.Generator().manual_seed(5)
+    M, NK, NL, NS, Ev = 9, 12, 6, 7, 5
+    pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)
+    z, mu, raw = t.randn(M, NK, Ev, generator=g), t.randn(NL, Ev, generator=g), (0.3 * t.randn(NS, Ev, generator=g)).exp()
+    sm = t.randn(M, NK, generator=g, dtype=t.float64)
+    G = t.randn(NL, NS, generator=g)
+    _, ref = _torch_reference(z, mu, raw, [(sm, ((pl, K), "mk"))], False, G)
+    zt = z.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)             # [K, plate, event]
+    mu2 = t.zeros(NL, 2 * Ev).to(DEV)
+    mu2[:, ::2] = mu.to(DEV)
+    mus = mu2[:, ::2].requires_grad_(True)                                           # stride 2 along the event
+    rd, sd = raw.to(DEV).requires_grad_(True), sm.to(DEV).requires_grad_(True)
+    out, _ = E.normal_lse((zt, (K, pl)), (mus, (dl,)), (rd, (ds,)), [(sd, (pl, K))], pl, K)
+    assert out.dtype == t.float64
+    gz, gm, gr, gs = t.autograd.grad((out * G.to(DEV)).sum(), [zt, mus, rd, sd])
+    assert gs.dtype == t.float64 and gz.shape == zt.shape
+    for n, a, b in (("value", gz.transpose(0, 1), ref[0]), ("loc", gm, ref[1]), ("scale", gr, ref[2]), ("small", gs, ref[3])):
+        scale = float(b.abs().max()) + 1e-6
+        t.testing.assert_close(a.cpu().double(), b, rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")
+
+
+@pytest.mark.parametrize("method", ["vi", "rws"])
+def test_movielens_gradients_fused_route_equals_materialised_route(method, monkeypatch):
+    """elbo_vi / elbo_rws parameter gradients with the fused plate step (forward + alan_normal_lse_backward) against
+    the materialised route (producer kernel, rows kernel, their backwards) on the same particles."""
+    fx = load_golden("e2e_movielens_K10.pt")
+    fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})
+
+    def grads(fuse):
+        monkeypatch.setattr(D, "FUSE_PLATE_STEP", fuse)
+        prob = models.BUILDERS["movielens"](fx).to(DEV)
+        t.manual_seed(3)
+        t.cuda.manual_seed_all(3)
+        sample = prob.sample(12, reparam=(method == "vi"))
+        elbo = sample.elbo_vi(alan.no_checkpoint) if method == "vi" else sample.elbo_rws(alan.no_checkpoint)
+        elbo.backward()
+        return float(elbo), {n: p.grad.detach().cpu().double().clone() for n, p in prob.named_parameters() if p.grad is not None}
+
+    e1, g1 = grads(True)
+    e0, g0 = grads(False)
+    assert abs(e1 - e0) <= 2e-6 * abs(e0) + 1e-5
+    assert set(g1) == set(g0) and len(g0) >= 2
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g1[n], g0[n], rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")

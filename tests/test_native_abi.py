@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 1
+    assert L.alan_abi_version() == 2
     assert L.alan_build_target() == b"gfx950"
 
 
@@ -43,6 +43,36 @@ def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
     assert L.alan_reduce_backward(None, None, 0, None) == -1
     assert L.alan_reduce_backward(ctypes.byref(b), None, 0, None) == -1      # no weight / lse given
     assert L.alan_reduce_backward_workspace_bytes(ctypes.byref(b)) == 0
+
+
+def test_fused_plate_step_struct_layout_and_rejections():
+    """alan_normal_lse_desc_t / alan_normal_lse_backward_desc_t as the header lays them out (natural alignment), and
+    malformed descriptors refused before any GPU work."""
+    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 4 * 4 + 5 * 8 + 8 + 2 * 8 + 4 + 4 + 8 + 8
+    assert ctypes.sizeof(N.NormalLseDesc) == fwd
+    assert ctypes.sizeof(N.NormalLseBackwardDesc) == fwd + 8 + 8 + 2 * 8 + 4 * 8
+    L = N.lib()
+    b = N.NormalLseBackwardDesc()
+    assert L.alan_normal_lse_backward(None, None, 0, None) == -1
+    assert L.alan_normal_lse_backward(ctypes.byref(b), None, 0, None) == -1          # null pointers
+    assert L.alan_normal_lse_backward_workspace_bytes(ctypes.byref(b)) == 0
+    d = N.NormalLseDesc()
+    assert L.alan_normal_lse(ctypes.byref(d), None, 0, None) == -1
+    # a well-formed problem the kernels do not take (event length 40): declined, not attempted
+    dummy = ctypes.c_void_p(0x1000)
+    for x in (b.fwd, d):
+        x.value = x.loc = x.scale = x.out = dummy
+        x.M, x.NK, x.NL, x.NS, x.E = 4, 5, 3, 3, 40
+    b.lse = b.grad_out = b.grad_small = dummy
+    assert L.alan_normal_lse_workspace_bytes(ctypes.byref(d)) == 0
+    assert L.alan_normal_lse(ctypes.byref(d), dummy, 1 << 20, None) == N.ERR_UNSUPPORTED
+    assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 1 << 20, None) == N.ERR_UNSUPPORTED
+    b.fwd.E = d.E = 18
+    assert L.alan_normal_lse_workspace_bytes(ctypes.byref(d)) > 0
+    assert L.alan_normal_lse_backward_workspace_bytes(ctypes.byref(b)) > 0
+    assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 16, None) == -3         # workspace too small
+    b.fwd.small_dtype[0], b.fwd.n_small, b.fwd.small[0] = 7, 1, dummy
+    assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 1 << 20, None) == -1    # bad small-factor dtype
 
 
 def test_bad_descriptors_are_rejected_without_touching_the_gpu():
