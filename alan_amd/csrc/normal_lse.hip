@@ -22,152 +22,199 @@ struct NLDesc {
     float *part;                      // [n_chunks][NL][NS]
     float *lse;                       // optional [M][NL][NS]: the per-plate-element log-sum-exp (the backward's input)
     int32_t M, NK, NL, NS, E, m_chunk, n_small, log_scale;
-    int32_t small_f64;                // bit f: small factor f is fp64 (converted on load)
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se;
-    const void *small[4];
+    const float *small[4];
     int64_t small_sm[4], small_sk[4];
 };
-
-// small factor f at element offset off (fp32, or fp64 converted on load: the likelihood of fp64 observations)
-__device__ __forceinline__ float nl_small(const void *p, int64_t off, bool f64) {
-    return f64 ? (float)((const double *)p)[off] : ((const float *)p)[off];
-}
 
 // On the matrix cores: for one (plate element m, loc row l) the block F[m, l, :, :] is a GEMM over the event dim;
 // with v_mfma_f32_32x32x2_f32 computing D[i = k][j = s] = sum_e d2[(m,k), e] * w[s, e] the log-sum-exp over
 // k runs DOWN the accumulator registers of a lane (16 rows per lane + one exchange between the two half-waves), the
 // sum over m stays in a register, and nothing but out[l, s] partials is ever stored:
-//   A (one VGPR per step): d2 of this lane's k row, rebuilt per plate element with two VALU ops per event pair;
-//   B (one VGPR per step, held for the whole kernel): w of this lane's scale row;  C of the first MFMA: lg[s];
-//   one extra event slot carries the small factors: A = -sum_f small_f[m,k], B = 1.
-// A wave owns one (l, tile of 32 scale rows) pair and a chunk of the plate; k runs in tiles of 32 with an online
-// log-sum-exp across tiles; the value rows of the next tile are loaded while the current one is multiplied.
+//   A (one VGPR per step): d2 of this lane's k row, rebuilt per (plate element, k tile) with two VALU ops per event
+//      pair and used for NST chains of MFMAs -- the wave owns one loc row and NST tiles of 32 scale rows;
+//   B (one VGPR per step and scale tile, held for the whole kernel): log2(e) * w of this lane's scale row, built by
+//      the wave itself in registers (no LDS tables, no barriers);  C = 0 (an inline constant): the log-normaliser
+//      does not depend on k, so it is subtracted once per plate element instead;
+//   one extra event slot carries the small factors: A = -sum_f small_f[m,k], B = log2(e).
+// D is therefore -log2(e) * (log-prob + small) up to the normaliser: the online log-sum-exp across k tiles runs on
+// v_exp_f32 directly (base 2), and log(sum + eps) + max (utils.py:218-220) is taken in natural units at the end.
+// The value rows of the next (m, k tile) are loaded while the current ones are multiplied.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int EH>       // MFMA steps: ceil((E + 1) / 2) -- the event dim plus the small-factor slot
+constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530942f;
+
+// STAGE: value[m, 32 kt .. 32 kt + 31, :] is one contiguous run of 32 * E floats (unit event stride, rows E apart):
+// the wave copies it into its own LDS tile with fully coalesced loads (lane i takes floats i, i + 64, ...) and reads
+// its A operand from there.  Per-lane row loads of the same bytes -- 64 lanes, 64 different rows 72 bytes apart, one
+// dword each, ten times per tile -- keep the CU's texture addresser busy for longer than the MFMAs take.
+
+template <int EH, int NST, bool STAGE>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
 __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     extern __shared__ __align__(16) float lds[];
-    constexpr int EP = 2 * EH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int NK = d.NK, E = d.E, NS = d.NS;
-    float *wt = lds;                                  // [NS][EP]   1/(2 scale^2), pads 0
-    float *lgs = wt + (size_t)NS * EP;                // [NS][EP]   log scale, pads 0
-    float *lgt = lgs + (size_t)NS * EP;               // [NS]       sum_e log scale + E log sqrt(2 pi)
-    const int nst = (NS + 31) >> 5, nkt = (NK + 31) >> 5;
-    const int q = blockIdx.x * 4 + wave;              // (l, scale tile) pair of this wave
-    const bool wave_ok = q < d.NL * nst;
-    const int l = wave_ok ? q / nst : 0, st = wave_ok ? q - l * nst : 0;
-    const int s = 32 * st + j;
-    const bool s_ok = s < NS;
-    const bool small_slot = (E & 1) == h;             // this lane's element of the last step is the small-factor slot
-    // everything this wave needs from global memory is requested before the tables are built: the loc row ...
-    float mreg[EH];
+    const int nkt = (NK + 31) >> 5, nsg = (((NS + 31) >> 5) + NST - 1) / NST;
+    const int q = blockIdx.x * 4 + wave;              // (loc row, group of NST scale tiles) of this wave
+    if (q >= d.NL * nsg) return;                      // (no barriers in this kernel)
+    const int l = q / nsg, sg = q - l * nsg;
+    // the small factors ride in the LAST step's spare element: half-wave 0 when the events leave both elements of
+    // that step free, else half-wave 1 (E = 2 EH - 1) -- one select per tile instead of one per step
+    const bool slot_lane = h == (E > 2 * (EH - 1) ? 1 : 0);
+    const float inf = __builtin_huge_valf();
+    // ---- the wave's operands, in registers: B and the log-normaliser per scale tile, the loc row
+    float breg[NST][EH], lgn[NST];
 #pragma unroll
-    for (int step = 0; step < EH; ++step)
-        mreg[step] = d.loc[(int64_t)l * d.l_sl + (int64_t)min(2 * step + h, E - 1) * d.l_se];
-    // ... and (below) the first tile; meanwhile the workgroup's tables, one scale element per thread and pass
-    for (int i = tid; i < NS * EP; i += 256) {
-        const int is = i / EP, e = i - is * EP;
-        float w = 0.f, lg = 0.f;
-        if (e < E) {
-            const float x = d.scl[(int64_t)is * d.s_ss + (int64_t)e * d.s_se];
-            w = d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x);
-            lg = d.log_scale ? x : logf(x);
+    for (int st = 0; st < NST; ++st) {
+        const int s = 32 * (sg * NST + st) + j;
+        const bool s_ok = s < NS;
+        float lg = 0.f;
+#pragma unroll
+        for (int step = 0; step < EH; ++step) {
+            const int e = 2 * step + h;
+            const float x = d.scl[(int64_t)min(s, NS - 1) * d.s_ss + (int64_t)min(e, E - 1) * d.s_se];
+            const float w = d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x);
+            breg[st][step] = (s_ok && e < E) ? w * NL_LOG2E : (s_ok && step == EH - 1 && slot_lane) ? NL_LOG2E : 0.f;
+            lg += e < E ? (d.log_scale ? x : logf(x)) : 0.f;
         }
-        wt[i] = w;
-        lgs[i] = lg;
+        lgn[st] = lg + __shfl_xor(lg, 32) + (float)E * 0.91893853320467274178f;
     }
-    __syncthreads();
-    for (int is = tid; is < NS; is += 256) {
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < EP; ++e) a += lgs[is * EP + e];
-        lgt[is] = a + (float)E * 0.91893853320467274178f;
-    }
-    __syncthreads();
-    if (!wave_ok) return;                             // (no barriers below)
-    float breg[EH];
+    float mreg[EH];
 #pragma unroll
     for (int step = 0; step < EH; ++step) {
         const int e = 2 * step + h;
-        breg[step] = (s_ok && e < E) ? wt[(size_t)s * EP + e] : (s_ok && e == E) ? 1.f : 0.f;
-        mreg[step] = e < E ? mreg[step] : 0.f;
-    }
-    f32x16 cinit;
-    {
-        const float lg = s_ok ? lgt[s] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cinit[r] = lg;
+        const float x = d.loc[(int64_t)l * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
+        mreg[step] = e < E ? x : 0.f;
     }
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
     const int n_tiles = (m1 - m0) * nkt;
-    // this lane's slice of tile t, RAW: value[m, k, 2 step + h] for k = 32 kt + j and the small factors at (m, k), from
-    // clamped (always valid) addresses, every load issued before anything waits; masks are applied where the values
-    // are used, one iteration later (selects next to the loads made the compiler branch around each pair of loads
-    // and wait for it on the spot)
-    auto load_tile = [&](int t, float (&x)[EH], float (&hs)[4]) {
-        const int m = m0 + t / nkt, kt_ = t - (t / nkt) * nkt;
-        const int k = min(32 * kt_ + j, NK - 1);
-        const float *vp = d.val + (int64_t)m * d.v_sm + (int64_t)k * d.v_sk;
+    // Tile t = (plate element m0 + t / nkt, k tile t % nkt), walked with counters (no division in the loop).  Everything
+    // that addresses a tile is the same for all four waves (they share blockIdx.y): a scalar base plus a 32-bit lane
+    // offset.  Loads are issued from clamped, always valid addresses, all of them before anything waits; masks are
+    // applied where the values are used, one iteration later.
+    // STAGE: x[] holds this lane's share of the tile's contiguous run (floats lane + 64 q): EH loads cover the longest
+    // run of this EH bucket (32 rows x (2 EH - 1) floats / 64 lanes); a shorter run re-reads its last float
+    constexpr int NX = EH;
+    float *tile = lds + wave * (32 * 33);
+    uint32_t soff[NX];                                // STAGE: LDS slot of float lane + 64 q: row * (E + 1) + column
+    if (STAGE) {
+        for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;        // rows beyond NK are never written: keep them finite
 #pragma unroll
-        for (int step = 0; step < EH; ++step) x[step] = vp[(int64_t)min(2 * step + h, E - 1) * d.v_se];
+        for (int qq = 0; qq < NX; ++qq) {
+            const int i = lane + 64 * qq, row = i / E;
+            soff[qq] = i < 32 * E ? row * (E + 1) + (i - row * E) : 32 * 33 - 1;      // (a slot nobody reads)
+        }
+    }
+    const uint32_t row_off = (uint32_t)j * (uint32_t)d.v_sk;               // !STAGE: this lane's row inside a tile
+    auto load_tile = [&](int m, int kt_, float (&x)[NX], float (&hs)[4]) {
+        const float *vp = d.val + (int64_t)m * d.v_sm + (int64_t)(32 * kt_) * d.v_sk;      // (uniform)
+        const int rows = min(32, NK - 32 * kt_);
+        if (STAGE) {
+            const uint32_t lim = (uint32_t)(rows * E - 1);                                  // last valid float of the run
 #pragma unroll
-        for (int f = 0; f < 4; ++f)                   // (the launcher points unused slots at valid memory, stride 0)
-            hs[f] = nl_small(d.small[f], (int64_t)m * d.small_sm[f] + (int64_t)k * d.small_sk[f], (d.small_f64 >> f) & 1);
+            for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        } else {
+            const uint32_t ro = j < rows ? row_off : (uint32_t)(rows - 1) * (uint32_t)d.v_sk;
+#pragma unroll
+            for (int step = 0; step < EH; ++step) x[step] = vp[ro + (uint32_t)min(2 * step + h, E - 1) * (uint32_t)d.v_se];
+        }
+        const uint32_t kk = (uint32_t)min(32 * kt_ + j, NK - 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                 // (the launcher points unused slots at valid memory, stride 0)
+            const float *sp = d.small[f] + (int64_t)m * d.small_sm[f];                       // (uniform)
+            hs[f] = sp[kk * (uint32_t)d.small_sk[f]];
+        }
         asm volatile("" ::: "memory");
     };
-    float zc[EH], zn[EH], hc[4], hn[4];
-    if (n_tiles > 0) load_tile(0, zc, hc);
-    float accm = 0.f, mn = __builtin_huge_valf(), sm = 0.f;
-    int kt = 0;
+    float zc[NX], zn[NX], hc[4], hn[4];
+    if (n_tiles > 0) load_tile(m0, 0, zc, hc);
+    float accm[NST], mn[NST], sm[NST];                // plate sum; running minimum of D (= -max, base 2) and sum 2^(mn - D)
+#pragma unroll
+    for (int st = 0; st < NST; ++st) accm[st] = 0.f, mn[st] = inf, sm[st] = 0.f;
+    const float n_small_mask[4] = {d.n_small > 0 ? 1.f : 0.f, d.n_small > 1 ? 1.f : 0.f, d.n_small > 2 ? 1.f : 0.f,
+                                   d.n_small > 3 ? 1.f : 0.f};
+    int kt = 0, m = m0;
     for (int t = 0; t < n_tiles; ++t) {
-        if (t + 1 < n_tiles) load_tile(t + 1, zn, hn);
+        {
+            int kt_n = kt + 1, m_n = m;
+            if (kt_n == nkt) kt_n = 0, ++m_n;
+            if (t + 1 < n_tiles) load_tile(m_n, kt_n, zn, hn);
+        }
         // A operand.  No masks: pad events meet a zero in B; rows beyond NK (and plate elements' -inf small factors)
         // put +inf into the small-factor slot, which makes their whole row of D +inf = a log-prob of -inf
         const bool k_ok = 32 * kt + j < NK;
+        float hsum = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) hsum += n_small_mask[f] != 0.f ? hc[f] : 0.f;
         float a[EH];
+        if (STAGE) {
+            // (one wave, in-order LDS queue: last tile's reads precede these writes, these writes the reads below)
+#pragma unroll
+            for (int qq = 0; qq < NX; ++qq) tile[soff[qq]] = zc[qq];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int step = 0; step < EH; ++step) a[step] = tile[j * (E + 1) + min(2 * step + h, E - 1)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int step = 0; step < EH; ++step) a[step] = zc[step];
+        }
 #pragma unroll
         for (int step = 0; step < EH; ++step) {
-            const float df = zc[step] - mreg[step];
+            const float df = a[step] - mreg[step];
             a[step] = df * df;
         }
-        {   // the small-factor slot is element E = 2 (EH - 1) + (E & 1): always in the LAST step's register
-            float hsum = 0.f;
+        if (slot_lane) a[EH - 1] = k_ok ? -hsum : inf;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) hsum += f < d.n_small ? hc[f] : 0.f;
-            if (small_slot) a[EH - 1] = k_ok ? -hsum : __builtin_huge_valf();
-        }
-        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], breg[0], cinit, 0, 0, 0);
+        for (int st = 0; st < NST; ++st) {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int step = 1; step < EH; ++step) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step], breg[step], acc, 0, 0, 0);
-        // acc[r] = -log-prob of row k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h: log-sum-exp down the registers
-        // (utils.py:218-220), kept on u = -value: running minimum mn = -max, sm = sum exp(mn - u)
-        float tmin = __builtin_huge_valf();
+            for (int step = 0; step < EH; ++step)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step], breg[st][step], acc, 0, 0, 0);
+            // acc[r] = -log2(e) (log-prob + small) of row k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h (normaliser apart):
+            // online log-sum-exp down the registers, branch-free (an infinite minimum is replaced by 0 where it
+            // enters a difference: 2^(0 - inf) = 0, and the sum it would scale is 0)
+            float tmin = acc[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmin = fminf(tmin, acc[r]);
-        if (tmin < mn) {
-            sm *= __expf(tmin - mn);                  // (mn = +inf at the start: exp(-inf) = 0, and sm is 0 anyway)
-            mn = tmin;
-        }
-        if (mn != __builtin_huge_valf()) {
+            for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
+            const float mnew = fminf(mn[st], tmin);
+            const float mf = mnew == inf ? 0.f : mnew;
+            float ssum = sm[st] * __builtin_amdgcn_exp2f(mf - (mn[st] == inf ? mf : mn[st]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm += __expf(mn - acc[r]);
+            for (int r = 0; r < 16; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc[r]);
+            mn[st] = mnew, sm[st] = ssum;
         }
         if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
-            float mx = -mn, mx2 = -__shfl_xor(mn, 32), sm2 = __shfl_xor(sm, 32);
-            lse_merge(mx, sm, mx2, sm2);
-            const float lse_m = lse_finish(mx, sm);
-            accm += lse_m;
-            if (d.lse && h == 0 && s_ok) d.lse[((int64_t)(m0 + t / nkt) * d.NL + l) * NS + s] = lse_m;
-            mn = __builtin_huge_valf(), sm = 0.f, kt = 0;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const float mn2 = __shfl_xor(mn[st], 32), sm2 = __shfl_xor(sm[st], 32);
+                const float mm = fminf(mn[st], mn2);
+                const float mf = mm == inf ? 0.f : mm;
+                const float tot = sm[st] * __builtin_amdgcn_exp2f(mf - (mn[st] == inf ? mf : mn[st])) +
+                                  sm2 * __builtin_amdgcn_exp2f(mf - (mn2 == inf ? mf : mn2));
+                // log(sum + eps) + max in natural units (utils.py:218-220); an all -inf (or +inf) column gives NaN there
+                float lse_m = logf(tot + Num<float>::eps) - mm * NL_LN2 - lgn[st];
+                if (mm == inf || mm == -inf) lse_m = __builtin_nanf("");
+                accm[st] += lse_m;
+                const int s = 32 * (sg * NST + st) + j;
+                if (d.lse && h == 0 && s < NS) d.lse[((int64_t)m * d.NL + l) * NS + s] = lse_m;
+                mn[st] = inf, sm[st] = 0.f;
+            }
+            kt = 0, ++m;
         }
 #pragma unroll
-        for (int step = 0; step < EH; ++step) zc[step] = zn[step];
+        for (int i = 0; i < NX; ++i) zc[i] = zn[i];
 #pragma unroll
         for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
-    if (h == 0 && s_ok) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int s = 32 * (sg * NST + st) + j;
+        if (h == 0 && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[st];
+    }
 }
 
 }  // namespace alan
@@ -176,9 +223,14 @@ using namespace alan;
 
 namespace {
 
+bool env_stage_ok() {
+    static const int knob = env_knob("ALAN_NLSE_STAGE");          // ablation knob: 0 = per-lane row loads
+    return knob == ENV_UNSET || knob != 0;
+}
+
 struct NLPlan {
-    int eh = 0, m_chunk = 1, n_chunks = 1;
-    size_t lds = 0, part_bytes = 0;
+    int eh = 0, nst = 1, m_chunk = 1, n_chunks = 1;
+    size_t part_bytes = 0;
     dim3 grid;
 };
 
@@ -186,24 +238,24 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     if (!a.value || !a.loc || !a.scale || !a.out) return ALAN_ERR_BAD_DESC;
     if (a.M < 1 || a.NK < 1 || a.NL < 1 || a.NS < 1 || a.E < 1) return ALAN_ERR_BAD_DESC;
     if (a.n_small < 0 || a.n_small > 4) return ALAN_ERR_BAD_DESC;
-    for (int f = 0; f < a.n_small; ++f) {
+    for (int f = 0; f < a.n_small; ++f)
         if (!a.small[f]) return ALAN_ERR_BAD_DESC;
-        if (a.small_dtype[f] != ALAN_F32 && a.small_dtype[f] != ALAN_F64) return ALAN_ERR_BAD_DESC;
-    }
-    if (a.out_dtype != ALAN_F32 && a.out_dtype != ALAN_F64) return ALAN_ERR_BAD_DESC;
     if (a.E > 32 || a.NK > 4096 || a.NS > 4096 || a.NL > (1 << 20) || a.M > (1 << 24)) return ALAN_ERR_UNSUPPORTED;
-    // a wave per (loc row, tile of 32 scale rows), 4 per workgroup; the plate in chunks so that ~4096 waves exist
-    p.eh = (int)(a.E + 2) / 2;
-    const int64_t nst = (a.NS + 31) / 32;
-    const int64_t gx = (a.NL * nst + 3) / 4;
-    int64_t target = 1024;                                                   // workgroups (x 4 waves)
+    // a wave per (loc row, group of up to 4 tiles of 32 scale rows), 4 per workgroup; the plate in chunks so that the
+    // chip holds every wave at once (3 per SIMD)
+    const int need = (int)(a.E + 2) / 2;
+    p.eh = need <= 4 ? 4 : need <= 8 ? 8 : need <= 10 ? 10 : need <= 12 ? 12 : 17;
+    const int64_t nst_total = (a.NS + 31) / 32;
+    p.nst = nst_total >= 4 ? 4 : nst_total >= 2 ? 2 : 1;
+    const int64_t nsg = (nst_total + p.nst - 1) / p.nst;
+    const int64_t gx = (a.NL * nsg + 3) / 4;
+    int64_t target = 768;                                                    // workgroups (x 4 waves)
     static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
     if (blocks_knob != ENV_UNSET) target = std::max(1, blocks_knob);
     int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, target / std::max<int64_t>(1, gx)));
+    nch = std::min<int64_t>(nch, 65535);
     p.m_chunk = (int)((a.M + nch - 1) / nch);
     p.n_chunks = (int)((a.M + p.m_chunk - 1) / p.m_chunk);
-    p.lds = ((size_t)a.NS * 4 * p.eh + a.NS + 8) * sizeof(float);
-    if (p.lds > 150 * 1024) return ALAN_ERR_UNSUPPORTED;
     p.part_bytes = (size_t)p.n_chunks * a.NL * a.NS * sizeof(float);
     p.grid = dim3((uint32_t)gx, (uint32_t)p.n_chunks);
     return ALAN_OK;
@@ -239,38 +291,32 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     d.l_sl = a->l_sl, d.l_se = a->l_se, d.s_ss = a->s_ss, d.s_se = a->s_se;
     for (int f = 0; f < 4; ++f) {
         const bool used = f < a->n_small;
-        d.small[f] = used ? a->small[f] : a->value;                                  // (unused: any valid address)
-        if (used && a->small_dtype[f] == ALAN_F64) d.small_f64 |= 1 << f;
+        d.small[f] = used ? (const float *)a->small[f] : (const float *)a->value;    // (unused: any valid address)
         d.small_sm[f] = used ? a->small_sm[f] : 0;
         d.small_sk[f] = used ? a->small_sk[f] : 0;
     }
+    // the staged variant needs the tile's 32 rows to be one contiguous run of the value tensor
+    const bool stage = a->v_se == 1 && a->v_sk == a->E && env_stage_ok();
+    const size_t lds = stage ? 4 * 32 * 33 * sizeof(float) : 0;
     auto launch = [&](auto kern) {
-        if (p.lds > 64 * 1024)
-            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
-                hipSuccess)
-                return ALAN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, p.grid, dim3(256), p.lds, stream, d);
+        hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
+#define NL_PICK(EHV, NSTV) (stage ? launch(normal_lse_mfma_kernel<EHV, NSTV, true>) : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
+#define NL_CASE(EHV)                                                                                   \
+    case EHV:                                                                                          \
+        rc = p.nst == 4 ? NL_PICK(EHV, 4) : p.nst == 2 ? NL_PICK(EHV, 2) : NL_PICK(EHV, 1);            \
+        break;
     switch (p.eh) {
-        case 1: rc = launch(normal_lse_mfma_kernel<1>); break;
-        case 2: rc = launch(normal_lse_mfma_kernel<2>); break;
-        case 3: rc = launch(normal_lse_mfma_kernel<3>); break;
-        case 4: rc = launch(normal_lse_mfma_kernel<4>); break;
-        case 5: rc = launch(normal_lse_mfma_kernel<5>); break;
-        case 6: rc = launch(normal_lse_mfma_kernel<6>); break;
-        case 7: rc = launch(normal_lse_mfma_kernel<7>); break;
-        case 8: rc = launch(normal_lse_mfma_kernel<8>); break;
-        case 9: rc = launch(normal_lse_mfma_kernel<9>); break;
-        case 10: rc = launch(normal_lse_mfma_kernel<10>); break;
-        case 11: rc = launch(normal_lse_mfma_kernel<11>); break;
-        case 12: rc = launch(normal_lse_mfma_kernel<12>); break;
-        case 13: rc = launch(normal_lse_mfma_kernel<13>); break;
-        case 14: rc = launch(normal_lse_mfma_kernel<14>); break;
-        case 15: rc = launch(normal_lse_mfma_kernel<15>); break;
-        case 16: rc = launch(normal_lse_mfma_kernel<16>); break;
-        default: rc = launch(normal_lse_mfma_kernel<17>);
+        NL_CASE(4)
+        NL_CASE(8)
+        NL_CASE(10)
+        NL_CASE(12)
+        default:
+            rc = p.nst == 4 ? NL_PICK(17, 4) : p.nst == 2 ? NL_PICK(17, 2) : NL_PICK(17, 1);
     }
+#undef NL_PICK
+#undef NL_CASE
     if (rc != ALAN_OK) return rc;
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
@@ -283,7 +329,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     s2.w.p = nullptr;
     s2.l.p = nullptr;
     s2.o.p = a->out;
-    s2.o.dtype = a->out_dtype;
+    s2.o.dtype = ALAN_F32;
     s2.o.scale = 1.f;
     for (int j = 0; j < MAXD; ++j) s2.f[0].ks[j] = s2.f[0].rs[j] = s2.o.ks[j] = 0;
     s2.nk = 0, s2.nr = 0, s2.n_out = 1, s2.n_red = 1;
@@ -305,7 +351,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     s2.keep_contig = true;
     GroupDesc gd;
     GroupLaunch gl;
-    rc = plan_group(s2, a->out_dtype, a->add_const, gd, gl);
+    rc = plan_group(s2, ALAN_F32, a->add_const, gd, gl);
     if (rc != ALAN_OK) return rc;
     rc = try_launch_small(s2, gd, gl, ALAN_MODE_SUM, ALAN_F32, stream, EvPair());
     if (rc == ALAN_ERR_UNSUPPORTED) rc = launch_group(gd, gl, ALAN_MODE_SUM, ALAN_F32, stream);

@@ -33,15 +33,11 @@ struct NLBDesc {
     float *dsm;       // [gy][M][NK]
     float *ploc;      // [M * nkt * nst][NL][E]
     float *pscl;      // [M * nkt * gy][NS][E]
-    int32_t M, NK, NL, NS, E, n_small, log_scale, small_f64;
+    int32_t M, NK, NL, NS, E, n_small, log_scale;
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se, g_sl, g_ss;
-    const void *small[4];
+    const float *small[4];
     int64_t small_sm[4], small_sk[4];
 };
-
-__device__ __forceinline__ float nlb_small(const void *p, int64_t off, bool f64) {
-    return f64 ? (float)((const double *)p)[off] : ((const float *)p)[off];
-}
 
 constexpr int NLB_TS = 36;                 // row stride (floats) of a wave's 32 x 32 transpose tile: 144 B, 16-byte aligned
 constexpr int NLB_SCR = 32 * NLB_TS;       // floats per wave
@@ -91,8 +87,7 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
     float hsum = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const float x = nlb_small(d.small[f], (int64_t)m * d.small_sm[f] + (int64_t)min(kA, NK - 1) * d.small_sk[f],
-                                  (d.small_f64 >> f) & 1);
+        const float x = d.small[f][(int64_t)m * d.small_sm[f] + (int64_t)min(kA, NK - 1) * d.small_sk[f]];
         hsum += f < d.n_small ? x : 0.f;
     }
     // the same rows with the event index on the lanes: vT[r] = value[m, k_r(h), e = j], 1 in column E, 0 beyond
@@ -349,10 +344,8 @@ int plan_nlb(const alan_normal_lse_backward_desc_t &b, NLBPlan &p) {
     if (!a.value || !a.loc || !a.scale || !b.lse || !b.grad_out) return ALAN_ERR_BAD_DESC;
     if (a.M < 1 || a.NK < 1 || a.NL < 1 || a.NS < 1 || a.E < 1) return ALAN_ERR_BAD_DESC;
     if (a.n_small < 0 || a.n_small > 4) return ALAN_ERR_BAD_DESC;
-    for (int f = 0; f < a.n_small; ++f) {
+    for (int f = 0; f < a.n_small; ++f)
         if (!a.small[f]) return ALAN_ERR_BAD_DESC;
-        if (a.small_dtype[f] != ALAN_F32 && a.small_dtype[f] != ALAN_F64) return ALAN_ERR_BAD_DESC;
-    }
     if (a.E > 31 || a.NK > 4096 || a.NS > 4096 || a.NL > (1 << 20) || a.M > (1 << 22)) return ALAN_ERR_UNSUPPORTED;
     const int need = (int)(a.E + 2) / 2;                     // MFMA steps: the event dim plus the small-factor slot
     p.eh = need <= 4 ? 4 : need <= 8 ? 8 : need <= 10 ? 10 : need <= 12 ? 12 : 16;
@@ -421,10 +414,9 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     d.g_sl = b->g_sl, d.g_ss = b->g_ss;
     for (int f = 0; f < 4; ++f) {
         const bool used = f < a.n_small;
-        d.small[f] = used ? a.small[f] : a.value;                             // (unused: any valid address)
+        d.small[f] = used ? (const float *)a.small[f] : (const float *)a.value;   // (unused: any valid address)
         d.small_sm[f] = used ? a.small_sm[f] : 0;
         d.small_sk[f] = used ? a.small_sk[f] : 0;
-        if (used && a.small_dtype[f] == ALAN_F64) d.small_f64 |= 1 << f;
     }
     const bool split = p.gy > 1;
     d.dval = b->grad_value ? (split ? (float *)(ws + p.o_dvp) : (float *)b->grad_value) : nullptr;
@@ -438,7 +430,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
                 hipSuccess)
                 return ALAN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, grid, dim3(256), p.lds, stream, d);
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), p.lds, stream, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
 #define NLB_CASE(EHV)                                                                        \

@@ -307,6 +307,10 @@ def _normal_lse_args(value, loc, scale, smalls, plate, K):
     if not all(x.dtype == t.float32 for x in (xv, xl, xs)) or \
             not all(x.dtype in (t.float32, t.float64) for x, _ in smalls):
         return None
+    wide = any(x.dtype == t.float64 for x, _ in smalls)
+    # (an fp64 small factor -- the likelihood of fp64 observations -- enters the fp32 kernel converted; the result is
+    # returned as fp64, the dtype torch's promotion gives the reference's sum of factors)
+    smalls = [(x.float() if x.dtype == t.float64 else x, d) for x, d in smalls]
     if len(dv) != 2 or len(dl) != 1 or len(ds) != 1:
         return None
     nev = xv.ndim - 2
@@ -329,7 +333,7 @@ def _normal_lse_args(value, loc, scale, smalls, plate, K):
             return None
         st = {id(dd): (x.stride(j) if x.shape[j] > 1 else 0) for j, dd in enumerate(dims)}
         sm.append((x, st.get(id(plate), 0), st.get(id(K), 0)))
-    return dict(xv=xv, xl=xl, xs=xs, ip=ip, smalls=sm, dl=dl[0], ds=ds[0])
+    return dict(xv=xv, xl=xl, xs=xs, ip=ip, smalls=sm, dl=dl[0], ds=ds[0], wide=wide)
 
 
 def _normal_lse_desc(a, log_scale, d=None):
@@ -340,7 +344,7 @@ def _normal_lse_desc(a, log_scale, d=None):
     d.scale, d.s_ss, d.s_se = xs.data_ptr(), xs.stride(0), xs.stride(1)
     d.log_scale, d.n_small = int(bool(log_scale)), len(a["smalls"])
     for i, (x, s_m, s_k) in enumerate(a["smalls"]):
-        d.small[i], d.small_sm[i], d.small_sk[i], d.small_dtype[i] = x.data_ptr(), s_m, s_k, N.dtype_code(x.dtype)
+        d.small[i], d.small_sm[i], d.small_sk[i] = x.data_ptr(), s_m, s_k
     d.M, d.NK, d.NL, d.NS, d.E = xv.shape[ip], xv.shape[1 - ip], xl.shape[0], xs.shape[0], xv.shape[2]
     return d
 
@@ -349,14 +353,13 @@ def _normal_lse_forward(a, log_scale, want_lse):
     """One alan_normal_lse launch.  -> (out [NL, NS], lse [M, NL, NS] or None), or None when the library declines."""
     d = _normal_lse_desc(a, log_scale)
     device = a["xv"].device
-    dtype = t.float64 if any(x.dtype == t.float64 for x, _, _ in a["smalls"]) else t.float32
-    out = t.empty(d.NL, d.NS, dtype=dtype, device=device)
-    d.out, d.o_sl, d.o_ss, d.out_dtype, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), N.dtype_code(dtype), 0.0
+    out = t.empty(d.NL, d.NS, dtype=t.float32, device=device)
+    d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
     lse = t.empty(d.M, d.NL, d.NS, dtype=t.float32, device=device) if want_lse else None
     d.lse_out = lse.data_ptr() if want_lse else None
     if not N.run_normal_lse(d, device):
         return None
-    return out, lse
+    return (out.double() if a["wide"] else out), lse
 
 
 class _NormalLse(t.autograd.Function):

@@ -18,6 +18,7 @@ F32, F64 = 0, 1
 KEEP, REDUCE, PLATE = 0, 1, 2
 MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSCALE = 0, 1, 2, 3, 4, 5
 MODE_PRODUCER_GRAD = 6
+MODE_FUSED_FWD, MODE_FUSED_BWD = 100, 101      # (KernelTimer record tags of alan_normal_lse / _backward; not library modes)
 GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
 
 _STATUS = {
@@ -70,10 +71,9 @@ class NormalLseDesc(C.Structure):
                 ("scale", C.c_void_p), ("s_ss", C.c_int64), ("s_se", C.c_int64),
                 ("log_scale", C.c_int32), ("n_small", C.c_int32),
                 ("small", C.c_void_p * 4), ("small_sm", C.c_int64 * 4), ("small_sk", C.c_int64 * 4),
-                ("small_dtype", C.c_int32 * 4),
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
-                ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64), ("out_dtype", C.c_int32),
-                ("lse_out", C.c_void_p), ("add_const", C.c_double)]
+                ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64),
+                ("lse_out", C.c_void_p), ("add_const", C.c_double), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 class NormalLseBackwardDesc(C.Structure):
@@ -303,6 +303,8 @@ def run_normal_lse(desc, device):
     nbytes = L.alan_normal_lse_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         return False
+    if _TIMER[0] is not None:
+        _TIMER[0].attach(desc, 0, mode=MODE_FUSED_FWD, flops=2.0 * desc.M * desc.NK * desc.NL * desc.NS * (desc.E + 1))
     ws = t.empty(nbytes, dtype=t.uint8, device=device)
     rc = L.alan_normal_lse(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
     if rc == ERR_UNSUPPORTED:
@@ -319,6 +321,9 @@ def run_normal_lse_backward(desc, device):
     nbytes = L.alan_normal_lse_backward_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         return False
+    if _TIMER[0] is not None:
+        f = desc.fwd
+        _TIMER[0].attach(f, 0, mode=MODE_FUSED_BWD, flops=2.0 * f.M * f.NK * f.NL * f.NS * (f.E + 1))
     ws = t.empty(nbytes, dtype=t.uint8, device=device)
     rc = L.alan_normal_lse_backward(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
     if rc == ERR_UNSUPPORTED:

@@ -36,14 +36,16 @@ class KernelTimer:
     def __exit__(self, *a):
         N._TIMER[0] = self._prev
 
-    def attach(self, desc, algo_bytes):
-        if algo_bytes < self.min_bytes:
+    def attach(self, desc, algo_bytes, mode=None, flops=0.0):
+        """``mode`` / ``flops``: the fused plate step's descriptors carry no mode field; their records are tagged
+        native.MODE_FUSED_FWD / _BWD and carry the algorithmic FLOPs of the tile GEMM in place of bytes."""
+        if mode is None and algo_bytes < self.min_bytes:
             return
         h = hip()
         a, b = C.c_void_p(), C.c_void_p()
         assert h.hipEventCreate(C.byref(a)) == 0 and h.hipEventCreate(C.byref(b)) == 0
         desc.ev_start, desc.ev_stop = a.value, b.value
-        self.records.append((int(desc.mode), algo_bytes, a, b))
+        self.records.append((int(desc.mode) if mode is None else mode, algo_bytes if mode is None else flops, a, b))
 
     def results(self):
         """[(mode, algorithmic_bytes, milliseconds)] -- call after the stream has been synchronised."""

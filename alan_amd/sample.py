@@ -12,6 +12,11 @@ from .logpq import logPQ_plate
 from .split import checkpoint, no_checkpoint
 
 
+AUTO_GRAPH = True
+"""``sample.elbo_nograd(strategy)`` -- the reference's own spelling, no ``graph=`` argument -- replays a captured HIP
+graph from the third call on (see Sample.elbo_nograd).  False: such calls always launch kernel by kernel."""
+
+
 def _detach_tree(tree):
     return {k: (_detach_tree(v) if isinstance(v, dict) else v.detach()) for k, v in tree.items()}
 
@@ -151,23 +156,58 @@ class Sample:
         """ELBO on the detached sample (gradients flow to parameters only, as RWS wants)."""
         return self._elbo(self._pt_detached, None, computation_strategy)
 
-    def elbo_nograd(self, computation_strategy=checkpoint, graph=False):
-        """The ELBO with no gradients.  ``graph=True`` (GPU only) captures the whole evaluation -- every
-        log-prob kernel, every alan_reduce launch and, for a sharded Split, the all-reduce -- into a HIP
-        graph on first use and replays it afterwards: the same kernels read the same sample /
-        parameter / data memory each time (in-place parameter updates are seen), but the ~1 ms of
-        Python + launch overhead per evaluation is paid once."""
-        if graph and self.device.type == "cuda":
-            return self._graphed(computation_strategy)()
+    def elbo_nograd(self, computation_strategy=checkpoint, graph=None):
+        """The ELBO with no gradients (Sample.py:135-148).  On the GPU the whole evaluation -- every log-prob kernel,
+        every alan_reduce launch and, for a sharded Split, the all-reduce -- can be captured into a HIP graph and
+        replayed: the same kernels read the same sample / parameter / data memory each time (in-place parameter
+        updates are seen), but the Python + launch overhead of an evaluation (0.5 ms) is paid once.
+        ``graph=True``: capture on first use; ``graph=False``: always launch kernel by kernel; default (``None``):
+        the SECOND evaluation of the same sample under the same strategy captures, later ones replay (AUTO_GRAPH) --
+        as long as the problem's tensors still live where they did (a ``problem.to(...)`` / ``.double()`` starts
+        over), and never inside someone else's stream capture."""
+        if self.device.type == "cuda":
+            if graph:
+                return self._graphed(computation_strategy)()
+            if graph is None and AUTO_GRAPH:
+                g = self._auto_graphed(computation_strategy)
+                if g is not None:
+                    return g()
         with t.no_grad():
             return self._elbo(self._pt_detached, None, computation_strategy)
 
-    def _graphed(self, computation_strategy):
+    def _auto_graphed(self, computation_strategy):
+        """The captured evaluation for an unadorned ``elbo_nograd()`` call, or None (first call under this key; an
+        evaluation that cannot be captured -- e.g. MultivariateNormal.log_prob synchronises --; timing / capture in
+        progress)."""
+        from . import native as N
+        if N._TIMER[0] is not None or t.cuda.is_current_stream_capturing():
+            return None
+        key = (self._graph_key(computation_strategy), self.problem.memory_fingerprint())
+        state = self.__dict__.setdefault("_auto", {})
+        g = state.get(key)
+        if g is None:
+            state[key] = "seen"                 # this call runs eagerly; the next one captures
+            return None
+        if g == "seen":
+            try:
+                g = _GraphedELBO(self, computation_strategy)
+            except Exception:
+                g = False                       # not capturable: stay eager for this key
+                t.cuda.synchronize()
+            if len(state) > 8:
+                state.clear()
+            state[key] = g
+        return g or None
+
+    def _graph_key(self, computation_strategy):
         from . import dist as D
         from . import native as N
         # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
-        key = (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-               N.DEFER_SMALL_LAUNCHES)
+        return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
+                N.DEFER_SMALL_LAUNCHES)
+
+    def _graphed(self, computation_strategy):
+        key = self._graph_key(computation_strategy)
         cache = self.__dict__.setdefault("_graphs", {})
         if key not in cache:
             cache[key] = _GraphedELBO(self, computation_strategy)

@@ -199,23 +199,43 @@ def cpu_baseline(K, gpu_sample, gpu_elbo, budget_s=20.0):
             "elbo": float(v), "elbo_rel_diff_vs_gpu": abs(float(v) - gpu_elbo) / abs(gpu_elbo)}
 
 
-def pmc_traffic(key):
-    """HBM bytes per launch of the rows kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, see profiles/r1_rows_kernel_pmc.md).  Counters cannot be read from inside this process;
-    null when the profile does not cover this configuration."""
+def pmc_traffic(name, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, collected in separate
+    --pmc runs as MI355X_MICROARCH.md prescribes: profiles/<name>).  Counters cannot be read from inside this process;
+    null when the committed profile does not cover this configuration."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_rows_kernel_pmc.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return d[key]["traffic_bytes"]
     except Exception:
         return None
 
 
-def roofline_scaled(K, scale=64, iters=20):
-    """The dominant kernel (S-ML plate step F[M,K,K,K] + g[M,K] -> lse K_z -> sum M) in the bandwidth
-    regime: M = 300*scale so that F (2 GB at K=30) is far beyond the 256 MiB Infinity Cache."""
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate
+
+
+def fused_roofline(records, tag, what):
+    """roofline object of the fused plate step from KernelTimer records (native.MODE_FUSED_*): algorithmic FLOPs of
+    the tile GEMM (2 * M * K^3 * (E + 1)) over the MFMA kernel's own duration."""
+    sel = [(f, ms) for mode, f, ms in records if mode == tag]
+    if not sel:
+        return None
+    flops = max(f for f, _ in sel)
+    ts = [ms for f, ms in sel if f == flops]
+    ms = sum(ts) / len(ts)
+    tf = flops / ms / 1e9
+    return {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "traffic": None, "kernel": what, "us_per_launch": ms * 1e3, "algorithmic_flops": flops,
+            "launches_timed": len(ts),
+            "note": "fp32 MFMA results are consumed by the vector unit (one exp per element) and on gfx950 the two do not "
+                    "overlap: tools/mfma_f32_probe.hip measures 0.60 of peak for a bare chain-of-10-MFMAs + "
+                    "log-sum-exp tile loop -- the practical ceiling of this kernel"}
+
+
+def rows_roofline(K, M, iters=20, traffic_key=None):
+    """The HBM-bound reduce_Ks kernel (rows.hip) on the S-ML plate step with the factor MATERIALISED --
+    F[M,K,K,K] + g[M,K] -> lse K_z -> sum M -- the route every shape other than the fused one takes."""
     from alan_amd import engine as E
     from alan_amd.profiling import KernelTimer
-    M = M_USERS * scale
     g = t.Generator(device="cuda").manual_seed(1234)
     F = -0.5 * t.randn(M, K, K, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
     gz = -0.5 * t.randn(M, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
@@ -223,7 +243,7 @@ def roofline_scaled(K, scale=64, iters=20):
     for _ in range(3):
         E.reduce_factors(fac, reduce=("z",), plate=("m",))
     t.cuda.synchronize()
-    with KernelTimer() as kt:
+    with KernelTimer(min_bytes=1 << 16) as kt:
         for _ in range(iters):
             E.reduce_factors(fac, reduce=("z",), plate=("m",))
         t.cuda.synchronize()
@@ -232,9 +252,19 @@ def roofline_scaled(K, scale=64, iters=20):
     ms = sum(m for _, _, m in res) / len(res)
     gbs = algo / ms / 1e6
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("scaled_K30_M19200") if (K, scale) == (30, 64) else None,
-            "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3,
-            "algorithmic_bytes": algo, "workload": f"S-ML plate step, K={K}, M={M} (300x{scale})"}
+            "traffic": pmc_traffic("r1_rows_kernel_pmc.json", traffic_key) if traffic_key else None,
+            "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3, "algorithmic_bytes": algo,
+            "workload": f"S-ML plate step on a materialised factor, K={K}, M={M}"}
+
+
+def cpu_elbo_of(builder, gpu_sample):
+    """The same ELBO (same particles) through the CPU oracle -- the parity check of a bench configuration."""
+    from oracle import backend
+    import alan_amd as alan
+    prob = builder("cpu")
+    sample = sample_on_cpu(gpu_sample, prob)
+    with backend.installed():
+        return float(sample.elbo_nograd(alan.no_checkpoint))
 
 
 def self_launch(args):
@@ -259,7 +289,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--K", type=int, default=30)
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline / scaled roofline / K sweep")
+    ap.add_argument("--no-extras", action="store_true", help="skip everything but the headline figure and its roofline")
     ap.add_argument("--c4-only", action="store_true", help="of the extras, only the C4 (movielens K=100) figure")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python each step instead of replaying a HIP graph")
@@ -281,7 +311,9 @@ def main():
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr "
                          f"127.0.0.1 bench.py --gpus {args.gpus} ...` or plain `python bench.py --gpus {args.gpus}`")
 
+    import alan_amd as alan
     from alan_amd import native
+    from alan_amd import dist as adist
     from alan_amd.profiling import KernelTimer
     native.lib()                                   # fail loudly if the HIP library is missing
 
@@ -290,13 +322,13 @@ def main():
     sample = draw(prob, K)
     strat = strategy_for(world, K)
     use_graph = not args.eager and os.environ.get("ALAN_BENCH_GRAPH", "1") != "0"
-    kt = KernelTimer(min_bytes=1 << 20)
     if use_graph:
         try:
             dt, elbo = timed_evals(sample, strat, args.steps, args.warmup, world, graph=True)
-        except Exception as e:                           # capture unsupported (e.g. a collective): eager
+        except Exception as e:                           # capture unsupported: eager
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
+    kt = KernelTimer(min_bytes=1 << 20)
     if use_graph:
         # per-kernel HIP events cannot be recorded inside a replayed graph: time the same launches
         # eagerly, same process, same buffers, right after the timed region
@@ -316,39 +348,35 @@ def main():
         "config": {"workload": f"movielens M={M_USERS} N={N_FILMS} d_z={D_Z}, K={K}, elbo_nograd on a fixed sample",
                    "launch": "HIP graph replay of one captured ELBO evaluation" if use_graph
                    else "eager (one Python-driven launch per kernel)",
+                   "plate_step": "fused (alan_normal_lse: producer + log-sum-exp + plate sum in one launch)"
+                   if adist.FUSE_PLATE_STEP else "materialised factor (producer kernel + rows kernel)",
                    "computation_strategy": type(strat).__name__ +
                    (f"('plate_1', {strat.split_size}, shard=True)" if world > 1 else ""),
                    "parallelism": f"plate_1 sharded over {world} rank(s), one all-reduce(SUM) of [K,K] per eval"
                    if world > 1 else "single GPU"},
         "elbo": elbo,
     }
-    # ---- roofline of the dominant reduce_Ks kernel, timed live with HIP events inside the timed region
-    res_lse = [(b, m) for mode, b, m in res if mode == native.MODE_LSE]
-    if res_lse:
-        big = max(b for b, _ in res_lse)
-        sel = [m for b, m in res_lse if b == big]
-        ms = sum(sel) / len(sel)
-        gbs = big / ms / 1e6
-        out["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": gbs / HBM_PEAK_GBS,
-                           "traffic": pmc_traffic("literal_K30_M300") if (K, world) == (30, 1) else None,
-                           "kernel": "alan::rows_kernel (plate_1 step: F[M,K,K,K]+g[M,K] -> lse K_z -> sum M)",
-                           "us_per_launch": ms * 1e3, "algorithmic_bytes": big, "launches_timed": len(sel),
-                           "note": "literal size: 32 MB fits the 256 MiB Infinity Cache and ~1 wave of workgroups; "
-                                   "see roofline_scaled for the bandwidth regime"}
-    res_prod = [(b, m) for mode, b, m in res if mode in (native.MODE_NORMAL, native.MODE_NORMAL_LOGSCALE)]
-    if res_prod:
-        big = max(b for b, _ in res_prod)
-        sel = [m for b, m in res_prod if b == big]
-        out["producer"] = {"kernel": "alan::normal_mfma_kernel (fused Normal log-prob producer of F: v_mfma_f32_32x32x2_f32 over "
-                                     "the event dim, store-bound)",
-                           "us_per_launch": sum(sel) / len(sel) * 1e3, "bytes_written": big,
-                           "achieved_write_GBps": big / (sum(sel) / len(sel)) / 1e6,
-                           "write_floor_us": 6.6 if K == 30 else None,      # plain fill of the same bytes (tools/readfloor.hip)
-                           "launches_timed": len(sel)}
+    # ---- roofline of the DOMINANT kernel of the evaluation, timed live with HIP events handed to its launch
+    rf = fused_roofline(res, native.MODE_FUSED_FWD,
+                        "alan::normal_lse_mfma_kernel (plate_1 step, the factor F[M,K,K,K] never materialised: per "
+                        "(m, K_mu) a 32x32 tile of log-probs on v_mfma_f32_32x32x2_f32, log-sum-exp over K_z down the "
+                        "accumulator registers, plate sum in a register)")
+    if rf is not None:
+        out["roofline"] = rf
+    else:                                                # FUSE_PLATE_STEP off: the HBM-bound rows kernel dominates
+        res_lse = [(b, m) for mode, b, m in res if mode == native.MODE_LSE]
+        if res_lse:
+            big = max(b for b, _ in res_lse)
+            sel = [m for b, m in res_lse if b == big]
+            ms = sum(sel) / len(sel)
+            out["roofline"] = {"bound": "hbm", "achieved": big / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": big / ms / 1e6 / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic("r1_rows_kernel_pmc.json", "literal_K30_M300"),
+                               "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3, "algorithmic_bytes": big,
+                               "launches_timed": len(sel)}
     if not args.no_extras:
         # BASELINE config C4 in the same run, under the same key at every N: movielens K=100,
-        # Split('plate_1', 38) -- 8 chunks on one GPU, sharded over the ranks (one all-reduce) at N > 1
+        # Split('plate_1', 38) -- one GPU evaluates its chunks as one slice; sharded over the ranks (one all-reduce) at N > 1
         s100 = draw(prob, 100)
         st100 = strategy_for(world, 100)
         try:
@@ -357,12 +385,41 @@ def main():
                                         "n_gpus": world,
                                         "strategy": f"Split('plate_1', {st100.split_size}" +
                                                     (", shard=True)" if world > 1 else ")")}
+            with KernelTimer() as kt100:
+                for _ in range(5):
+                    s100.elbo_nograd(st100)
+                t.cuda.synchronize()
+            rf100 = fused_roofline(kt100.results(), native.MODE_FUSED_FWD, "alan::normal_lse_mfma_kernel at K=100")
+            if rf100 is not None:
+                out["c4_movielens_K100"]["roofline"] = rf100
         except Exception as e:
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
         t.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_extras and not args.c4_only:
-        out["roofline_scaled"] = roofline_scaled(K)
+        # ---- the reduce_Ks kernel proper (rows.hip): what streams a MATERIALISED factor -- literal size and bandwidth regime
+        out["roofline_rows"] = {"literal": rows_roofline(K, M_USERS, traffic_key="literal_K30_M300" if K == 30 else None),
+                                "scaled": rows_roofline(K, M_USERS * 64, traffic_key="scaled_K30_M19200" if K == 30 else None)}
+        # ---- the same evaluation with the factor materialised (dist.FUSE_PLATE_STEP = False)
+        adist.FUSE_PLATE_STEP = False
+        try:
+            sf = draw(prob, K)
+            d_f, v_f = timed_evals(sf, strat, args.steps, args.warmup, world, graph=use_graph)
+            out["materialised_route"] = {"evals_per_s": args.steps / d_f, "us_per_eval": d_f / args.steps * 1e6,
+                                         "elbo": v_f, "default": False,
+                                         "what": "dist.FUSE_PLATE_STEP = False: producer kernel writes F, rows kernel reads it"}
+        finally:
+            adist.FUSE_PLATE_STEP = True
+        # ---- the reference-signature call: sample.elbo_nograd() with no graph argument
+        for _ in range(5):
+            sample.elbo_nograd(strat)
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            sample.elbo_nograd(strat)
+        t.cuda.synchronize()
+        out["plain_call"] = {"us_per_eval": (time.perf_counter() - t0) / 50 * 1e6,
+                             "what": "sample.elbo_nograd(strategy), as the reference spells it"}
         # sample() + elbo per iteration, as examples/basic_runner.py:86-97 of the reference counts it (eager)
         for _ in range(3):
             prob.sample(K, reparam=False).elbo_nograd(strat)
@@ -375,8 +432,7 @@ def main():
         out["sample_plus_elbo"] = {"ms_per_iter": dt_se * 1e3, "iters_per_s": 1 / dt_se,
                                    "launch": "eager (a fresh sample every iteration)"}
         try:                                      # the same iteration captured once (alan_amd.GraphedEval)
-            import alan_amd as _alan
-            ev = _alan.GraphedEval(prob, K, strat)
+            ev = alan.GraphedEval(prob, K, strat)
             for _ in range(3):
                 ev()
             t.cuda.synchronize()
@@ -392,13 +448,12 @@ def main():
         # row a10 (the path's backward) in production use: a whole training iteration -- sample -> elbo_vi | elbo_rws ->
         # backward -> Adam, the loop of examples/basic_runner.py:81-112 -- captured once and replayed
         try:
-            import alan_amd as _alan
             tr = {}
             for mode in ("vi", "rws"):
                 p_tr = build_problem("cuda")
                 params = list(p_tr.parameters()) if mode == "vi" else list(p_tr.Q.parameters())
                 opt = t.optim.Adam(params, lr=1e-2, capturable=True, maximize=(mode == "rws"))
-                step = _alan.GraphedStep(p_tr, K, opt, method=mode)
+                step = alan.GraphedStep(p_tr, K, opt, method=mode)
                 for _ in range(5):
                     step()
                 t.cuda.synchronize()
@@ -408,43 +463,64 @@ def main():
                 t.cuda.synchronize()
                 tr[mode] = {"ms_per_iter": (time.perf_counter() - t0) / 50 * 1e3, "last_elbo": float(v_tr)}
                 del step, opt, p_tr
+            # the fused plate step's backward alone (elbo_vi, eager, HIP events on its launch)
+            p_tr = build_problem("cuda")
+            with KernelTimer() as ktb:
+                for _ in range(5):
+                    for q in p_tr.parameters():
+                        q.grad = None
+                    p_tr.sample(K, reparam=True).elbo_vi(alan.no_checkpoint).backward()
+                t.cuda.synchronize()
+            rfb = fused_roofline(ktb.results(), native.MODE_FUSED_BWD, "alan::normal_lse_bwd_kernel (every gradient of the "
+                                 "plate step in one pass: D recomputed, V and U products on the matrix cores)")
+            if rfb is not None:
+                rfb["algorithmic_flops"] *= 4.2          # D (E + 1 steps) + V and U (32 steps each) per tile
+                rfb["achieved"] *= 4.2
+                rfb["frac"] *= 4.2
+                tr["fused_backward_kernel"] = rfb
+            del p_tr
             out["training_iteration"] = tr
         except Exception as e:
             out["training_iteration"] = {"error": f"{type(e).__name__}: {e}"}
-        # the optional fused plate step (dist.FUSE_PLATE_STEP: producer + log-sum-exp + plate sum in one launch, the
-        # factor never materialised) -- off by default, so `value` and `roofline` above describe the default path
-        from alan_amd import dist as _dist
-        _dist.FUSE_PLATE_STEP = False
-        try:
-            sf = draw(prob, K)
-            d_f, v_f = timed_evals(sf, strat, args.steps, args.warmup, world, graph=use_graph)
-            out["materialised_route"] = {"evals_per_s": args.steps / d_f, "us_per_eval": d_f / args.steps * 1e6,
-                                         "elbo": v_f, "default": False,
-                                         "what": "dist.FUSE_PLATE_STEP = False: producer kernel writes F, rows kernel reads it"}
-        finally:
-            _dist.FUSE_PLATE_STEP = True
         out["cpu_baseline"] = cpu_baseline(K, sample, elbo)
         sweep = {}
         for k2 in (3, 10, 100):
             s2 = draw(prob, k2)
             st2 = strategy_for(world, k2)
-            n2 = 3 if k2 >= 100 else 20
+            n2 = 5 if k2 >= 100 else 20
             d2, _ = timed_evals(s2, st2, n2, 2, world, graph=use_graph)
             sweep[f"K{k2}"] = {"evals_per_s": n2 / d2, "ms_per_eval": d2 / n2 * 1e3,
                                "strategy": type(st2).__name__}
             del s2
             t.cuda.empty_cache()
         out["sweep"] = sweep
-        import alan_amd as alan
+        # ---- S-BUS (C3) and S-TS (C5) at K in {3, 10, 30, 100}; K=30 checked against the CPU oracle
         others = {}
-        for name, builder in (("bus_breakdown Y=2 B=3 I=150 (3 nested plates), K=30", build_bus_problem),
-                              ("timeseries Kalman T=1000, K=30", build_timeseries_problem)):
+        for name, builder, algo in (
+                ("bus_breakdown Y=2 B=3 I=150 (3 nested plates)", build_bus_problem,
+                 lambda k: 4 * (k * k * 900 + 6 * k * k + 4 * k * k + 2 * k)),
+                ("timeseries Kalman T=1000", build_timeseries_problem, lambda k: 4 * 1000 * k * k)):
             p2 = builder("cuda")
-            s2 = draw(p2, 30)
-            d_e, v_e = timed_evals(s2, alan.no_checkpoint, 20, 3, world)
-            d_g, v_g = timed_evals(s2, alan.no_checkpoint, 50, 3, world, graph=True)
-            others[name] = {"evals_per_s_eager": 20 / d_e, "evals_per_s_graph": 50 / d_g,
-                            "us_per_eval_graph": d_g / 50 * 1e6, "elbo": v_g}
+            per_k = {}
+            for k2 in (3, 10, 30, 100):
+                s2 = draw(p2, k2)
+                n_g = 50 if k2 <= 30 else 10
+                d_g, v_g = timed_evals(s2, alan.no_checkpoint, n_g, 3, world, graph=True)
+                us = d_g / n_g * 1e6
+                rec = {"evals_per_s": n_g / d_g, "us_per_eval": us, "elbo": v_g, "algorithmic_bytes": algo(k2),
+                       "hbm_floor_us": algo(k2) / HBM_PEAK_GBS / 1e3}
+                if k2 == 30:
+                    d_e, _ = timed_evals(s2, alan.no_checkpoint, 20, 3, world)
+                    rec["evals_per_s_plain_call"] = 20 / d_e
+                    try:
+                        v_cpu = cpu_elbo_of(builder, s2)
+                        rec["elbo_cpu_oracle"] = v_cpu
+                        rec["elbo_rel_diff_vs_cpu"] = abs(v_cpu - v_g) / abs(v_cpu)
+                    except Exception as e:
+                        rec["elbo_cpu_oracle_error"] = f"{type(e).__name__}: {e}"
+                per_k[f"K{k2}"] = rec
+                del s2
+            others[name] = per_k
         out["other_configs"] = others
     if rank == 0:
         print(json.dumps(out))

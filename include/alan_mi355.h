@@ -139,9 +139,9 @@ int alan_reduce_backward(const alan_backward_desc_t *desc, void *workspace, size
  * log-prob factor): replaces TorchDimDist.py:127-162 + utils.py:147-152 (the Normal log-prob over the K cross
  * product), reduce_Ks.py:249-251 + utils.py:218-220 (log-sum-exp over the child K) and logpq.py:149 (plate sum) for
  *     out[l, s] = sum_m LSE_k( log N(value[m,k,:]; loc[l,:], scale[s,:]) + sum_f small_f[m,k] ) + add_const
- * value / loc / scale are fp32; strides in elements; small factors may have stride 0 along m or k and may be fp64 (the
- * likelihood of fp64 observations: converted on load, the arithmetic is fp32); out may be fp32 or fp64.  scale holds
- * log(scale) when log_scale != 0.  lse_out (optional) receives the per-plate-element values
+ * All tensors fp32; strides in elements; small factors may have stride 0 along m or k (a caller holding an fp64
+ * small factor -- the likelihood of fp64 observations -- converts it first: the kernel's arithmetic is fp32 either way).
+ * scale holds log(scale) when log_scale != 0.  lse_out (optional) receives the per-plate-element values
  * LSE_k(...)[m, l, s], contiguous [M, NL, NS] fp32: what alan_normal_lse_backward needs.  ALAN_ERR_UNSUPPORTED (event
  * length > 32, ...) -> produce the factor with ALAN_MODE_NORMAL and call alan_reduce instead. */
 typedef struct {
@@ -150,12 +150,13 @@ typedef struct {
     const void *scale;  int64_t s_ss, s_se;            /* [NS, E]    */
     int32_t log_scale, n_small;                        /* n_small <= 4 */
     const void *small[4]; int64_t small_sm[4], small_sk[4];   /* [M, NK] each */
-    int32_t small_dtype[4];                            /* alan_dtype_t per small factor */
     int64_t M, NK, NL, NS, E;
     void *out;          int64_t o_sl, o_ss;            /* [NL, NS]   */
-    int32_t out_dtype;                                 /* alan_dtype_t */
     void *lse_out;                                     /* optional [M, NL, NS] fp32 contiguous */
     double add_const;
+    void *ev_start, *ev_stop;                          /* optional hipEvent_t pair (NULL = off) recorded immediately
+                                                          before / after the MFMA kernel of the call (forward, or the
+                                                          backward when the descriptor sits in a backward desc) */
 } alan_normal_lse_desc_t;
 size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
@@ -169,7 +170,7 @@ int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t 
  *     grad_loc[l,e]     = sum_{m,k,s} X *  (value - loc) / scale^2
  *     grad_scale[s,e]   = sum_{m,k,l} X * ((value - loc)^2 / scale^3 - 1 / scale)      (times scale when fwd.log_scale:
  *                                                                                        the gradient wrt log(scale))
- *   fwd         the forward's descriptor (out, o_sl, o_ss, out_dtype, lse_out, add_const are not used)
+ *   fwd         the forward's descriptor (out, o_sl, o_ss, lse_out, add_const are not used)
  *   lse         [M, NL, NS] fp32 contiguous: the forward's lse_out
  *   grad_out    [NL, NS] fp32 with element strides (g_sl, g_ss)
  *   grad_*      fp32, contiguous, any of them NULL = not wanted

@@ -395,3 +395,52 @@ def test_all_fp64_problem_matches_the_reference_more_closely(fixture, model):
     assert got.dtype == t.float64
     assert abs(float(got) - ref) <= 2e-7 * abs(ref) + 1e-6, (float(got), ref)
     assert float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) == float(got)
+
+
+@pytest.mark.gpu
+def test_plain_elbo_nograd_calls_promote_to_a_replayed_graph():
+    """``sample.elbo_nograd(strategy)`` with no graph argument (the reference's spelling, Sample.py:135-148): the first
+    call launches kernel by kernel, the second captures, later ones replay -- same value, in-place parameter updates
+    seen, ``graph=False`` stays eager, and moving / re-typing the problem's tensors starts over."""
+    from alan_amd import sample as S
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda")
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+    ref = float(fx["elbo"]["no_checkpoint"])
+    vals = [float(sample.elbo_nograd(alan.no_checkpoint)) for _ in range(4)]
+    assert all(abs(v - ref) <= 1e-4 * abs(ref) for v in vals)
+    assert vals[2] == vals[3]
+    graphs = [g for g in sample._auto.values() if isinstance(g, S._GraphedELBO)]
+    assert len(graphs) == 1
+    eager = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert abs(eager - vals[3]) <= 1e-6 * abs(eager)
+    with t.no_grad():
+        for p in prob.Q.parameters():
+            p.add_(0.05)
+    moved = float(sample.elbo_nograd(alan.no_checkpoint))                          # replay: sees the update
+    moved_eager = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert abs(moved - eager) > 1e-3 * abs(eager) and abs(moved - moved_eager) <= 1e-6 * abs(moved_eager)
+    # another strategy = another key (first call eager again)
+    n = len(sample._auto)
+    sample.elbo_nograd(alan.Split("plate_1", 38))
+    assert len(sample._auto) == n + 1
+    # re-typed problem: the old graph reads dead memory -- it must not be used
+    prob.double()
+    key_before = set(sample._auto)
+    sample.elbo_nograd(alan.no_checkpoint)
+    assert len(set(sample._auto) - key_before) == 1
+
+
+@pytest.mark.gpu
+def test_plain_elbo_nograd_stays_eager_when_the_evaluation_cannot_be_captured():
+    """MultivariateNormal.log_prob synchronises with the host: capture fails, the call quietly stays eager."""
+    small = load_golden("e2e_small_models.pt")
+    name = next(n for n in sorted(small) if "multivariate" in n)
+    fx = small[name]
+    prob = models.small_model(name, fx).to("cuda")
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+    ref = float(fx["elbo"]["no_checkpoint"])
+    for _ in range(4):
+        v = float(sample.elbo_nograd(alan.no_checkpoint))
+        assert abs(v - ref) <= 1e-4 * abs(ref) + 1e-5
+    assert list(sample._auto.values()) == [False]

@@ -48,7 +48,7 @@ def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
 def test_fused_plate_step_struct_layout_and_rejections():
     """alan_normal_lse_desc_t / alan_normal_lse_backward_desc_t as the header lays them out (natural alignment), and
     malformed descriptors refused before any GPU work."""
-    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 4 * 4 + 5 * 8 + 8 + 2 * 8 + 4 + 4 + 8 + 8
+    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8
     assert ctypes.sizeof(N.NormalLseDesc) == fwd
     assert ctypes.sizeof(N.NormalLseBackwardDesc) == fwd + 8 + 8 + 2 * 8 + 4 * 8
     L = N.lib()
@@ -71,8 +71,8 @@ def test_fused_plate_step_struct_layout_and_rejections():
     assert L.alan_normal_lse_workspace_bytes(ctypes.byref(d)) > 0
     assert L.alan_normal_lse_backward_workspace_bytes(ctypes.byref(b)) > 0
     assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 16, None) == -3         # workspace too small
-    b.fwd.small_dtype[0], b.fwd.n_small, b.fwd.small[0] = 7, 1, dummy
-    assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 1 << 20, None) == -1    # bad small-factor dtype
+    b.fwd.n_small = 5
+    assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 1 << 20, None) == -1    # too many small factors
 
 
 def test_bad_descriptors_are_rejected_without_touching_the_gpu():
