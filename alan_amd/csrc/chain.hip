@@ -334,6 +334,167 @@ __global__ __launch_bounds__(TREE_THREADS) void chain_tree_kernel(
     }
 }
 
+// One product of the tree for 32 < K <= 128 (fp32) with the K x K x K contraction on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact k-ordered fp32 fmaf chains, the arithmetic of the vector loop).  What the matrix
+// instruction buys here is LDS traffic, not FLOPs (fp32 MFMA runs at the vector rate): the 1x4 register tiles of
+// chain_segment_kernel read 5 x 16 bytes per 16 FMAs -- 5.2 MB through the LDS per K = 100 product, 20 us of a 40 us
+// workgroup -- the 32x32 tiles read 8 bytes per 4096 FMAs.  A workgroup of KT*KT/NTW waves takes one pair (P, C);
+// a wave owns NTW output tiles of one tile row: per four k values one 16-byte read of its P rows (shared by its
+// tiles) and four dword reads per tile down C's rows, then four MFMAs per tile (lane half h takes k = 4q + h and
+// 4q + 2 + h: the order of k inside a step is free as long as A and B agree).
+// Same normalisation, eps and bracketing as utils.py:503-507; an odd leftover passes through (utils.py:488-495).
+typedef float chain_f32x16 __attribute__((ext_vector_type(16)));
+typedef float chain_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KT, int NTW>
+__global__ __launch_bounds__(64 * KT * KT / NTW) void chain_pair_mfma_kernel(
+    const float *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_src, int K,
+    float *out, float *vec_out, const ChainAdd<float> ad) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int KP = 32 * KT, S = KP + 4, NTH = 64 * KT * KT / NTW;
+    float *Pe = reinterpret_cast<float *>(smem_raw);      // [KP][S]  log-space, then exp-space, then the result R
+    float *Ce = Pe + KP * S;                              // [KP][S]
+    float *pm = Ce + KP * S, *cm = pm + KP;               // row maxima of P, column maxima of C
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.y, node = blockIdx.x;
+    const int t0 = 2 * (int)node, t1 = t0 + 1, KK = K * K;
+    const float NINF = -__builtin_huge_valf();
+    ms += b * sB;
+    float *o = out ? out + (b * gridDim.x + node) * (int64_t)KK : nullptr;
+    const bool pair = t1 < n_src;
+
+    for (int i = tid; i < 2 * KP; i += NTH) pm[i] = NINF;
+    __syncthreads();
+    // A wave per row, lanes across the columns (coalesced): P's row maximum by a wave reduction, C's column maxima
+    // kept per lane over the wave's rows and merged across the waves at the end.  Every load of the wave is issued
+    // before the first one is used: a product is a chain of dependent launches reading what the previous one wrote,
+    // and a loop of load -> reduce -> next row pays that latency a dozen times.
+    {
+        constexpr int NW = NTH / 64, NC = KP / 64, RPW = KP / NW;
+        float pv[RPW][NC], cv[RPW][NC];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int i = wave + NW * rr;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int jj = lane + 64 * c;
+                const bool in = i < K && jj < K;
+                const int ic = min(i, K - 1), jc = min(jj, K - 1);
+                pv[rr][c] = chain_in(ms, (int64_t)t0 * sT + ic * sRow + jc * sCol, ad, b, (int64_t)t0, ic, jc);
+                cv[rr][c] = pair ? chain_in(ms, (int64_t)t1 * sT + ic * sRow + jc * sCol, ad, b, (int64_t)t1, ic, jc) : NINF;
+                if (!in) pv[rr][c] = NINF, cv[rr][c] = NINF;
+            }
+        }
+        float cmax[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cmax[c] = NINF;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int i = wave + NW * rr;
+            float rmax = NINF;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int jj = lane + 64 * c;
+                if (i < K && jj < K) {
+                    Pe[i * S + jj] = pv[rr][c];
+                    if (pair) Ce[i * S + jj] = cv[rr][c];
+                }
+                rmax = fmaxf(rmax, pv[rr][c]);
+                cmax[c] = fmaxf(cmax[c], cv[rr][c]);
+            }
+#pragma unroll
+            for (int o_ = 32; o_ >= 1; o_ >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o_));
+            if (lane == 0 && i < K) pm[i] = rmax;
+        }
+        if (pair) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (lane + 64 * c < K) lds_max(&cm[lane + 64 * c], cmax[c]);
+        }
+    }
+    __syncthreads();
+    if (pair) {
+        for (int e = tid; e < KP * KP; e += NTH) {        // utils.py:503-505, pads -> 0
+            const int i = e / KP, jj = e - i * KP;
+            const bool in = i < K && jj < K;
+            Pe[i * S + jj] = in ? Num<float>::exp(Pe[i * S + jj] - pm[i]) : 0.f;
+            Ce[i * S + jj] = in ? Num<float>::exp(Ce[i * S + jj] - cm[jj]) : 0.f;
+        }
+        __syncthreads();
+        const int tr = (wave * NTW) / KT, tc0 = (wave * NTW) - tr * KT;
+        chain_f32x16 acc[NTW];
+#pragma unroll
+        for (int q = 0; q < NTW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        const float *prow = Pe + (32 * tr + j) * S;
+        const int nq4 = (K + 3) >> 2;
+        for (int q4 = 0; q4 < nq4; ++q4) {
+            const chain_f32x4 a4 = *reinterpret_cast<const chain_f32x4 *>(prow + 4 * q4);
+            const float a_lo = h ? a4[1] : a4[0], a_hi = h ? a4[3] : a4[2];
+            const float *c_lo = Ce + (4 * q4 + h) * S + 32 * tc0 + j, *c_hi = c_lo + 2 * S;
+#pragma unroll
+            for (int q = 0; q < NTW; ++q) {
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, c_lo[32 * q], acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, c_hi[32 * q], acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading Pe / Ce: R goes into Pe
+        // ---- R = log(Pe @ Ce + eps) + pm + cm (utils.py:506-507)
+#pragma unroll
+        for (int q = 0; q < NTW; ++q) {
+            const int col = 32 * (tc0 + q) + j;
+            const float cmj = col < K ? cm[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * tr + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < K && col < K) {
+                    const float v = Num<float>::log(acc[q][r] + Num<float>::eps) + pm[row] + cmj;
+                    Pe[row * S + col] = v;
+                    if (o) o[row * K + col] = v;
+                }
+            }
+        }
+    } else if (o) {                                        // the leftover of this round passes through
+        for (int e = tid; e < KK; e += NTH) o[e] = Pe[(e / K) * S + (e % K)];
+    }
+    if (vec_out) {                                         // torch.logsumexp(lp, -1)  (logpq.py:139): no eps
+        __syncthreads();
+        for (int i = tid; i < K; i += NTH) {
+            float mx = NINF;
+            for (int jj = 0; jj < K; ++jj) mx = fmaxf(mx, Pe[i * S + jj]);
+            float sum = 0.f;
+            const float mref = (mx == NINF || mx == -NINF) ? 0.f : mx;
+            for (int jj = 0; jj < K; ++jj) sum += Num<float>::exp(Pe[i * S + jj] - mref);
+            vec_out[b * K + i] = Num<float>::log(sum) + mref;
+        }
+    }
+}
+
+// (the launcher of the kernel above: fp32 only)
+template <typename T>
+static int launch_pair_mfma(int64_t, uint32_t, uint32_t, hipStream_t, const T *, int64_t, int64_t, int64_t, int64_t, int,
+                            T *, T *, const ChainAdd<T> &) {
+    return ALAN_ERR_UNSUPPORTED;
+}
+template <>
+int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t stream, const float *src, int64_t cB,
+                            int64_t cT, int64_t cR, int64_t cC, int n_src, float *dst, float *vec_out,
+                            const ChainAdd<float> &ad) {
+    if (K <= 32 || K > 128) return ALAN_ERR_UNSUPPORTED;
+    const int kt = K <= 64 ? 2 : 4;
+    const size_t smem = (size_t)(2 * 32 * kt * (32 * kt + 4) + 2 * 32 * kt) * sizeof(float);
+    auto go = [&](auto kern, int threads) {
+        if (smem > 64 * 1024)
+            if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                return ALAN_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(n_out, B), dim3(threads), smem, stream, src, cB, cT, cR, cC, n_src, (int)K, dst,
+                           vec_out, ad);
+        return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+    };
+    return kt == 2 ? go(chain_pair_mfma_kernel<2, 1>, 256) : go(chain_pair_mfma_kernel<4, 2>, 512);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The tree in memory: round r = 1..L holds n_r = ceil(n_{r-1} / 2) matrices per chain ([B][n_r][K][K], each round
 // 256-byte aligned), n_0 = T, n_L = 1 (the root = chain_logmmexp(ms)); T = 1 has one round holding a copy of ms[0].
@@ -385,7 +546,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
     if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
     const T *src = (const T *)ms_;
     int64_t cB = sB, cT = sT, cR = sRow, cC = sCol;
-    static const bool per_round = getenv("ALAN_CHAIN_PER_ROUND") != nullptr;      // ablation: one round per launch
+    static const bool per_round = env_knob("ALAN_CHAIN_PER_ROUND") != ENV_UNSET;  // ablation: one round per launch
     if (K <= 32 && !per_round) {
         const size_t slot = (KP * (KP + 4) + KP * KP + 2 * KP) * sizeof(T);
         auto tk = chain_tree_kernel<T>;
@@ -410,12 +571,20 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             cC = 1;
         }
     } else {
+        static const bool no_mfma = env_knob("ALAN_CHAIN_MFMA") == 0;                 // ablation: vector-unit products
         for (int r = 1; r <= tl.L; ++r) {
             T *dst = (T *)((char *)ws + tl.off[r]);
-            hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
-                               cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr,
-                               r == 1 ? ad0 : none);
-            if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            int rc = no_mfma ? (int)ALAN_ERR_UNSUPPORTED
+                             : launch_pair_mfma<T>(K, (uint32_t)tl.n[r], (uint32_t)B, stream, src, cB, cT, cR, cC,
+                                                   (int)tl.n[r - 1], dst, r == tl.L ? (T *)out_vec : (T *)nullptr,
+                                                   r == 1 ? ad0 : none);
+            if (rc == ALAN_ERR_LAUNCH) return rc;
+            if (rc == ALAN_ERR_UNSUPPORTED) {
+                hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
+                                   cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr,
+                                   r == 1 ? ad0 : none);
+                if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            }
             src = dst;
             cB = tl.n[r] * K * K;
             cT = K * K;

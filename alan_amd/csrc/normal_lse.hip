@@ -99,11 +99,16 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     float *tile = lds + wave * (32 * 33);
     uint32_t soff[NX];                                // STAGE: LDS slot of float lane + 64 q: row * (E + 1) + column
     if (STAGE) {
-        for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;        // rows beyond NK are never written: keep them finite
+        if (NK & 31)                                  // rows beyond NK are never written: keep them finite
+            for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;
+        // (row, column) of float lane + 64 q, stepped by 64 floats = (64 / E) rows + (64 % E) columns: one division
+        const int r64 = 64 / E, c64 = 64 - r64 * E;
+        int row = lane / E, col = lane - row * E;
 #pragma unroll
         for (int qq = 0; qq < NX; ++qq) {
-            const int i = lane + 64 * qq, row = i / E;
-            soff[qq] = i < 32 * E ? row * (E + 1) + (i - row * E) : 32 * 33 - 1;      // (a slot nobody reads)
+            soff[qq] = row < 32 ? row * (E + 1) + col : 32 * 33 - 1;                    // (beyond: a slot nobody reads)
+            row += r64, col += c64;
+            if (col >= E) col -= E, ++row;
         }
     }
     const uint32_t row_off = (uint32_t)j * (uint32_t)d.v_sk;               // !STAGE: this lane's row inside a tile

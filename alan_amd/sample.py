@@ -40,10 +40,12 @@ class _GraphedELBO:
                     sample._elbo(sample._pt_detached, None, strategy)
             t.cuda.current_stream().wait_stream(side)
             t.cuda.synchronize()
-            self.graph = t.cuda.CUDAGraph()
+            self.graph = t.cuda.CUDAGraph(keep_graph=True)
             # thread_local: a collective's watchdog thread must not invalidate the capture
             with t.cuda.graph(self.graph, capture_error_mode="thread_local"), t.no_grad():
                 self.out = sample._elbo(sample._pt_detached, None, strategy)
+            from .training import check_no_memset_nodes
+            check_no_memset_nodes(self.graph, "Sample.elbo_nograd(graph=True)")
         finally:
             N._TIMER[0] = timer
 
@@ -169,16 +171,18 @@ class Sample:
             if graph:
                 return self._graphed(computation_strategy)()
             if graph is None and AUTO_GRAPH:
-                g = self._auto_graphed(computation_strategy)
-                if g is not None:
-                    return g()
+                val = self._auto_eval(computation_strategy)
+                if val is not None:
+                    return val
         with t.no_grad():
             return self._elbo(self._pt_detached, None, computation_strategy)
 
-    def _auto_graphed(self, computation_strategy):
-        """The captured evaluation for an unadorned ``elbo_nograd()`` call, or None (first call under this key; an
-        evaluation that cannot be captured -- e.g. MultivariateNormal.log_prob synchronises --; timing / capture in
-        progress)."""
+    def _auto_eval(self, computation_strategy):
+        """An unadorned ``elbo_nograd()`` call: the first one under a key runs kernel by kernel and watches for host
+        synchronisations (an evaluation that synchronises -- e.g. MultivariateNormal.log_prob -- cannot be captured and
+        stays eager for good), the second captures, later ones replay.  None: not handled here (timing in progress,
+        inside someone else's capture, not capturable)."""
+        import warnings
         from . import native as N
         if N._TIMER[0] is not None or t.cuda.is_current_stream_capturing():
             return None
@@ -186,18 +190,27 @@ class Sample:
         state = self.__dict__.setdefault("_auto", {})
         g = state.get(key)
         if g is None:
-            state[key] = "seen"                 # this call runs eagerly; the next one captures
-            return None
+            if len(state) >= 8:
+                state.clear()
+            mode = t.cuda.get_sync_debug_mode()
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                t.cuda.set_sync_debug_mode("warn")
+                try:
+                    with t.no_grad():
+                        val = self._elbo(self._pt_detached, None, computation_strategy)
+                finally:
+                    t.cuda.set_sync_debug_mode(mode)
+            synced = any("synchroniz" in str(w.message).lower() for w in seen)
+            state[key] = False if synced else "seen"
+            return val
         if g == "seen":
             try:
                 g = _GraphedELBO(self, computation_strategy)
             except Exception:
-                g = False                       # not capturable: stay eager for this key
-                t.cuda.synchronize()
-            if len(state) > 8:
-                state.clear()
+                g = False                       # not capturable after all: stay eager for this key
             state[key] = g
-        return g or None
+        return g() if g else None
 
     def _graph_key(self, computation_strategy):
         from . import dist as D

@@ -7,9 +7,53 @@ later iteration is one graph launch: fresh particles are drawn each replay (PyTo
 generator's Philox state with the graph), the forward and backward alan_reduce launches, the fused
 producers and the optimizer update all replay on the device.
 """
+import ctypes as C
+import warnings
+
 import torch as t
 
 from .split import no_checkpoint
+
+
+class GraphContainsMemsetNodes(RuntimeError):
+    pass
+
+
+def memset_nodes(graph):
+    """Number of memset nodes in a captured graph (``torch.cuda.CUDAGraph(keep_graph=True)``), or None when the handle
+    cannot be inspected.  On this ROCm a replay that starts on an idle GPU mis-executes torch's multi-block
+    reductions, whose semaphore buffer is cleared by a hipMemsetAsync captured as a memset node -- the ONLY structural
+    difference between failing and passing graphs (tools/graph_race_probe.py: one linear chain either way; the
+    reduction is wrong when the host synchronises between replays, right back to back).  alan_amd's own kernels never
+    need one; a captured graph holding any is refused (GraphedStep / GraphedEval) or not used (Sample.elbo_nograd)."""
+    try:
+        raw = graph.raw_cuda_graph()
+        hip = C.CDLL("libamdhip64.so")
+        n = C.c_size_t(0)
+        if hip.hipGraphGetNodes(C.c_void_p(raw), None, C.byref(n)) != 0:
+            return None
+        nodes = (C.c_void_p * max(1, n.value))()
+        hip.hipGraphGetNodes(C.c_void_p(raw), nodes, C.byref(n))
+        count = 0
+        for nd in nodes[: n.value]:
+            ty = C.c_int(-1)
+            hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(ty))
+            count += ty.value == 2                      # hipGraphNodeTypeMemset
+        return count
+    except Exception:
+        return None
+
+
+def check_no_memset_nodes(graph, what, allow=False):
+    n = memset_nodes(graph)
+    if n:
+        msg = (f"{what}: the captured HIP graph holds {n} memset node(s) -- a torch multi-block reduction (a sum over a "
+               "long leading dim in a model lambda or a non-fused distribution's log_prob?).  Replays that start on an "
+               "idle GPU compute such reductions wrongly on this ROCm (DESIGN.md, graph replay and memset nodes).")
+        if not allow:
+            raise GraphContainsMemsetNodes(msg)
+        warnings.warn(msg)
+    return n
 
 
 class GraphedStep:
@@ -20,7 +64,10 @@ class GraphedStep:
     reference's runner, "rws" expects an optimizer over ``problem.Q.parameters()`` built with
     ``maximize=True`` (the loss is ``-elbo`` for both methods)."""
 
-    def __init__(self, problem, K, optimizer, method="vi", computation_strategy=no_checkpoint, warmup=3):
+    def __init__(self, problem, K, optimizer, method="vi", computation_strategy=no_checkpoint, warmup=3,
+                 capture_stream=None, allow_memset_nodes=False):
+        """``capture_stream``: diagnostics (tools/graph_race_probe.py) -- capture on another stream than the warm-up
+        one.  ``allow_memset_nodes``: only warn about memset nodes in the captured graph (see ``memset_nodes``)."""
         if method not in ("vi", "rws"):
             raise Exception("method must be 'vi' or 'rws'")
         if problem.device.type != "cuda":
@@ -34,13 +81,15 @@ class GraphedStep:
                 self._iteration()
         t.cuda.current_stream().wait_stream(side)
         t.cuda.synchronize()
-        self.graph = t.cuda.CUDAGraph()
+        self.graph = t.cuda.CUDAGraph(keep_graph=True)
         self.opt.zero_grad(set_to_none=True)
         # Capture on the SAME stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it
         # was first used on and autograd runs it there; a different capture stream would put the gradient
         # accumulation on a parallel branch of the graph (PyTorch warns "AccumulateGrad node's stream does not match").
-        with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+        with t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
+                          capture_error_mode="thread_local"):
             self.elbo = self._iteration()
+        self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedStep", allow_memset_nodes)
 
     def _iteration(self):
         self.opt.zero_grad(set_to_none=True)
@@ -74,9 +123,10 @@ class GraphedEval:
                 self._iteration()
         t.cuda.current_stream().wait_stream(side)
         t.cuda.synchronize()
-        self.graph = t.cuda.CUDAGraph()
+        self.graph = t.cuda.CUDAGraph(keep_graph=True)
         with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.elbo = self._iteration()
+        self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedEval")
 
     def _iteration(self):
         with t.no_grad():

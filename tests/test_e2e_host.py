@@ -222,6 +222,39 @@ def test_graphed_vi_step_does_not_depend_on_host_synchronisation():
 
 
 @pytest.mark.gpu
+def test_captured_graphs_hold_no_memset_nodes_and_one_that_does_is_refused(monkeypatch):
+    """The root cause of the symptom above (tools/graph_race_probe.py): a torch multi-block reduction clears its
+    semaphores with a hipMemsetAsync, captured as a memset node; a replay that starts on an idle GPU then computes the
+    reduction wrongly.  The captured graphs of the bench models hold none; a graph that does is refused at capture."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from alan_amd import dist as D, training as TR
+    prob = bench.build_problem("cuda")
+    for method in ("vi", "rws"):
+        opt = t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True, maximize=(method == "rws"))
+        assert alan.GraphedStep(prob, 30, opt, method=method).n_memset_nodes == 0
+    assert alan.GraphedEval(prob, 30).n_memset_nodes == 0
+    # the materialised route's producer backward with ONE long torch reduction put back
+    monkeypatch.setattr(D, "FUSE_PLATE_STEP", False)
+    monkeypatch.setattr(D, "_sum_leading", lambda x, blk=64: x.sum(0))
+    real = D._FusedNormalLogProb._backward_outer
+
+    def with_long_sum(ctx, G, *a):
+        out = real(ctx, G, *a)
+        G.reshape(-1, G.shape[-1]).sum(0)                  # [270000, 30] -> [30]: multi-block, semaphore memset
+        return out
+
+    monkeypatch.setattr(D._FusedNormalLogProb, "_backward_outer", staticmethod(with_long_sum))
+    prob2 = bench.build_problem("cuda")
+    opt = t.optim.Adam(prob2.parameters(), lr=1e-2, capturable=True)
+    with pytest.raises(TR.GraphContainsMemsetNodes):
+        alan.GraphedStep(prob2, 30, opt, method="vi")
+    step = alan.GraphedStep(prob2, 30, opt, method="vi", allow_memset_nodes=True)
+    assert step.n_memset_nodes >= 1
+
+
+@pytest.mark.gpu
 def test_graphed_eval_draws_fresh_particles_and_agrees_with_eager_in_distribution():
     """GraphedEval = sample() + elbo_nograd() per replay (basic_runner.py:86-97 of the reference): every replay sees new
     particles; its mean agrees with the mean of eagerly drawn evaluations."""
@@ -412,6 +445,7 @@ def test_plain_elbo_nograd_calls_promote_to_a_replayed_graph():
     assert vals[2] == vals[3]
     graphs = [g for g in sample._auto.values() if isinstance(g, S._GraphedELBO)]
     assert len(graphs) == 1
+    assert t.cuda.get_sync_debug_mode() == 0
     eager = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
     assert abs(eager - vals[3]) <= 1e-6 * abs(eager)
     with t.no_grad():
@@ -424,8 +458,9 @@ def test_plain_elbo_nograd_calls_promote_to_a_replayed_graph():
     n = len(sample._auto)
     sample.elbo_nograd(alan.Split("plate_1", 38))
     assert len(sample._auto) == n + 1
-    # re-typed problem: the old graph reads dead memory -- it must not be used
+    # re-created tensors (here: a round trip through fp64): the old graph reads dead memory -- it must not be used
     prob.double()
+    prob.float()
     key_before = set(sample._auto)
     sample.elbo_nograd(alan.no_checkpoint)
     assert len(set(sample._auto) - key_before) == 1

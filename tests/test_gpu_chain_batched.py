@@ -25,7 +25,9 @@ def _oracle(ms):
     return t.logsumexp(chain, -1), chain
 
 
-SHAPES = [(1, 1, 3), (3, 2, 3), (5, 7, 3), (4, 50, 30), (700, 9, 10), (2, 33, 40), (3, 12, 100), (2500, 4, 30)]
+# (K in 33..100, fp32: the matrix-core pair kernel, 2x2 and 4x4 tiles with ragged edges; an odd leftover per round)
+SHAPES = [(1, 1, 3), (3, 2, 3), (5, 7, 3), (4, 50, 30), (700, 9, 10), (2, 33, 40), (3, 12, 100), (2500, 4, 30),
+          (2, 9, 33), (1, 17, 64), (2, 5, 65), (1, 1, 70), (3, 3, 97)]
 
 
 @pytest.mark.parametrize("B,T,K", SHAPES, ids=[f"B{b}_T{T}_K{k}" for b, T, k in SHAPES])
@@ -106,3 +108,13 @@ def test_chain_of_terms_adds_the_factors_on_load(B, T, K, dtype):
         t.testing.assert_close(got.cpu().double(), want, **kw)
     one, _, _ = N.chain_logmmexp(a)
     assert t.equal(N.chain_logmmexp_terms([a]), one)                       # one term = the plain entry point
+
+
+def test_chain_terms_are_added_on_load_by_the_matrix_core_kernel_too():
+    """alan_chain_logmmexp_terms at K = 50 (2x2 tiles): the plate's factors, one with a broadcast K_init dim, are summed
+    by the first round as it loads."""
+    B, T, K = 2, 21, 50
+    a, b3 = _ms(B, T, K, t.float32, 1), _ms(B, T, K, t.float32, 2)[:, :, :1, :]
+    want, _ = _oracle(a + b3)
+    vec = N.chain_logmmexp_terms([a.to(DEV), b3.to(DEV).expand(B, T, K, K)])
+    t.testing.assert_close(vec.cpu().double(), want, rtol=2e-5, atol=2e-4)
