@@ -201,14 +201,20 @@ class Sample:
                         val = self._elbo(self._pt_detached, None, computation_strategy)
                 finally:
                     t.cuda.set_sync_debug_mode(mode)
-            synced = any("synchroniz" in str(w.message).lower() for w in seen)
+            # ("called a synchronizing CUDA operation"; set_sync_debug_mode's own one-off "prototype feature" notice
+            # also speaks of synchronizing operations)
+            synced = [str(w.message) for w in seen if "synchroniz" in str(w.message).lower()
+                      and "prototype feature" not in str(w.message)]
             state[key] = False if synced else "seen"
+            if synced:
+                self.__dict__.setdefault("_auto_why", {})[key] = "synchronises: " + synced[0][:200]
             return val
         if g == "seen":
             try:
                 g = _GraphedELBO(self, computation_strategy)
-            except Exception:
+            except Exception as e:
                 g = False                       # not capturable after all: stay eager for this key
+                self.__dict__.setdefault("_auto_why", {})[key] = f"capture failed: {type(e).__name__}: {e}"[:300]
             state[key] = g
         return g() if g else None
 

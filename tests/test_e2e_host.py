@@ -479,3 +479,5 @@ def test_plain_elbo_nograd_stays_eager_when_the_evaluation_cannot_be_captured():
         v = float(sample.elbo_nograd(alan.no_checkpoint))
         assert abs(v - ref) <= 1e-4 * abs(ref) + 1e-5
     assert list(sample._auto.values()) == [False]
+    # (found by the synchronisation watch of the first call, not by a failed capture)
+    assert all(w.startswith("synchronises") for w in sample._auto_why.values()), sample._auto_why
