@@ -210,10 +210,23 @@ def pmc_traffic(name, key):
         return None
 
 
+def fused_pmc_traffic(K, backward=False):
+    """The same for the fused plate step at the S-ML sizes profiles/r2_fused_kernel_pmc.json covers (M=300, K=30 / 100)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r2_fused_kernel_pmc.json")))["kernels"]
+        want = 4 * M_USERS * K ** 3
+        for name, rec in d.items():
+            if ("bwd" in name) == backward and rec["factor_bytes_never_materialised"] == want:
+                return rec["traffic_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate
 
 
-def fused_roofline(records, tag, what):
+def fused_roofline(records, tag, what, traffic=None):
     """roofline object of the fused plate step from KernelTimer records (native.MODE_FUSED_*): algorithmic FLOPs of
     the tile GEMM (2 * M * K^3 * (E + 1)) over the MFMA kernel's own duration."""
     sel = [(f, ms) for mode, f, ms in records if mode == tag]
@@ -224,7 +237,7 @@ def fused_roofline(records, tag, what):
     ms = sum(ts) / len(ts)
     tf = flops / ms / 1e9
     return {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-            "traffic": None, "kernel": what, "us_per_launch": ms * 1e3, "algorithmic_flops": flops,
+            "traffic": traffic, "kernel": what, "us_per_launch": ms * 1e3, "algorithmic_flops": flops,
             "launches_timed": len(ts),
             "note": "fp32 MFMA results are consumed by the vector unit (one exp per element) and on gfx950 the two do not "
                     "overlap: tools/mfma_f32_probe.hip measures 0.60 of peak for a bare chain-of-10-MFMAs + "
@@ -252,7 +265,7 @@ def rows_roofline(K, M, iters=20, traffic_key=None):
     ms = sum(m for _, _, m in res) / len(res)
     gbs = algo / ms / 1e6
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("r1_rows_kernel_pmc.json", traffic_key) if traffic_key else None,
+            "traffic": pmc_traffic("r2_rows_kernel_pmc.json", traffic_key) if traffic_key else None,
             "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3, "algorithmic_bytes": algo,
             "workload": f"S-ML plate step on a materialised factor, K={K}, M={M}"}
 
@@ -360,7 +373,8 @@ def main():
     rf = fused_roofline(res, native.MODE_FUSED_FWD,
                         "alan::normal_lse_mfma_kernel (plate_1 step, the factor F[M,K,K,K] never materialised: per "
                         "(m, K_mu) a 32x32 tile of log-probs on v_mfma_f32_32x32x2_f32, log-sum-exp over K_z down the "
-                        "accumulator registers, plate sum in a register)")
+                        "accumulator registers, plate sum in a register)",
+                        traffic=fused_pmc_traffic(K) if world == 1 else None)
     if rf is not None:
         out["roofline"] = rf
     else:                                                # FUSE_PLATE_STEP off: the HBM-bound rows kernel dominates
@@ -371,7 +385,7 @@ def main():
             ms = sum(sel) / len(sel)
             out["roofline"] = {"bound": "hbm", "achieved": big / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": big / ms / 1e6 / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic("r1_rows_kernel_pmc.json", "literal_K30_M300"),
+                               "traffic": pmc_traffic("r2_rows_kernel_pmc.json", "literal_K30_M300"),
                                "kernel": "alan::rows_kernel", "us_per_launch": ms * 1e3, "algorithmic_bytes": big,
                                "launches_timed": len(sel)}
     if not args.no_extras:
@@ -389,7 +403,8 @@ def main():
                 for _ in range(5):
                     s100.elbo_nograd(st100)
                 t.cuda.synchronize()
-            rf100 = fused_roofline(kt100.results(), native.MODE_FUSED_FWD, "alan::normal_lse_mfma_kernel at K=100")
+            rf100 = fused_roofline(kt100.results(), native.MODE_FUSED_FWD, "alan::normal_lse_mfma_kernel at K=100",
+                                   traffic=fused_pmc_traffic(100) if world == 1 else None)
             if rf100 is not None:
                 out["c4_movielens_K100"]["roofline"] = rf100
         except Exception as e:
@@ -472,7 +487,8 @@ def main():
                     p_tr.sample(K, reparam=True).elbo_vi(alan.no_checkpoint).backward()
                 t.cuda.synchronize()
             rfb = fused_roofline(ktb.results(), native.MODE_FUSED_BWD, "alan::normal_lse_bwd_kernel (every gradient of the "
-                                 "plate step in one pass: D recomputed, V and U products on the matrix cores)")
+                                 "plate step in one pass: D recomputed, V and U products on the matrix cores)",
+                                 traffic=fused_pmc_traffic(K, backward=True))
             if rfb is not None:
                 rfb["algorithmic_flops"] *= 4.2          # D (E + 1 steps) + V and U (32 steps each) per tile
                 rfb["achieved"] *= 4.2
