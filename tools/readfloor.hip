@@ -92,6 +92,33 @@ int main() {
                    bytes / 1e6, blocks, u1, bytes / u1 / 1e3, u4, bytes / u4 / 1e3, u8, bytes / u8 / 1e3);
             fflush(stdout);
         }
+        // the same read inside a replayed HIP graph, 20 launches back to back (how the kernels of a captured ELBO
+        // evaluation run: no idle gap, no per-launch host work): time per launch = replay time / 20
+        if (bytes < 100000000) {
+            for (int blocks : {600, 1200, 2048}) {
+                hipGraph_t g;
+                hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(read_kernel<4>, dim3(blocks), dim3(256), 0, s, p, n4, out);
+                CK(hipStreamEndCapture(s, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+                CK(hipStreamSynchronize(s));
+                hipEvent_t a, b2;
+                CK(hipEventCreate(&a));
+                CK(hipEventCreate(&b2));
+                CK(hipEventRecord(a, s));
+                for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(ge, s));
+                CK(hipEventRecord(b2, s));
+                CK(hipEventSynchronize(b2));
+                float ms;
+                CK(hipEventElapsedTime(&ms, a, b2));
+                printf("%8.1f MB read inside a replayed graph, blocks=%5d unr4: %8.2f us per launch %7.0f GB/s\n", bytes / 1e6,
+                       blocks, ms * 1e3f / 200, bytes / (ms * 1e3f / 200) / 1e3);
+                CK(hipGraphExecDestroy(ge));
+                CK(hipGraphDestroy(g));
+            }
+        }
         // write floor: a plain 16-byte-per-lane fill of the same buffer (what the factor PRODUCER is bounded by)
         for (int blocks : {1024, 2048, 4096, 8192}) {
             const float uw = time_us([&](hipEvent_t a, hipEvent_t b) {
