@@ -138,6 +138,13 @@ def lib():
         L.alan_chain_logmmexp_backward_batched.restype = C.c_int
         L.alan_chain_logmmexp_backward_batched.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 7),
                                                            *([C.c_void_p] * 6), C.c_size_t, C.c_void_p]
+        L.alan_chain_messages.restype = C.c_int
+        L.alan_chain_messages.argtypes = [C.c_void_p, *([C.c_int64] * 7), C.c_void_p, C.c_void_p]
+        L.alan_chain_sample.restype = C.c_int
+        L.alan_chain_sample.argtypes = [C.c_void_p, *([C.c_int64] * 6), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_void_p, *([C.c_int64] * 4), C.c_void_p, C.c_void_p]
+        L.alan_chain_filter.restype = C.c_int
+        L.alan_chain_filter.argtypes = [C.c_void_p, *([C.c_int64] * 7), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -151,6 +158,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_batch", "a
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
+           "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
            "alan_abi_version", "alan_build_target")
 
 
@@ -384,6 +392,45 @@ def chain_logmmexp_terms(terms):
                                      nbytes, current_stream(device))
     check(rc, "alan_chain_logmmexp_terms")
     return vec
+
+
+POSTERIOR_MAX_K = 128
+
+
+def chain_messages(ms):
+    """ms [C,T,K,K] fp32 -> backward messages beta [C,T+1,K] (alan_chain_messages: one launch)."""
+    require_device(ms, "timeseries factor")
+    flush()
+    C_, T, K, _ = ms.shape
+    beta = t.empty(C_, T + 1, K, dtype=t.float32, device=ms.device)
+    check(lib().alan_chain_messages(ms.data_ptr(), C_, T, K, *ms.stride(), beta.data_ptr(), current_stream(ms.device)),
+          "alan_chain_messages")
+    return beta
+
+
+def chain_sample(ms, beta, init, N, B, chain_of_n, chain_of_b, generator=None):
+    """Forward sampling given the messages (alan_chain_sample: one launch).  init: int64 [N, B] (stride 0 welcome);
+    sample (n, b) walks chain n * chain_of_n + b * chain_of_b.  -> int64 [N, B, T]."""
+    _, T, K, _ = ms.shape
+    u = t.rand(N, B, T, dtype=t.float32, device=ms.device, generator=generator)
+    out = t.empty(N, B, T, dtype=t.int64, device=ms.device)
+    init = init.expand(N, B)
+    check(lib().alan_chain_sample(ms.data_ptr(), T, K, *ms.stride(), beta.data_ptr(), init.data_ptr(), init.stride(0),
+                                  init.stride(1), u.data_ptr(), N, B, chain_of_n, chain_of_b, out.data_ptr(),
+                                  current_stream(ms.device)), "alan_chain_sample")
+    return out
+
+
+def chain_filter(ms, init):
+    """ms [C,T,K,K], init int64 [N] -> alpha [C,T,N,K]: the forward recursion from each initial state."""
+    require_device(ms, "timeseries factor")
+    flush()
+    C_, T, K, _ = ms.shape
+    init = init.contiguous()
+    alpha = t.empty(C_, T, init.numel(), K, dtype=t.float32, device=ms.device)
+    check(lib().alan_chain_filter(ms.data_ptr(), C_, T, K, *ms.stride(), init.data_ptr(), init.numel(), alpha.data_ptr(),
+                                  current_stream(ms.device)), "alan_chain_filter")
+    return alpha
 
 
 def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):

@@ -11,6 +11,7 @@ step eliminated.  Timeseries K dims are drawn by a filter / sample pass over T (
 import torch as t
 
 from . import engine as E
+from . import native as N_
 from .dims import PT, Dim, pt_align, pt_order
 from .logpq import plate_factors
 from .model import Plate
@@ -43,6 +44,30 @@ def _index_all(lps, indices):
     return out
 
 
+def _step_table(facs, now):
+    """Sum of a step's factors laid out [batch dims..., the Ks drawn at this step (``now``)...]: the (unnormalised)
+    log-weights the draw is taken from -- the ``lp`` of reduce_Ks.py:52-64.  -> (PT, number of K dims drawn)"""
+    dims, ids = pt_order(facs, last=now)                       # the Ks to draw innermost
+    total = None
+    for f in facs:
+        a = pt_align(f, ids)
+        total = a if total is None else total + a
+    total = total.expand([max(s) for s in zip(*[pt_align(f, ids).shape for f in facs])])
+    return PT(total, dims), len(now)
+
+
+def step_tables(lps, Ks):
+    """The tables ``sample_Ks`` draws from, in drawing order, with NOTHING plugged in yet (every K drawn at an earlier
+    step is still a dim of the later tables): what tests compare with the reference's pre-multinomial tables
+    (tests/golden/posterior.pt).  -> [(Ks drawn, PT table)]"""
+    _, _, record = E.contract([(lp.x, lp.dims) for lp in lps], tuple(Ks))
+    out = []
+    for group, now in reversed(record):
+        if len(now):
+            out.append((tuple(now), _step_table([PT(x, d) for x, d in group], now)[0]))
+    return out
+
+
 def sample_Ks(lps, Ks, N_dim, N):
     """Draw the K dims ``Ks`` of one plate jointly from their posterior given the factors ``lps`` (whose
     already-sampled K dims have been indexed away).  Returns {id(K): (K, PT index over (N, plates...))}."""
@@ -53,17 +78,12 @@ def sample_Ks(lps, Ks, N_dim, N):
         if not len(now):
             continue
         facs = _index_all([PT(x, d) for x, d in group], indices)
-        dims, ids = pt_order(facs, last=now)                       # the Ks to draw innermost
-        total = None
-        for f in facs:
-            a = pt_align(f, ids)
-            total = a if total is None else total + a
-        nk = len(now)
-        total = total.expand([max(s) for s in zip(*[pt_align(f, ids).shape for f in facs])])
-        flat = total.reshape(*total.shape[: len(ids) - nk], -1)
+        table, nk = _step_table(facs, now)
+        total, dims = table.x, table.dims
+        flat = total.reshape(*total.shape[: len(dims) - nk], -1)
         probs = (flat - flat.amax(-1, keepdim=True)).exp()
         assert bool(t.isfinite(probs).all()) and bool((probs >= 0).all())
-        batch = dims[: len(ids) - nk]
+        batch = dims[: len(dims) - nk]
         if any(d is N_dim for d in batch):                          # one draw per (n, plates...) row
             draw = t.multinomial(probs.reshape(-1, probs.shape[-1]), 1, replacement=True)
             draw = draw.reshape(probs.shape[:-1])
@@ -72,44 +92,106 @@ def sample_Ks(lps, Ks, N_dim, N):
             draw = t.multinomial(probs.reshape(-1, probs.shape[-1]), N, replacement=True)
             draw = draw.reshape(*probs.shape[:-1], N).movedim(-1, 0)
             out_dims = [N_dim, *batch]
-        sizes = [total.shape[len(ids) - nk + j] for j in range(nk)]
+        sizes = [total.shape[len(dims) - nk + j] for j in range(nk)]
         for j in range(nk - 1, -1, -1):                             # unravel the joint index
             indices[id(now[j])] = (now[j], PT(draw % sizes[j], out_dims))
             draw = draw // sizes[j]
     return indices
 
 
+TIMESERIES_POSTERIOR = "smoothing"
+"""How ``importance_sample`` draws a timeseries variable's K indices.
+
+"smoothing" (default): an exact joint draw of the whole trajectory from p(k_0..k_{T-1} | everything), by backward
+messages + forward sampling (two launches, O(T K^2)).
+
+"reference": what reduce_Ks.py:85-232 evaluates -- every timestep drawn INDEPENDENTLY from the filtering marginal
+p(k_t | factors up to t), mixed over the N sampled initial states.  (Its backward term is added on the K_init torchdim
+while the filtered term lives on the K torchdim; after indexing K_init with the sampled initial states and summing over
+N it is a constant over k, so the normalised "smoothed" table equals the filtered one -- tests/golden/posterior.pt
+records exactly that.)  Kept for parity checks; the trajectories it returns are not joint draws."""
+
+
+def _timeseries_factor(lps, Ks, K_cur, K_init, T_dim, indices):
+    """The plate's factors with its ordinary Ks summed out and every already-drawn K (but the initial state's) plugged
+    in: a PT over (batch dims..., T, K_init, K_cur), batch = enclosing plates (+ N once a drawn K was plugged in)."""
+    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], tuple(Ks))
+    lp = PT(out, dims)
+    core = (T_dim, K_init, K_cur)
+    assert all(lp.has(d) for d in core)
+    sub = {k: v for k, v in indices.items() if k != id(K_init)}
+    (lp,) = _index_all([lp], sub)
+    batch = tuple(d for d in lp.dims if not any(d is c for c in core))
+    return lp, batch, core
+
+
+def filtering_marginals(ms, init):
+    """[C, T, K]: log softmax_k( LSE_n alpha_t[n, k] ) with alpha the forward recursion from init[n] -- the table the
+    reference's sample_Ks_timeseries hands to t.multinomial at every timestep (see TIMESERIES_POSTERIOR)."""
+    alpha = N_.chain_filter(ms, init)                            # [C, T, N, K]
+    mix = t.logsumexp(alpha, 2)
+    return mix - t.logsumexp(mix, -1, keepdim=True)
+
+
 def sample_Ks_timeseries(lps, Ks, K_currs, K_inits, T_dim, indices, N_dim, N):
-    """Posterior draw of a timeseries variable's K index at every timestep (role of
-    sample_Ks_timeseries, reduce_Ks.py:85-232) by forward-filtering / backward-sampling in the
-    reversed direction: backward messages beta_t[a] = LSE_b(M_{t+1}[a,b] + beta_{t+1}[b]) (one alan_reduce
-    per step), then k_t ~ softmax_b(M_t[k_{t-1}, b] + beta_t[b]) forwards from the already-sampled
-    initial-state index.  O(T K^2) instead of the reference's O(T^2) chain evaluations."""
-    if len(Ks) or len(K_currs) != 1:
-        raise NotImplementedError("alan_amd: a timeseries plate with further latent groups cannot be "
-                                  "posterior-sampled yet")
+    """Posterior draw of a timeseries variable's K index at every timestep (role of sample_Ks_timeseries,
+    reduce_Ks.py:85-232).  The plate may hold further latent groups (their Ks are summed out first and drawn afterwards
+    by ``sample_Ks`` given the trajectory) and sit under other plates / parents' K dims (a batch of chains)."""
+    assert len(K_currs) == 1 and len(K_inits) == 1, "one timeseries group per plate (logpq.py:136,140)"
     K_cur, K_init = K_currs[0], K_inits[0]
     assert id(K_init) in indices, "the initial state must have been sampled in the parent plate"
-    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], ())
-    lp = PT(out, dims)
-    want = (id(T_dim), id(K_init), id(K_cur))
-    if set(lp.ids) != set(want):
-        raise NotImplementedError("alan_amd: timeseries plates nested under other K/plate dims are not supported")
-    ms = pt_align(lp, want).contiguous()                         # [T, K_prev, K]
-    T, K = ms.shape[0], ms.shape[2]
+    lp, batch, core = _timeseries_factor(lps, Ks, K_cur, K_init, T_dim, indices)
+    has_N = any(d is N_dim for d in batch)
+    plates = tuple(d for d in batch if d is not N_dim)
+    # chains laid out [N (if the factor depends on the sample), plates..., T, K_prev, K]
+    lead = ((N_dim,) if has_N else ()) + plates
+    ms = pt_align(lp, tuple(id(d) for d in (*lead, *core))).contiguous()
+    T, K = ms.shape[-3], ms.shape[-1]
+    B = 1
+    for d in plates:
+        B *= d.size
+    init = pt_align(indices[id(K_init)][1], tuple(id(d) for d in (N_dim, *plates)))
+    init = init.expand(N, *[d.size for d in plates]).reshape(N, B)
+    flat = ms.reshape(-1, T, K, K)
+    if ms.dtype != t.float32 or K > N_.POSTERIOR_MAX_K or not ms.is_cuda:
+        # (not on the GPU: only under the test-only CPU backend, whose seam is alan_reduce)
+        draws = _sample_chain_by_steps(flat, init, N, B, has_N)
+    elif TIMESERIES_POSTERIOR == "reference":
+        if has_N:
+            raise NotImplementedError("TIMESERIES_POSTERIOR = 'reference' with chains that depend on the sample")
+        if B == 1 or bool((init == init[:, :1]).all()):
+            logp = filtering_marginals(flat, init[:, 0].contiguous())                  # [B, T, K]
+        else:                                                                           # initial states differ by plate
+            logp = t.cat([filtering_marginals(flat[b:b + 1], init[:, b].contiguous()) for b in range(B)], 0)
+        # N independent draws per (b, t)
+        d = t.multinomial(logp.exp().reshape(B * T, K), N, replacement=True)            # [B*T, N]
+        draws = d.reshape(B, T, N).permute(2, 0, 1).contiguous()
+    else:
+        beta = N_.chain_messages(flat)
+        draws = N_.chain_sample(flat, beta, init, N, B, B if has_N else 0, 1)
+    draws = draws.reshape(N, *[d.size for d in plates], T)
+    return {id(K_cur): (K_cur, PT(draws, (N_dim, *plates, T_dim)))}
+
+
+def _sample_chain_by_steps(flat, init, N, B, has_N):
+    """The same draw with one alan_reduce per backward message and one torch.multinomial per step (fp64 factors, or
+    more than 128 particles)."""
+    C_, T, K, _ = flat.shape
     beta = [None] * (T + 1)
-    beta[T] = t.zeros(K, dtype=ms.dtype, device=ms.device)
+    beta[T] = t.zeros(C_, K, dtype=flat.dtype, device=flat.device)
     for step in range(T - 1, 0, -1):
-        beta[step], _ = E.reduce_factors([(ms[step], ("a", "b")), (beta[step + 1], ("b",))], reduce=("b",))
-    prev = pt_align(indices[id(K_init)][1], (id(N_dim),))        # [N] indices of the initial state
-    assert prev.ndim == 1
+        beta[step], _ = E.reduce_factors([(flat[:, step], ("c", "a", "b")), (beta[step + 1], ("c", "b"))], reduce=("b",))
+    n_idx = t.arange(N, device=flat.device).unsqueeze(1).expand(N, B)
+    b_idx = t.arange(B, device=flat.device).unsqueeze(0).expand(N, B)
+    chain = (n_idx * B + b_idx) if has_N else b_idx
+    prev = init
     draws = []
     for step in range(T):
-        logits = ms[step][prev] + beta[step + 1]                 # [N, K]
+        logits = flat[chain, step, prev] + beta[step + 1][chain]                         # [N, B, K]
         probs = (logits - logits.amax(-1, keepdim=True)).exp()
-        prev = t.multinomial(probs, 1, replacement=True).squeeze(-1)
+        prev = t.multinomial(probs.reshape(N * B, K), 1, replacement=True).reshape(N, B)
         draws.append(prev)
-    return {id(K_cur): (K_cur, PT(t.stack(draws, 1), (N_dim, T_dim)))}
+    return t.stack(draws, -1)
 
 
 def logPQ_sample(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
@@ -119,8 +201,8 @@ def logPQ_sample(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims, all_platedims,
         groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy, {})
     if K_currs:
+        # the trajectory first (the plate's ordinary Ks summed out), then those Ks given the trajectory
         indices = {**indices, **sample_Ks_timeseries(lps, Ks, K_currs, K_inits, platedim, indices, N_dim, N)}
-        Ks = ()
     lps = _index_all(lps, indices)
     if Ks:
         indices = {**indices, **sample_Ks(lps, Ks, N_dim, N)}

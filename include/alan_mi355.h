@@ -238,6 +238,24 @@ int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t 
                                          const void *grad_chain, void *grad_ms,
                                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* Posterior sampling of a timeseries variable's K index at every timestep -- the role of sample_Ks_timeseries
+ * (reduce_Ks.py:85-232, O(T^2) chain evaluations) as backward messages + forward sampling, two launches whatever T is.
+ * ms is [C, T, K, K] fp32 with element strides (sC, sT, sRow, sCol): C chains of the [T, K_init, K] factor of
+ * logpq.py:133.  K <= 128.
+ *   alan_chain_messages   beta [C, T+1, K] contiguous:  beta[c,T,:] = 0,  beta[c,t,a] = LSE_b(ms[c,t,a,b] + beta[c,t+1,b])
+ *   alan_chain_sample     out [N, B, T] int64:  k_t ~ softmax_b(ms[c,t,k_{t-1},b] + beta[c,t+1,b]) for t = 0..T-1, with
+ *                         k_{-1} = init[n*iN + b*iB] (int64), chain c = n*cN + b*cB, one uniform in [0,1) per draw in
+ *                         uniforms [N, B, T] fp32 (the caller's generator: draws are reproducible from its seed)
+ *   alan_chain_filter     alpha [C, T, N, K] contiguous: the forward recursion from init[n] -- what the reference's
+ *                         per-timestep draws are taken from (after mixing over n and normalising), for parity checks */
+int alan_chain_messages(const void *ms, int64_t C, int64_t T, int64_t K, int64_t sC, int64_t sT, int64_t sRow,
+                        int64_t sCol, void *beta, void *stream);
+int alan_chain_sample(const void *ms, int64_t T, int64_t K, int64_t sC, int64_t sT, int64_t sRow, int64_t sCol,
+                      const void *beta, const void *init, int64_t iN, int64_t iB, const void *uniforms, int64_t N,
+                      int64_t B, int64_t cN, int64_t cB, void *out, void *stream);
+int alan_chain_filter(const void *ms, int64_t C, int64_t T, int64_t K, int64_t sC, int64_t sT, int64_t sRow,
+                      int64_t sCol, const void *init, int64_t N, void *alpha, void *stream);
+
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);
 const char *alan_build_target(void);

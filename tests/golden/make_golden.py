@@ -17,6 +17,8 @@ What is captured:
                      floors most entries: results then depend on the tree's bracketing, and autograd differentiates
                      through the floor.  Includes batches of chains (torchdim batch dims, logpq.py:133-139).
   e2e_*.pt           sample tree + data + params + ELBO under no_checkpoint / checkpoint / Split
+  posterior.pt       the tables the reference's posterior K sampling hands to t.multinomial: per step of sample_Ks
+                     (reduce_Ks.py:35-83) and per timestep of sample_Ks_timeseries (reduce_Ks.py:85-232)
   e2e_wide_group.pt  a Group of seven Normal latents (more factors on one K than one launch takes)
   e2e_movielens_K30.pt, e2e_bus_breakdown_K30.pt, e2e_movielens_K100_split38.pt
                      the same at the BASELINE.json sizes (C2, C3, C4): `make_golden.py baseline_sizes`
@@ -473,6 +475,63 @@ def gen_wide_group():
     save("e2e_wide_group.pt", rec)
 
 
+def gen_posterior():
+    """What the reference's posterior K sampling draws FROM (the tables handed to t.multinomial), so that the draws
+    themselves -- random -- need not be compared:
+      sample_Ks (reduce_Ks.py:35-83): per elimination step, walked backwards, the table sum(lps) over the step's Ks
+        (before already-drawn indices are plugged in: deterministic) and the Ks drawn from it;
+      sample_Ks_timeseries (reduce_Ks.py:85-232): called directly on a hand-built [T, K_init, K] factor and given
+        initial-state indices (an end-to-end timeseries model cannot be built with this torch: Timeseries.py:123), with
+        t.multinomial wrapped to record its weights at every timestep."""
+    from alan.reduce_Ks import collect_lps, sample_Ks_timeseries as ref_sample_ts
+    out = {"sample_Ks": [], "timeseries": []}
+    g = t.Generator().manual_seed(515)
+    cases = [
+        ("chain3", [(loglike(g, 4, 5), ("K1", "K2")), (loglike(g, 5, 6), ("K2", "K3")), (loglike(g, 6, 3), ("K3", "K4"))],
+         ("K1", "K2", "K3", "K4")),
+        ("star_plate", [(loglike(g, 7, 4), ("p", "Kc")), (loglike(g, 4, 3), ("Kc", "K1")),
+                        (loglike(g, 7, 4, 5), ("p", "Kc", "K2")), (loglike(g, 5), ("K2",))], ("Kc", "K1", "K2")),
+        ("top_level", [(loglike(g, 5), ("Ka",)), (loglike(g, 4), ("Kb",)), (loglike(g, 5, 4) * 3, ("Ka", "Kb"))], ("Ka", "Kb")),
+        ("single", [(loglike(g, 6, 5), ("p", "K"))], ("K",)),
+    ]
+    for name, factors, Ks in cases:
+        dm = {}
+        lps = [todim(x, n, dm) for x, n in factors]
+        _, lps_for_sampling, Ks_to_sample = collect_lps(lps, [dm[k] for k in Ks])
+        steps = []
+        for lps_s, kd in zip(lps_for_sampling[::-1], Ks_to_sample[::-1]):
+            tab, names = undim(sum(lps_s))
+            steps.append(dict(Ks=tuple(str(k) for k in kd), table=tab, names=names))
+        out["sample_Ks"].append(dict(name=name, factors=[(x, tuple(n)) for x, n in factors], Ks=Ks, steps=steps))
+    for (T, K, N, seed) in [(4, 3, 6, 1), (7, 5, 9, 2), (12, 10, 20, 3)]:
+        gg = t.Generator().manual_seed(900 + seed)
+        P = 2          # an enclosing plate: two independent chains (without one the reference's index bookkeeping,
+        #                t.zeros(...)[N_dim, []] at reduce_Ks.py:123, breaks under this torch)
+        ms = loglike(gg, P, T, K, K, K=K) + 0.7 * t.randn(P, T, 1, K, generator=gg)
+        init = t.randint(0, K, (N,), generator=gg)
+        dm = {}
+        lp = todim(ms, ("p", "T", "K_init", "K_ts"), dm)
+        N_dim = Dim("N", N)
+        recorded = []
+        real = t.multinomial
+
+        def spy(probs, *a, **k):
+            recorded.append(undim(probs))
+            return real(probs, *a, **k)
+
+        t.multinomial = spy
+        try:
+            res = ref_sample_ts([lp], [dm["K_ts"]], [dm["K_init"]], N_dim, N, dm["T"], {dm["K_init"]: init[N_dim]})
+        finally:
+            t.multinomial = real
+        assert len(recorded) == T and all(n == ("p",) for _, n in recorded), [n for _, n in recorded]
+        # recorded[0] belongs to t = T-1 (the reference walks backwards); store in time order [p, T, K], normalised
+        probs = t.stack([x for x, _ in recorded[::-1]], 1)
+        out["timeseries"].append(dict(T=T, K=K, N=N, ms=ms, init=init, probs=probs / probs.sum(-1, keepdim=True),
+                                      drawn=undim(res[dm["K_ts"]])))
+    save("posterior.pt", out)
+
+
 def gen_baseline_sizes():
     """The BASELINE.json configurations at their literal sizes (SURVEY section 6 timed the reference on exactly these):
     C2 movielens K=30, C4 movielens K=100 under Split('plate_1', 38) (the reference's unsplit K=100 evaluation would
@@ -494,6 +553,9 @@ def gen_baseline_sizes():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["posterior"]:
+        gen_posterior()
+        sys.exit(0)
     if sys.argv[1:] == ["wide_group"]:
         gen_wide_group()
         sys.exit(0)
@@ -509,4 +571,5 @@ if __name__ == "__main__":
     gen_chain_peaked()
     gen_models()
     gen_wide_group()
+    gen_posterior()
     gen_baseline_sizes()

@@ -278,3 +278,75 @@ def test_timeseries_fp64_matches_the_oracle_to_rounding():
         cpu = float(_same_sample_on_cpu(sample, cpu_prob, 30).elbo_nograd(alan.no_checkpoint))
     assert abs(float(gpu) - cpu) <= 1e-10 * abs(cpu) + 1e-9, (float(gpu), cpu)
     assert float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) == float(gpu)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# posterior sampling of timeseries K indices beyond the bare chain (sample_Ks_timeseries, reduce_Ks.py:85-232, handles
+# both): a timeseries plate nested under another plate and a parent's K, and a timeseries plate that also holds an
+# ordinary latent group.  Checked against the exact K-marginals (the path's backward), which the tests above pin to
+# the Kalman smoother.
+def with_group_problem(T, seed=0):
+    """ts_t ~ N(A ts_{t-1}, NOISE);  z_t ~ N(ts_t, 0.5) (an ordinary latent in the same plate);  obs_t ~ N(z_t, OBS)"""
+    g = t.Generator().manual_seed(seed)
+    y = t.randn(T, generator=g)
+    P = Plate(init=Normal(0, INIT_SCALE),
+              T=Plate(ts=Timeseries("init", Normal(lambda prev: A * prev, NOISE)), z=Normal("ts", 0.5), obs=Normal("z", OBS)))
+    Q = Plate(init=Normal(0, 1), T=Plate(ts=Normal(0, 1), z=Normal(0, 1), obs=Data()))
+    sizes = {"T": T}
+    return Problem(BoundPlate(P, sizes), BoundPlate(Q, sizes), {"obs": y.refine_names("T")})
+
+
+def _posterior_samples_match_marginals(prob, device, K, N, varnames):
+    from alan_amd import mean
+    from alan_amd.dims import dims_of
+    prob.to(device)
+    t.manual_seed(7)
+    if device == "cuda":
+        t.cuda.manual_seed_all(7)
+    sample = prob.sample(K, reparam=False)
+    marg = sample.marginals()
+    isamp = sample.importance_sample(N)
+    for v in varnames:
+        m = marg._moments(v, mean)
+        var = marg._moments(v, alan.var_from_raw_moment(mean))
+        est = isamp._moments(v, mean)
+        ds = dims_of(m)
+        m, var, est = ((x.order(*ds) if ds else x).cpu().double() for x in (m, var, est))
+        assert bool(((est - m).abs() < 6 * (var / N).sqrt() + 2e-3).all()), (v, (est - m).abs().max())
+    return isamp
+
+
+def test_posterior_of_a_nested_timeseries_host_logic(oracle_backend):
+    prob, _ = nested_problem(4)
+    isamp = _posterior_samples_match_marginals(prob, "cpu", 40, 3000, ["ts", "init", "drift"])
+    assert set(isamp.dump()["ts"].names) == {"N", "R", "T"}
+
+
+def test_posterior_of_a_timeseries_plate_with_another_group_host_logic(oracle_backend):
+    _posterior_samples_match_marginals(with_group_problem(5), "cpu", 40, 3000, ["ts", "z", "init"])
+
+
+@pytest.mark.gpu
+def test_posterior_of_a_nested_timeseries_gpu():
+    prob, _ = nested_problem(6)
+    isamp = _posterior_samples_match_marginals(prob, "cuda", 100, 20000, ["ts", "init", "drift"])
+    assert set(isamp.dump()["ts"].names) == {"N", "R", "T"}
+
+
+@pytest.mark.gpu
+def test_posterior_of_a_timeseries_plate_with_another_group_gpu():
+    _posterior_samples_match_marginals(with_group_problem(8), "cuda", 100, 20000, ["ts", "z", "init"])
+
+
+@pytest.mark.gpu
+def test_timeseries_posterior_reference_mode_runs_end_to_end(monkeypatch):
+    """posterior.TIMESERIES_POSTERIOR = "reference": per-timestep draws from the filtering marginals, as
+    reduce_Ks.py:85-232 evaluates them (tests/test_gpu_posterior.py pins the tables)."""
+    from alan_amd import posterior as PS
+    monkeypatch.setattr(PS, "TIMESERIES_POSTERIOR", "reference")
+    prob, _ = kalman_problem(6)
+    prob.to("cuda")
+    t.manual_seed(1)
+    isamp = prob.sample(50, reparam=False).importance_sample(500)
+    d = isamp.dump()["ts"]
+    assert set(d.names) == {"N", "T"} and bool(t.isfinite(d.rename(None)).all())
