@@ -21,6 +21,10 @@ struct NLDesc {
     const float *val, *loc, *scl;
     float *part;                      // [n_chunks][NL][NS]
     float *lse;                       // optional [M][NL][NS]: the per-plate-element log-sum-exp (the backward's input)
+    float *out;                       // with counters: the last workgroup of a column of the grid adds up the chunks
+    int32_t *counters;                //   [gridDim.x] arrival counters, zero on entry, left zero (nullptr: second stage)
+    int64_t o_sl, o_ss;
+    float add_const;
     int32_t M, NK, NL, NS, E, m_chunk, n_small, log_scale;
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se;
     const float *small[4];
@@ -57,8 +61,9 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     const int NK = d.NK, E = d.E, NS = d.NS;
     const int nkt = (NK + 31) >> 5, nsg = (((NS + 31) >> 5) + NST - 1) / NST;
     const int q = blockIdx.x * 4 + wave;              // (loc row, group of NST scale tiles) of this wave
-    if (q >= d.NL * nsg) return;                      // (no barriers in this kernel)
-    const int l = q / nsg, sg = q - l * nsg;
+    const bool wave_on = q < d.NL * nsg;
+    if (!wave_on && !d.counters) return;              // (no barriers unless the chunks are combined in this launch)
+    const int l = wave_on ? q / nsg : 0, sg = wave_on ? q - l * nsg : 0;
     // the small factors ride in the LAST step's spare element: half-wave 0 when the events leave both elements of
     // that step free, else half-wave 1 (E = 2 EH - 1) -- one select per tile instead of one per step
     const bool slot_lane = h == (E > 2 * (EH - 1) ? 1 : 0);
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         mreg[step] = e < E ? x : 0.f;
     }
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
-    const int n_tiles = (m1 - m0) * nkt;
+    const int n_tiles = wave_on ? (m1 - m0) * nkt : 0;
     // Tile t = (plate element m0 + t / nkt, k tile t % nkt), walked with counters (no division in the loop).  Everything
     // that addresses a tile is the same for all four waves (they share blockIdx.y): a scalar base plus a 32-bit lane
     // offset.  Loads are issued from clamped, always valid addresses, all of them before anything waits; masks are
@@ -218,7 +223,50 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         const int s = 32 * (sg * NST + st) + j;
-        if (h == 0 && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[st];
+        if (wave_on && h == 0 && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[st];
+    }
+    if (!d.counters) return;
+    // ---- the chunks of the plate are combined in this launch: the workgroup that arrives LAST at its column's
+    // counter adds them up, in chunk order (deterministic).  Agent-scope release / acquire as the inter-workgroup
+    // hand-off needs on gfx950 (per-XCD L2s are not coherent): every storing wave drains its stores, the workgroup
+    // barrier, ONE lane's release fence, then the relaxed ticket; the last arriver's acquire fence before its loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *flag = reinterpret_cast<int *>(lds + 4 * 32 * 33);
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(&d.counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.y - 1;
+        if (last) {
+            __hip_atomic_store(&d.counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    // this workgroup's outputs: waves -> (l, sg), lanes -> scale rows; 4 * NST * 32 sums of gridDim.y partials each
+    for (int i = tid; i < 4 * NST * 32; i += 256) {
+        const int w = i / (NST * 32), r = i - w * (NST * 32);
+        const int qq = blockIdx.x * 4 + w;
+        if (qq >= d.NL * nsg) continue;
+        const int ll = qq / nsg, ss = 32 * ((qq - ll * nsg) * NST) + r;
+        if (ss >= NS) continue;
+        const float *pp = d.part + (int64_t)ll * NS + ss;
+        const int64_t cs = (int64_t)d.NL * NS;
+        float tot = 0.f;
+        int c = 0;
+        for (; c + 16 <= (int)gridDim.y; c += 16) {           // 16 loads in flight, added in chunk order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = pp[(c + u) * cs];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tot += v[u];
+        }
+        for (; c < (int)gridDim.y; ++c) tot += pp[c * cs];
+        d.out[(int64_t)ll * d.o_sl + (int64_t)ss * d.o_ss] = tot + d.add_const;
     }
 }
 
@@ -302,7 +350,10 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     }
     // the staged variant needs the tile's 32 rows to be one contiguous run of the value tensor
     const bool stage = a->v_se == 1 && a->v_sk == a->E && env_stage_ok();
-    const size_t lds = stage ? 4 * 32 * 33 * sizeof(float) : 0;
+    const size_t lds = 4 * 32 * 33 * sizeof(float) + 16;          // the waves' value tiles + the combine's flag
+    d.counters = (int32_t *)a->counters;
+    d.out = (float *)a->out, d.o_sl = a->o_sl, d.o_ss = a->o_ss, d.add_const = (float)a->add_const;
+    if (d.counters && (int64_t)p.grid.x > a->n_counters) return ALAN_ERR_BAD_DESC;
     auto launch = [&](auto kern) {
         hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
@@ -323,6 +374,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
 #undef NL_PICK
 #undef NL_CASE
     if (rc != ALAN_OK) return rc;
+    if (d.counters) return ALAN_OK;                   // (the chunks were combined by the launch itself)
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
     Canon s2;

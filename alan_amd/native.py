@@ -73,7 +73,8 @@ class NormalLseDesc(C.Structure):
                 ("small", C.c_void_p * 4), ("small_sm", C.c_int64 * 4), ("small_sk", C.c_int64 * 4),
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
                 ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64),
-                ("lse_out", C.c_void_p), ("add_const", C.c_double), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("lse_out", C.c_void_p), ("add_const", C.c_double), ("counters", C.c_void_p), ("n_counters", C.c_int64),
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 class NormalLseBackwardDesc(C.Structure):
@@ -304,10 +305,34 @@ def run_reduce_backward(desc, device):
     return True
 
 
+_COUNTERS = {}          # device index -> zeroed int32 arrival counters (every launch leaves them zero)
+N_COUNTERS = 8192
+COMBINE_IN_LAUNCH = False
+"""True: alan_normal_lse adds up its per-chunk partial sums itself (the last workgroup to arrive does it) instead of in
+a second launch.  Off by default -- measured slower: at K=30 the kernel goes from 16.9 to 26.7 us (600 workgroups each
+pay an agent-scope release fence, ~2-6 us of write-back per workgroup on gfx950) to save one 4.6 us launch: 48.3 us per
+evaluation against 42.3.  When on, the arrival counters are ONE array per device, shared by every call on that device:
+evaluations whose kernels may overlap in time on different streams must not share it (the C ABI takes the array from
+the caller and keeps no state of its own)."""
+
+
+def arrival_counters(device):
+    """The device's counter array, or None while a capture is under way and it does not exist yet (allocating it then
+    would put its fill kernel into the graph and tie its memory to the graph's pool)."""
+    c = _COUNTERS.get(device.index)
+    if c is None and not t.cuda.is_current_stream_capturing():
+        c = _COUNTERS[device.index] = t.zeros(N_COUNTERS, dtype=t.int32, device=device)
+    return c
+
+
 def run_normal_lse(desc, device):
     """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
     L = lib()
     flush()
+    if COMBINE_IN_LAUNCH and desc.NL * ((desc.NS + 31) // 32) <= N_COUNTERS:
+        c = arrival_counters(device)
+        if c is not None:
+            desc.counters, desc.n_counters = c.data_ptr(), N_COUNTERS
     nbytes = L.alan_normal_lse_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         return False

@@ -154,6 +154,12 @@ typedef struct {
     void *out;          int64_t o_sl, o_ss;            /* [NL, NS]   */
     void *lse_out;                                     /* optional [M, NL, NS] fp32 contiguous */
     double add_const;
+    void *counters; int64_t n_counters;                /* optional int32[n_counters], n_counters >= NL * ceil(NS / 32):
+                                                          ZERO on entry, left zero.  When given, the per-chunk partial
+                                                          sums are added up by the launch itself (the last workgroup to
+                                                          arrive, agent-scope release / acquire) instead of by a second
+                                                          launch.  One array per stream: two calls in flight at once
+                                                          must not share it */
     void *ev_start, *ev_stop;                          /* optional hipEvent_t pair (NULL = off) recorded immediately
                                                           before / after the MFMA kernel of the call (forward, or the
                                                           backward when the descriptor sits in a backward desc) */

@@ -272,3 +272,22 @@ def test_movielens_gradients_fused_route_equals_materialised_route(method, monke
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
         t.testing.assert_close(g1[n], g0[n], rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")
+
+
+def test_in_launch_combine_of_the_chunk_partials_gives_the_same_result(monkeypatch):
+    """alan_normal_lse with arrival counters (the last workgroup of a grid column adds up the per-chunk partial sums:
+    agent-scope release / acquire hand-off) against the default second-stage launch: bit-identical (same order of
+    additions), launch after launch (the counters are left zero), eagerly and as a replayed graph."""
+    from alan_amd import native as N
+    g = t.Generator().manual_seed(11)
+    for M, NK, NL, NS, Ev in ((300, 30, 30, 30, 18), (64, 100, 100, 100, 18), (37, 33, 5, 70, 7)):
+        pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)
+        z, mu, raw = t.randn(M, NK, Ev, generator=g).to(DEV), t.randn(NL, Ev, generator=g).to(DEV), (0.3 * t.randn(NS, Ev, generator=g)).to(DEV)
+        sm = [(t.randn(M, NK, generator=g).to(DEV), (pl, K))]
+        args = ((z, (pl, K)), (mu, (dl,)), (raw, (ds,)), sm, pl, K)
+        monkeypatch.setattr(N, "COMBINE_IN_LAUNCH", False)
+        two, _ = E.normal_lse(*args, log_scale=True)
+        monkeypatch.setattr(N, "COMBINE_IN_LAUNCH", True)
+        outs = [E.normal_lse(*args, log_scale=True)[0] for _ in range(5)]
+        assert all(t.equal(o, two) for o in outs), (M, NK, NL, NS)
+        assert int(N.arrival_counters(z.device).abs().sum()) == 0
