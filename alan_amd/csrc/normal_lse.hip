@@ -53,17 +53,21 @@ constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530
 // its A operand from there.  Per-lane row loads of the same bytes -- 64 lanes, 64 different rows 72 bytes apart, one
 // dword each, ten times per tile -- keep the CU's texture addresser busy for longer than the MFMAs take.
 
-template <int EH, int NST, bool STAGE>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
+// NLW: loc rows per wave (2 when one scale tile covers all scale rows, K <= 32: the value tile's loads, its LDS
+// stage and the small-factor sum are then shared by two tiles of work -- 110 of the 250 instructions of a tile).
+template <int EH, int NST, bool STAGE, int NLW = 1>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
 __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int NK = d.NK, E = d.E, NS = d.NS;
     const int nkt = (NK + 31) >> 5, nsg = (((NS + 31) >> 5) + NST - 1) / NST;
-    const int q = blockIdx.x * 4 + wave;              // (loc row, group of NST scale tiles) of this wave
-    const bool wave_on = q < d.NL * nsg;
+    const int nlg = (d.NL + NLW - 1) / NLW;           // groups of NLW loc rows
+    const int q = blockIdx.x * 4 + wave;              // (group of loc rows, group of NST scale tiles) of this wave
+    const bool wave_on = q < nlg * nsg;
     if (!wave_on && !d.counters) return;              // (no barriers unless the chunks are combined in this launch)
-    const int l = wave_on ? q / nsg : 0, sg = wave_on ? q - l * nsg : 0;
+    const int lgp = wave_on ? q / nsg : 0, sg = wave_on ? q - lgp * nsg : 0;
+    const int l = lgp * NLW;                          // first loc row of the wave
     // the small factors ride in the LAST step's spare element: half-wave 0 when the events leave both elements of
     // that step free, else half-wave 1 (E = 2 EH - 1) -- one select per tile instead of one per step
     const bool slot_lane = h == (E > 2 * (EH - 1) ? 1 : 0);
@@ -85,13 +89,15 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         }
         lgn[st] = lg + __shfl_xor(lg, 32) + (float)E * 0.91893853320467274178f;
     }
-    float mreg[EH];
+    float mreg[NLW][EH];
 #pragma unroll
-    for (int step = 0; step < EH; ++step) {
-        const int e = 2 * step + h;
-        const float x = d.loc[(int64_t)l * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
-        mreg[step] = e < E ? x : 0.f;
-    }
+    for (int lw = 0; lw < NLW; ++lw)
+#pragma unroll
+        for (int step = 0; step < EH; ++step) {
+            const int e = 2 * step + h;
+            const float x = d.loc[(int64_t)min(l + lw, d.NL - 1) * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
+            mreg[lw][step] = e < E ? x : 0.f;
+        }
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
     const int n_tiles = wave_on ? (m1 - m0) * nkt : 0;
     // Tile t = (plate element m0 + t / nkt, k tile t % nkt), walked with counters (no division in the loop).  Everything
@@ -139,9 +145,10 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     };
     float zc[NX], zn[NX], hc[4], hn[4];
     if (n_tiles > 0) load_tile(m0, 0, zc, hc);
-    float accm[NST], mn[NST], sm[NST];                // plate sum; running minimum of D (= -max, base 2) and sum 2^(mn - D)
+    constexpr int NU = NLW * NST;                     // units of work per value tile: (loc row, scale tile) pairs
+    float accm[NU], mn[NU], sm[NU];                   // plate sum; running minimum of D (= -max, base 2) and sum 2^(mn - D)
 #pragma unroll
-    for (int st = 0; st < NST; ++st) accm[st] = 0.f, mn[st] = inf, sm[st] = 0.f;
+    for (int u = 0; u < NU; ++u) accm[u] = 0.f, mn[u] = inf, sm[u] = 0.f;
     const float n_small_mask[4] = {d.n_small > 0 ? 1.f : 0.f, d.n_small > 1 ? 1.f : 0.f, d.n_small > 2 ? 1.f : 0.f,
                                    d.n_small > 3 ? 1.f : 0.f};
     int kt = 0, m = m0;
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         float hsum = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) hsum += n_small_mask[f] != 0.f ? hc[f] : 0.f;
-        float a[EH];
+        float a[EH], zv[EH];
         if (STAGE) {
             // (one wave, in-order LDS queue: last tile's reads precede these writes, these writes the reads below)
 #pragma unroll
@@ -165,21 +172,25 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int step = 0; step < EH; ++step) a[step] = tile[j * (E + 1) + min(2 * step + h, E - 1)];
+            for (int step = 0; step < EH; ++step) zv[step] = tile[j * (E + 1) + min(2 * step + h, E - 1)];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
-            for (int step = 0; step < EH; ++step) a[step] = zc[step];
+            for (int step = 0; step < EH; ++step) zv[step] = zc[step];
         }
+        const float slot = k_ok ? -hsum : inf;
 #pragma unroll
-        for (int step = 0; step < EH; ++step) {
-            const float df = a[step] - mreg[step];
-            a[step] = df * df;
-        }
-        if (slot_lane) a[EH - 1] = k_ok ? -hsum : inf;
+        for (int u = 0; u < NU; ++u) {
+            const int lw = u / NST, st = u - lw * NST;
+            if (st == 0) {
 #pragma unroll
-        for (int st = 0; st < NST; ++st) {
+                for (int step = 0; step < EH; ++step) {
+                    const float df = zv[step] - mreg[lw][step];
+                    a[step] = df * df;
+                }
+                if (slot_lane) a[EH - 1] = slot;
+            }
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int step = 0; step < EH; ++step)
@@ -190,28 +201,29 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             float tmin = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
-            const float mnew = fminf(mn[st], tmin);
+            const float mnew = fminf(mn[u], tmin);
             const float mf = mnew == inf ? 0.f : mnew;
-            float ssum = sm[st] * __builtin_amdgcn_exp2f(mf - (mn[st] == inf ? mf : mn[st]));
+            float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
 #pragma unroll
             for (int r = 0; r < 16; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc[r]);
-            mn[st] = mnew, sm[st] = ssum;
+            mn[u] = mnew, sm[u] = ssum;
         }
         if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
-                const float mn2 = __shfl_xor(mn[st], 32), sm2 = __shfl_xor(sm[st], 32);
-                const float mm = fminf(mn[st], mn2);
+            for (int u = 0; u < NU; ++u) {
+                const int lw = u / NST, st = u - lw * NST;
+                const float mn2 = __shfl_xor(mn[u], 32), sm2 = __shfl_xor(sm[u], 32);
+                const float mm = fminf(mn[u], mn2);
                 const float mf = mm == inf ? 0.f : mm;
-                const float tot = sm[st] * __builtin_amdgcn_exp2f(mf - (mn[st] == inf ? mf : mn[st])) +
+                const float tot = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u])) +
                                   sm2 * __builtin_amdgcn_exp2f(mf - (mn2 == inf ? mf : mn2));
                 // log(sum + eps) + max in natural units (utils.py:218-220); an all -inf (or +inf) column gives NaN there
                 float lse_m = logf(tot + Num<float>::eps) - mm * NL_LN2 - lgn[st];
                 if (mm == inf || mm == -inf) lse_m = __builtin_nanf("");
-                accm[st] += lse_m;
+                accm[u] += lse_m;
                 const int s = 32 * (sg * NST + st) + j;
-                if (d.lse && h == 0 && s < NS) d.lse[((int64_t)m * d.NL + l) * NS + s] = lse_m;
-                mn[st] = inf, sm[st] = 0.f;
+                if (d.lse && h == 0 && s < NS && l + lw < d.NL) d.lse[((int64_t)m * d.NL + l + lw) * NS + s] = lse_m;
+                mn[u] = inf, sm[u] = 0.f;
             }
             kt = 0, ++m;
         }
@@ -221,9 +233,10 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
 #pragma unroll
-    for (int st = 0; st < NST; ++st) {
+    for (int u = 0; u < NU; ++u) {
+        const int lw = u / NST, st = u - lw * NST;
         const int s = 32 * (sg * NST + st) + j;
-        if (wave_on && h == 0 && s < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s] = accm[st];
+        if (wave_on && h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.y * d.NL + l + lw) * NS + s] = accm[u];
     }
     if (!d.counters) return;
     // ---- the chunks of the plate are combined in this launch: the workgroup that arrives LAST at its column's
@@ -247,13 +260,13 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     }
     __syncthreads();
     if (!*flag) return;
-    // this workgroup's outputs: waves -> (l, sg), lanes -> scale rows; 4 * NST * 32 sums of gridDim.y partials each
-    for (int i = tid; i < 4 * NST * 32; i += 256) {
-        const int w = i / (NST * 32), r = i - w * (NST * 32);
+    // this workgroup's outputs: waves -> (loc-row group, sg), lanes -> scale rows; 4 * NU * 32 sums of gridDim.y partials
+    for (int i = tid; i < 4 * NU * 32; i += 256) {
+        const int w = i / (NU * 32), r0 = i - w * (NU * 32), lw = r0 / (NST * 32), r = r0 - lw * (NST * 32);
         const int qq = blockIdx.x * 4 + w;
-        if (qq >= d.NL * nsg) continue;
-        const int ll = qq / nsg, ss = 32 * ((qq - ll * nsg) * NST) + r;
-        if (ss >= NS) continue;
+        if (qq >= nlg * nsg) continue;
+        const int ll = (qq / nsg) * NLW + lw, ss = 32 * ((qq - (qq / nsg) * nsg) * NST) + r;
+        if (ss >= NS || ll >= d.NL) continue;
         const float *pp = d.part + (int64_t)ll * NS + ss;
         const int64_t cs = (int64_t)d.NL * NS;
         float tot = 0.f;
@@ -282,7 +295,7 @@ bool env_stage_ok() {
 }
 
 struct NLPlan {
-    int eh = 0, nst = 1, m_chunk = 1, n_chunks = 1;
+    int eh = 0, nst = 1, nlw = 1, m_chunk = 1, n_chunks = 1;
     size_t part_bytes = 0;
     dim3 grid;
 };
@@ -301,7 +314,10 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     const int64_t nst_total = (a.NS + 31) / 32;
     p.nst = nst_total >= 4 ? 4 : nst_total >= 2 ? 2 : 1;
     const int64_t nsg = (nst_total + p.nst - 1) / p.nst;
-    const int64_t gx = (a.NL * nsg + 3) / 4;
+    static const int nlw_knob = env_knob("ALAN_NLSE_NLW");                            // tuning knob
+    p.nlw = (p.nst == 1 && a.NL >= 8) ? 2 : 1;
+    if (nlw_knob != ENV_UNSET) p.nlw = (p.nst == 1 && nlw_knob == 2) ? 2 : 1;
+    const int64_t gx = (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
     int64_t target = 768;                                                    // workgroups (x 4 waves)
     static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
     if (blocks_knob != ENV_UNSET) target = std::max(1, blocks_knob);
@@ -359,9 +375,10 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
 #define NL_PICK(EHV, NSTV) (stage ? launch(normal_lse_mfma_kernel<EHV, NSTV, true>) : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
+#define NL_PICK2(EHV) (stage ? launch(normal_lse_mfma_kernel<EHV, 1, true, 2>) : launch(normal_lse_mfma_kernel<EHV, 1, false, 2>))
 #define NL_CASE(EHV)                                                                                   \
     case EHV:                                                                                          \
-        rc = p.nst == 4 ? NL_PICK(EHV, 4) : p.nst == 2 ? NL_PICK(EHV, 2) : NL_PICK(EHV, 1);            \
+        rc = p.nst == 4 ? NL_PICK(EHV, 4) : p.nst == 2 ? NL_PICK(EHV, 2) : p.nlw == 2 ? NL_PICK2(EHV) : NL_PICK(EHV, 1); \
         break;
     switch (p.eh) {
         NL_CASE(4)
@@ -369,9 +386,10 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         NL_CASE(10)
         NL_CASE(12)
         default:
-            rc = p.nst == 4 ? NL_PICK(17, 4) : p.nst == 2 ? NL_PICK(17, 2) : NL_PICK(17, 1);
+            rc = p.nst == 4 ? NL_PICK(17, 4) : p.nst == 2 ? NL_PICK(17, 2) : p.nlw == 2 ? NL_PICK2(17) : NL_PICK(17, 1);
     }
 #undef NL_PICK
+#undef NL_PICK2
 #undef NL_CASE
     if (rc != ALAN_OK) return rc;
     if (d.counters) return ALAN_OK;                   // (the chunks were combined by the launch itself)
