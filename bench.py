@@ -315,10 +315,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not t.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # (rehearsal hook for a one-GPU box: ALAN_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves the partials with
+    # gloo -- the control flow of an N-rank run without N GPUs; never set by the driver)
+    rehearsal = os.environ.get("ALAN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     t.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=t.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=t.device("cuda", local))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr "
@@ -334,7 +342,7 @@ def main():
     prob = build_problem("cuda")
     sample = draw(prob, K)
     strat = strategy_for(world, K)
-    use_graph = not args.eager and os.environ.get("ALAN_BENCH_GRAPH", "1") != "0"
+    use_graph = not args.eager and os.environ.get("ALAN_BENCH_GRAPH", "1") != "0" and not (rehearsal and world > 1)
     if use_graph:
         try:
             dt, elbo = timed_evals(sample, strat, args.steps, args.warmup, world, graph=True)

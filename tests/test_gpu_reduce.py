@@ -696,3 +696,22 @@ def test_large_few_output_reductions_fuzz(seed):
     s_want = x.double().sum(axes) if axes else x.double()
     s_want = s_want.permute([kd.index(n) for n in sd]) if len(kd) > 1 else s_want
     t.testing.assert_close(s_got.double(), s_want, rtol=3e-5, atol=2e-2 * (target / (1 << 21)) ** 0.5)
+
+
+@pytest.mark.gpu
+def test_small_strided_view_into_a_huge_tensor_does_not_wrap_32_bit_offsets():
+    """A 3 x 5 problem whose rows sit 2^30 elements apart inside a tensor of more than 2^31 elements (a strided slice
+    of a K=100 factor has this shape): every stride fits 31 bits, the largest reachable offset does not -- the compact
+    small-problem kernel (32-bit offsets) must decline it and the 64-bit kernel take it."""
+    big = t.empty((1 << 31) + 64, dtype=t.float32, device="cuda")
+    view = big.as_strided((3, 5), (1 << 30, 7))
+    vals = t.randn(3, 5, generator=t.Generator().manual_seed(0))
+    view.copy_(vals.to("cuda"))
+    out, dims = E.reduce_factors([(view, ("a", "k"))], reduce=("k",))
+    want = t.logsumexp(vals.double(), 1)
+    got = out if dims == ("a",) else out
+    t.testing.assert_close(got.cpu().double(), want, rtol=2e-6, atol=2e-6)
+    o2, _ = E.reduce_factors([(view, ("a", "k"))], plate=("a",))            # a SUM over the huge stride
+    t.testing.assert_close(o2.cpu().double(), vals.double().sum(0), rtol=2e-6, atol=2e-6)
+    del big
+    t.cuda.empty_cache()
