@@ -1,36 +1,13 @@
 #!/usr/bin/env python3
-"""Sweeps the rows kernel's launch-geometry knobs (env ALAN_ROWS_RBMAX / ALAN_ROWS_BLOCKS) at the literal
-and scaled S-ML sizes; kernel time from library-recorded HIP events."""
-import math, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch as t
-from alan_amd import engine as E
-from alan_amd.profiling import KernelTimer
-
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-cases = {}
-for M in (300, 300 * 64 if K <= 30 else 600):
-    g = t.Generator(device="cuda").manual_seed(1234)
-    F = -0.5 * t.randn(M, K, K, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
-    gz = -0.5 * t.randn(M, K, device="cuda", generator=g) ** 2 - 0.9189 - math.log(K)
-    cases[M] = [(F, ("m", "a", "b", "z")), (gz, ("m", "z"))]
-grid = [(256, b, 0) for b in (1024, 4096)] + [(128, b, 1) for b in (2048, 8192)] + \
-       [(64, b, 2) for b in (4096, 16384)] + [(32, b, 3) for b in (8192, 32768)]
+"""Sweeps the rows kernel's launch-geometry knobs (ALAN_ROWS_RBMAX / ALAN_ROWS_BLOCKS / ALAN_ROWS_LOGG) at the literal and
+scaled S-ML sizes.  The library reads its knobs once per process, so every setting runs in a process of its own
+(tools/rows_point.py)."""
+import os, subprocess, sys
+K = sys.argv[1] if len(sys.argv) > 1 else "30"
+sizes = ["300", str(300 * 64 if int(K) <= 30 else 600)]
+here = os.path.dirname(os.path.abspath(__file__))
+grid = [(256, b, 0) for b in (600, 1200, 4096)] + [(128, b, 1) for b in (2048, 8192)] + [(64, b, 2) for b in (4096, 16384)]
 for rb, blocks, logg in grid:
-        os.environ["ALAN_ROWS_RBMAX"] = str(rb)
-        os.environ["ALAN_ROWS_BLOCKS"] = str(blocks)
-        os.environ["ALAN_ROWS_LOGG"] = str(logg)
-        line = f"RBMAX={rb:4d} BLOCKS={blocks:5d} LOGG={logg}"
-        for M, fac in cases.items():
-            for _ in range(3):
-                E.reduce_factors(fac, reduce=("z",), plate=("m",))
-            t.cuda.synchronize()
-            with KernelTimer() as kt:
-                for _ in range(20 if M == 300 else 6):
-                    E.reduce_factors(fac, reduce=("z",), plate=("m",))
-                t.cuda.synchronize()
-            ms = sorted(m for _, _, m in kt.results())
-            med = ms[len(ms) // 2]
-            nbytes = 4 * (M * K ** 3 + M * K + K * K)
-            line += f" | M={M}: {med*1e3:8.1f} us {nbytes/med/1e9:6.2f} TB/s"
-        print(line, flush=True)
+    env = dict(os.environ, ALAN_ROWS_RBMAX=str(rb), ALAN_ROWS_BLOCKS=str(blocks), ALAN_ROWS_LOGG=str(logg))
+    out = subprocess.run([sys.executable, os.path.join(here, "rows_point.py"), K, *sizes], env=env, capture_output=True, text=True)
+    print("\n".join(l for l in out.stdout.splitlines() if "K=" in l), flush=True)
