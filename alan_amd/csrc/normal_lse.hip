@@ -55,7 +55,13 @@ constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530
 
 // NLW: loc rows per wave (2 when one scale tile covers all scale rows, K <= 32: the value tile's loads, its LDS
 // stage and the small-factor sum are then shared by two tiles of work -- 110 of the 250 instructions of a tile).
-template <int EH, int NST, bool STAGE, int NLW = 1>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
+// RAG: the last of the wave's NST scale tiles holds at most 16 scale rows (K = 100: 3 full tiles + 4 rows): it is
+// computed as two 16 x 16 blocks by v_mfma_f32_16x16x4_f32 -- half the matrix time and half the exps of a 32 x 32 tile
+// that would be 7/8 padding.  (STAGE only: its A operand has the event index spread over the four lane quarters and is
+// read from the wave's LDS tile.)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int EH, int NST, bool STAGE, int NLW = 1, bool RAG = false>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
 __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +104,28 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             const float x = d.loc[(int64_t)min(l + lw, d.NL - 1) * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
             mreg[lw][step] = e < E ? x : 0.f;
         }
+    // RAG: operands of the 16-wide tile -- lane (r16 = lane & 15, q4 = lane >> 4) holds column s16 of B and event 4 t + q4
+    constexpr int T16 = (EH + 1) / 2;                 // K = 4 steps covering the same 2 EH event slots
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int s16 = 32 * (sg * NST + NST - 1) + r16;
+    float b16[T16], m16[T16], lgn16 = 0.f;
+    if (RAG) {
+        const bool ok = s16 < NS;
+        float lg = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < T16; ++tt) {
+            const int e = 4 * tt + q4;
+            const float x = d.scl[(int64_t)min(s16, NS - 1) * d.s_ss + (int64_t)min(e, E - 1) * d.s_se];
+            const float w = d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x);
+            b16[tt] = (ok && e < E) ? w * NL_LOG2E : (ok && e == E) ? NL_LOG2E : 0.f;
+            lg += e < E ? (d.log_scale ? x : logf(x)) : 0.f;
+            const float mu = d.loc[(int64_t)min(l, d.NL - 1) * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
+            m16[tt] = e < E ? mu : 0.f;
+        }
+        lg += __shfl_xor(lg, 16);
+        lg += __shfl_xor(lg, 32);
+        lgn16 = lg + (float)E * 0.91893853320467274178f;
+    }
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
     const int n_tiles = wave_on ? (m1 - m0) * nkt : 0;
     // Tile t = (plate element m0 + t / nkt, k tile t % nkt), walked with counters (no division in the loop).  Everything
@@ -180,8 +208,36 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             for (int step = 0; step < EH; ++step) zv[step] = zc[step];
         }
         const float slot = k_ok ? -hsum : inf;
+        if (RAG) {
+            // the 16-wide tile: rows 16 b + r16 of the k tile, events 4 t + q4 (slot E carries the small factors)
+            constexpr int u = NU - 1;
+            float tmin = inf;
+            f32x4v acc4[2];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
+            for (int b = 0; b < 2; ++b) {
+                const float hsb = __shfl(slot, 16 * b + r16);           // (slot is per k row: lanes j = row, either half)
+                acc4[b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tt = 0; tt < T16; ++tt) {
+                    const int e = 4 * tt + q4;
+                    const float df = tile[(16 * b + r16) * (E + 1) + min(e, E - 1)] - m16[tt];
+                    const float av = e == E ? hsb : df * df;
+                    acc4[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b16[tt], acc4[b], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmin = fminf(tmin, acc4[b][r]);
+            }
+            const float mnew = fminf(mn[u], tmin);
+            const float mf = mnew == inf ? 0.f : mnew;
+            float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc4[b][r]);
+            mn[u] = mnew, sm[u] = ssum;
+        }
+#pragma unroll
+        for (int u = 0; u < NU - (RAG ? 1 : 0); ++u) {
             const int lw = u / NST, st = u - lw * NST;
             if (st == 0) {
 #pragma unroll
@@ -209,8 +265,26 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             mn[u] = mnew, sm[u] = ssum;
         }
         if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
+            if (RAG) {                                // (the 16-wide tile's rows are spread over the four lane quarters)
+                constexpr int u = NU - 1;
+                float mm = mn[u], tot = sm[u];
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float mn2 = __shfl_xor(mm, o), sm2 = __shfl_xor(tot, o);
+                    const float mx = fminf(mm, mn2);
+                    const float mf = mx == inf ? 0.f : mx;
+                    tot = tot * __builtin_amdgcn_exp2f(mf - (mm == inf ? mf : mm)) +
+                          sm2 * __builtin_amdgcn_exp2f(mf - (mn2 == inf ? mf : mn2));
+                    mm = mx;
+                }
+                float lse_m = logf(tot + Num<float>::eps) - mm * NL_LN2 - lgn16;
+                if (mm == inf || mm == -inf) lse_m = __builtin_nanf("");
+                accm[u] += lse_m;
+                if (d.lse && lane < 16 && s16 < NS) d.lse[((int64_t)m * d.NL + l) * NS + s16] = lse_m;
+                mn[u] = inf, sm[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < NU - (RAG ? 1 : 0); ++u) {
                 const int lw = u / NST, st = u - lw * NST;
                 const float mn2 = __shfl_xor(mn[u], 32), sm2 = __shfl_xor(sm[u], 32);
                 const float mm = fminf(mn[u], mn2);
@@ -233,11 +307,12 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NU - (RAG ? 1 : 0); ++u) {
         const int lw = u / NST, st = u - lw * NST;
         const int s = 32 * (sg * NST + st) + j;
         if (wave_on && h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.y * d.NL + l + lw) * NS + s] = accm[u];
     }
+    if (RAG && wave_on && lane < 16 && s16 < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s16] = accm[NU - 1];
     if (!d.counters) return;
     // ---- the chunks of the plate are combined in this launch: the workgroup that arrives LAST at its column's
     // counter adds them up, in chunk order (deterministic).  Agent-scope release / acquire as the inter-workgroup
@@ -296,6 +371,7 @@ bool env_stage_ok() {
 
 struct NLPlan {
     int eh = 0, nst = 1, nlw = 1, m_chunk = 1, n_chunks = 1;
+    bool rag = false;
     size_t part_bytes = 0;
     dim3 grid;
 };
@@ -317,6 +393,9 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     static const int nlw_knob = env_knob("ALAN_NLSE_NLW");                            // tuning knob
     p.nlw = (p.nst == 1 && a.NL >= 8) ? 2 : 1;
     if (nlw_knob != ENV_UNSET) p.nlw = (p.nst == 1 && nlw_knob == 2) ? 2 : 1;
+    // the last scale tile as a 16-wide one: a single group of tiles whose last holds at most 16 rows (NS = 100: 4)
+    static const int rag_knob = env_knob("ALAN_NLSE_RAG");                            // ablation knob: 0 = off
+    p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16 && rag_knob != 0;
     const int64_t gx = (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
     int64_t target = 768;                                                    // workgroups (x 4 waves)
     static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
@@ -366,6 +445,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     }
     // the staged variant needs the tile's 32 rows to be one contiguous run of the value tensor
     const bool stage = a->v_se == 1 && a->v_sk == a->E && env_stage_ok();
+    const bool rag = p.rag && stage;
     const size_t lds = 4 * 32 * 33 * sizeof(float) + 16;          // the waves' value tiles + the combine's flag
     d.counters = (int32_t *)a->counters;
     d.out = (float *)a->out, d.o_sl = a->o_sl, d.o_ss = a->o_ss, d.add_const = (float)a->add_const;
@@ -374,7 +454,8 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
-#define NL_PICK(EHV, NSTV) (stage ? launch(normal_lse_mfma_kernel<EHV, NSTV, true>) : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
+#define NL_PICK(EHV, NSTV) (rag && NSTV > 1 ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1)>) \
+                            : stage ? launch(normal_lse_mfma_kernel<EHV, NSTV, true>) : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
 #define NL_PICK2(EHV) (stage ? launch(normal_lse_mfma_kernel<EHV, 1, true, 2>) : launch(normal_lse_mfma_kernel<EHV, 1, false, 2>))
 #define NL_CASE(EHV)                                                                                   \
     case EHV:                                                                                          \

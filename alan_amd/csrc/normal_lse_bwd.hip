@@ -296,16 +296,19 @@ __global__ __launch_bounds__(256) void nlb_colsum_kernel(ColSeg a, ColSeg b) {
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
     if (blockIdx.x * 16 >= sg.C) return;
-    float acc0 = 0.f, acc1 = 0.f;
+    float acc = 0.f;
     if (c < sg.C) {
         int p = ry;
-        for (; p + 16 < sg.P; p += 32) {
-            acc0 += sg.part[(int64_t)p * sg.C + c];
-            acc1 += sg.part[(int64_t)(p + 16) * sg.C + c];
+        for (; p + 16 * 7 < sg.P; p += 16 * 8) {               // eight loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sg.part[(int64_t)(p + 16 * u) * sg.C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        if (p < sg.P) acc0 += sg.part[(int64_t)p * sg.C + c];
+        for (; p < sg.P; p += 16) acc += sg.part[(int64_t)p * sg.C + c];
     }
-    red[ry][cx] = acc0 + acc1;
+    red[ry][cx] = acc;
     __syncthreads();
     if (ry == 0 && c < sg.C) {
         float t = 0.f;
@@ -358,7 +361,9 @@ int plan_nlb(const alan_normal_lse_backward_desc_t &b, NLBPlan &p) {
     // workgroups: one per (plate element, k tile), times gy shares of the loc rows so that the chip is covered
     const int64_t base = a.M * p.nkt;
     if (base * 64 >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
-    int64_t gy = std::max<int64_t>(1, (768 + base - 1) / base);
+    // (one share unless the plate is short: every share adds a row of partials to the column sums and the loc-share
+    // add launch -- at K=30, M=300 one share is 39 + 4 us, three are 37 + 10 + 4)
+    int64_t gy = std::max<int64_t>(1, (256 + base - 1) / base);
     static const int gy_knob = env_knob("ALAN_NLB_GY");                       // tuning knob
     if (gy_knob != ENV_UNSET) gy = std::max(1, gy_knob);
     gy = std::min<int64_t>(gy, (a.NL + 3) / 4);
