@@ -353,7 +353,6 @@ static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunc
         if (split_long_dim(d, keep, red, plate, d2)) return false;
     }
     mode = d.mode;
-    if (mode == ALAN_MODE_WEXPSUM) return false;
     if (mode == ALAN_MODE_LSE && red == 0) mode = ALAN_MODE_SUM;
     Canon c;
     if (canonicalise(d, keep, red, d.out, c) != ALAN_OK) return false;

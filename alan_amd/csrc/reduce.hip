@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
         case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE>(d, logG, block, bid); break;
         case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
         case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
-        default: break;                                                    // (WEXPSUM is not batched)
+        case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM>(d, logG, block, bid); break;   // (per-factor backward launches)
+        default: break;
     }
 }
 

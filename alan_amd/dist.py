@@ -76,8 +76,10 @@ class _FusedNormalLogProb(t.autograd.Function):
         vd, ld, sd, od, log_scale, affine = ctx.spec
         value, loc, scale = ctx.saved_tensors
         ids = lambda ds: {id(d) for d in ds}
-        outer = OUTER_BACKWARD and not (ids(vd) & ids(ld)) and not (ids(vd) & ids(sd)) and not (ids(ld) & ids(sd)) \
-            and ids(od) == ids(vd) | ids(ld) | ids(sd)
+        # (the GEMM formulation is for the big cross-product factor: loc and scale both carry dims of their own; a prior
+        # with constant parameters is a small factor and takes the producer-gradient kernels below)
+        outer = OUTER_BACKWARD and ids(ld) and ids(sd) and not (ids(vd) & ids(ld)) and not (ids(vd) & ids(sd)) \
+            and not (ids(ld) & ids(sd)) and ids(od) == ids(vd) | ids(ld) | ids(sd)
         if HIP_PRODUCER_BACKWARD and G.is_cuda and not outer:
             from . import engine as E
             from . import native as N
@@ -309,13 +311,22 @@ class TorchDimDist:
         extra = [d for d in sample_dims if id(d) not in have]
         d = self._build(self.all_arg_ids)
         shape = t.Size([*sample_shape, *[e.size for e in extra]])
+
+        def draw():
+            if self.dist is td.Normal:
+                # loc + eps * scale as ONE kernel (and one backward node) instead of rsample's two: a training
+                # iteration is bound by its count of small launches
+                eps = t.empty(d._extended_shape(shape), dtype=d.loc.dtype, device=d.loc.device).normal_()
+                return t.addcmul(d.loc, eps, d.scale)
+            return d.rsample(shape)
+
         if reparam:
-            x = d.rsample(shape)
+            x = draw()
         elif self.dist.has_rsample:
             # same distribution as .sample(), but e.g. Normal.sample() calls torch.normal(mean, std), whose
             # std >= 0 check synchronises with the device and cannot be captured into a HIP graph
             with t.no_grad():
-                x = d.rsample(shape)
+                x = draw()
         else:
             x = d.sample(shape)
         ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)

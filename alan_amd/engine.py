@@ -144,19 +144,24 @@ class _Reduce(t.autograd.Function):
             if fused is not None:
                 return (None, *fused)
         grads = []
-        for i, (x, dims) in enumerate(factors):
-            if not need[i]:
-                grads.append(None)
-                continue
-            g = t.empty(x.shape, dtype=x.dtype, device=x.device)
-            roles = {d: (N.KEEP if d in dims else N.REDUCE) for d in sizes}
-            if ctx.has_lse:
-                lse = saved[nf]
-                _launch(N.MODE_WEXPSUM, factors + [(lse, ctx.lse_dims)], sizes, roles, g, dims,
-                        weight=(grad_out, out_dims), scales=[1.0] * nf + [-1.0])
-            else:
-                _launch(N.MODE_SUM, [(grad_out, out_dims)], sizes, roles, g, dims)
-            grads.append(g)
+        # the wanted gradients are independent problems: small ones leave as ONE multi-problem launch
+        # (alan_reduce_batch; the queue is flushed when the block ends, before anyone can read a gradient)
+        import contextlib
+        batch = contextlib.nullcontext() if t.is_grad_enabled() else N.deferring()
+        with batch, N.may_defer():
+            for i, (x, dims) in enumerate(factors):
+                if not need[i]:
+                    grads.append(None)
+                    continue
+                g = t.empty(x.shape, dtype=x.dtype, device=x.device)
+                roles = {d: (N.KEEP if d in dims else N.REDUCE) for d in sizes}
+                if ctx.has_lse:
+                    lse = saved[nf]
+                    _launch(N.MODE_WEXPSUM, factors + [(lse, ctx.lse_dims)], sizes, roles, g, dims,
+                            weight=(grad_out, out_dims), scales=[1.0] * nf + [-1.0])
+                else:
+                    _launch(N.MODE_SUM, [(grad_out, out_dims)], sizes, roles, g, dims)
+                grads.append(g)
         return (None, *grads)
 
 
