@@ -44,6 +44,9 @@ struct SmallDesc {
     int32_t fks[MAXF][SMALL_NK], frs[MAXF][SMALL_NR];
     int32_t wks[SMALL_NK], wrs[SMALL_NR], oks[SMALL_NK];
     float fscale[MAXF];
+    float *const *ring_slots;      // result ring (alan_reduce_desc_t.ring_*); ring_n = 0: off
+    int32_t *ring_counter;
+    int32_t ring_n;
 };
 
 struct GroupLaunch {
@@ -78,6 +81,9 @@ int canonicalise(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t red_m
 // of a call, so the events carry that kernel's own start / stop timestamps (what rocprofv3 reports).
 struct EvPair {
     hipEvent_t start = nullptr, stop = nullptr;
+    // result ring of the call (alan_reduce_desc_t.ring_*): only the single-workgroup small kernel honours it
+    void *ring_slots = nullptr, *ring_counter = nullptr;
+    int ring_n = 0;
 };
 int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl,
                float out_scale = 1.f);

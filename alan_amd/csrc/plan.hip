@@ -222,6 +222,12 @@ static int run_single(const alan_reduce_desc_t &d, uint32_t keep_mask, uint32_t 
     const bool producer = mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE || mode == ALAN_MODE_BERNOULLI ||
                           mode == ALAN_MODE_PRODUCER_GRAD;
     const float out_scale = producer ? out.scale : 1.f;
+    if (ev.ring_n) {                     // result ring: the single-workgroup small kernel or nothing
+        GroupDesc gd;
+        GroupLaunch gl;
+        rc = plan_group(c, out.dtype, add_const, gd, gl, out_scale);
+        return rc != ALAN_OK ? rc : try_launch_small(c, gd, gl, mode, compute, stream, ev);
+    }
     if (mode == ALAN_MODE_NORMAL || mode == ALAN_MODE_NORMAL_LOGSCALE) {
         rc = try_launch_normal_outer(c, mode == ALAN_MODE_NORMAL_LOGSCALE, out_scale, add_const, stream, ev);
         if (rc != ALAN_ERR_UNSUPPORTED) return rc;
@@ -456,6 +462,16 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     ev.start = (hipEvent_t)d->ev_start;
     ev.stop = (hipEvent_t)d->ev_stop;
 
+    if (d->ring_n) {
+        if (d->ring_n < 0 || !d->ring_slots || !d->ring_counter) return ALAN_ERR_BAD_DESC;
+        // one launch writing one value: no plate stage, no workspace (i.e. no two-stage plan), no long-dim split
+        alan_reduce_desc_t d2;
+        if (plate || alan_reduce_workspace_bytes(d) != 0 || split_long_dim(*d, keep, red, plate, d2))
+            return ALAN_ERR_UNSUPPORTED;
+        ev.ring_slots = d->ring_slots;
+        ev.ring_counter = d->ring_counter;
+        ev.ring_n = d->ring_n;
+    }
     if (d->mode == ALAN_MODE_LSE && red == 0) {
         // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,
         // followed by the plate sum if any.
@@ -528,5 +544,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 2; }
+extern "C" int alan_abi_version(void) { return 3; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

@@ -286,7 +286,14 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
         if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI ||
             MODE == ALAN_MODE_PRODUCER_GRAD)
             v *= d.out_scale;
-        d.out[obase] = v + d.add_const;
+        if (d.ring_n) {
+            // one workgroup, one value (try_launch_small checked): deliver it to this replay's slot and move on
+            const int32_t slot = *d.ring_counter;
+            *d.ring_slots[slot] = v + d.add_const;
+            *d.ring_counter = slot + 1 == d.ring_n ? 0 : slot + 1;
+        } else {
+            d.out[obase] = v + d.add_const;
+        }
     }
 }
 
@@ -446,6 +453,12 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
     SmallDesc sd;
     const int rc = build_small(c, gd, mode, compute_dtype, sd);
     if (rc != ALAN_OK) return rc;
+    if (ev.ring_n) {
+        if (gd.n_out != 1 || gl.grid != 1) return ALAN_ERR_UNSUPPORTED;
+        sd.ring_slots = (float *const *)ev.ring_slots;
+        sd.ring_counter = (int32_t *)ev.ring_counter;
+        sd.ring_n = ev.ring_n;
+    }
     if (gd.n_out == 0) return ALAN_OK;
     switch (mode) {
         case ALAN_MODE_LSE: launch_small_T<ALAN_MODE_LSE>(sd, gl, stream, ev); break;

@@ -135,14 +135,14 @@ def _chain_of_terms(lps, Ks, core):
     return PT(vec if batch else vec[0], (*batch, core[1]))
 
 
-def _contract(lps, Ks, plate=()):
+def _contract(lps, Ks, plate=(), final=False):
     fused = _fused_plate_step(lps, Ks, plate)
     if fused is not None:
         return fused
     for lp in lps:
         # "There shouldn't be any non-torchdim dimensions" (reduce_Ks.py:13-14)
         assert lp.n_pos == 0, "log-prob factors must have no positional dims"
-    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], tuple(Ks), plate=tuple(plate))
+    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], tuple(Ks), plate=tuple(plate), final=final)
     return PT(out, dims)
 
 
@@ -216,7 +216,7 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
         groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy, dimcache)
 
     if name is None:
-        return _contract(lps, Ks)
+        return _contract(lps, Ks, final=True)
 
     if K_inits:
         # timeseries plate (logpq.py:131-143): eliminate the ordinary Ks, then the chain over T

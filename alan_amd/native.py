@@ -58,6 +58,9 @@ class ReduceDesc(C.Structure):
         ("add_const", C.c_double),
         ("ev_start", C.c_void_p),
         ("ev_stop", C.c_void_p),
+        ("ring_slots", C.c_void_p),
+        ("ring_counter", C.c_void_p),
+        ("ring_n", C.c_int32),
     ]
 
 
@@ -267,8 +270,11 @@ def flush():
 
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
+    """Enqueue one alan_reduce call.  False only for a call with a result ring (desc.ring_n) that the library declines
+    -- nothing was enqueued, the caller launches again without the ring."""
     L = lib()
     if (DEFER_SMALL_LAUNCHES and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
+            and not desc.ring_n
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
             and (not _Q.pending or _Q.pending[0][1] == device)):
         if _POISON_QUEUED and len(keepalive) > 1 and keepalive[1] is not None:
@@ -276,7 +282,7 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
         _Q.pending.append((desc, device, keepalive))
         if len(_Q.pending) >= 8:
             flush()
-        return
+        return True
     flush()
     if _TIMER[0] is not None:
         _TIMER[0].attach(desc, algo_bytes)
@@ -284,7 +290,10 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
     rc = L.alan_reduce(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes,
                        current_stream(device))
+    if rc == ERR_UNSUPPORTED and desc.ring_n:
+        return False
     check(rc, "alan_reduce")
+    return True
 
 
 ERR_UNSUPPORTED = -2

@@ -17,6 +17,11 @@ AUTO_GRAPH = True
 graph from the third call on (see Sample.elbo_nograd).  False: such calls always launch kernel by kernel."""
 
 
+RESULT_RING = True
+"""A captured evaluation delivers its result through engine.ResultRing (no copy out of the graph's output buffer after
+each replay).  False: every call returns a clone of that buffer."""
+
+
 def _detach_tree(tree):
     return {k: (_detach_tree(v) if isinstance(v, dict) else v.detach()) for k, v in tree.items()}
 
@@ -28,10 +33,15 @@ def _pt_tree(tree):
 class _GraphedELBO:
     """One captured elbo_nograd evaluation (HIP graph), replayed on call."""
 
-    def __init__(self, sample, strategy):
+    def __init__(self, sample, strategy, ring=True):
         self.strategy = strategy
         from . import native as N
+        from . import engine as E
+        from .training import check_no_memset_nodes
         timer, N._TIMER[0] = N._TIMER[0], None       # event records must not be captured
+        device = t.device("cuda", t.cuda.current_device())
+        self.ring = E.ResultRing.create(device) if (ring and RESULT_RING) else None
+        E._RING[0] = self.ring
         try:
             side = t.cuda.Stream()
             side.wait_stream(t.cuda.current_stream())
@@ -40,21 +50,37 @@ class _GraphedELBO:
                     sample._elbo(sample._pt_detached, None, strategy)
             t.cuda.current_stream().wait_stream(side)
             t.cuda.synchronize()
+            if self.ring is not None:
+                self.ring.taken = 0
             self.graph = t.cuda.CUDAGraph(keep_graph=True)
             # thread_local: a collective's watchdog thread must not invalidate the capture
             with t.cuda.graph(self.graph, capture_error_mode="thread_local"), t.no_grad():
                 self.out = sample._elbo(sample._pt_detached, None, strategy)
-            from .training import check_no_memset_nodes
             # (a sharded Split's graph holds RCCL's own nodes: whatever the collective captures is its business --
             # the guard is about torch's multi-block reductions)
             if not getattr(strategy, "sharded", lambda: False)():
                 check_no_memset_nodes(self.graph, "Sample.elbo_nograd(graph=True)")
         finally:
             N._TIMER[0] = timer
+            E._RING[0] = None
+        if self.ring is not None:
+            taken = self.ring.taken
+            if taken == 1 and self.out is self.ring.placeholder:
+                self.ring.sync_position()
+            elif taken == 0:
+                self.ring = None                      # the last launch could not take it: results are copied out
+            else:
+                # the ring's value is not the evaluation's result (something was computed from it afterwards):
+                # capture again without
+                self.__init__(sample, strategy, ring=False)
 
     def __call__(self):
+        if self.ring is None:
+            self.graph.replay()
+            return self.out.clone()
+        slot = self.ring.claim()
         self.graph.replay()
-        return self.out.clone()
+        return slot.detach()
 
 
 def strategy_key(strategy):

@@ -104,6 +104,14 @@ typedef struct {
     void *ev_start, *ev_stop;             /* optional hipEvent_t pair (NULL = off): recorded on `stream` immediately
                                              before / after the DOMINANT kernel of this call (the one that streams the
                                              largest factor), so a caller can time that kernel alone (bench.py) */
+    /* Optional result ring (ring_n = 0: off), for a call that is REPLAYED from a HIP graph and produces ONE fp32
+     * value.  ring_slots: device array of ring_n float*; ring_counter: device int32 in [0, ring_n).  The launch writes
+     * its value through ring_slots[*ring_counter] instead of `out` and then advances the counter (mod ring_n), so
+     * consecutive replays of one graph deliver their results to different addresses and the caller need not copy a
+     * result out before the next replay.  ALAN_ERR_UNSUPPORTED (nothing enqueued) unless the call is one
+     * single-workgroup launch. */
+    void *ring_slots, *ring_counter;
+    int32_t ring_n;
 } alan_reduce_desc_t;
 
 /* Bytes of scratch alan_reduce() needs for this descriptor (0 is possible). */

@@ -467,6 +467,64 @@ def test_plain_elbo_nograd_calls_promote_to_a_replayed_graph():
 
 
 @pytest.mark.gpu
+def test_replayed_results_are_delivered_through_the_ring_and_outlive_their_slot():
+    """A captured evaluation hands out the ring slot its last launch wrote (no copy kernel): the value equals the
+    copied-out one; results, views and detach()es held for more than SLOTS further calls keep their values (the slot
+    is given fresh memory instead); and the slot order survives that."""
+    from alan_amd import sample as S, engine as E
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda").float()          # (the fixture's observations are fp64)
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+    ref = float(fx["elbo"]["no_checkpoint"])
+    g = S._GraphedELBO(sample, alan.no_checkpoint)
+    assert g.ring is not None and g.out is g.ring.placeholder
+    plain = S._GraphedELBO(sample, alan.no_checkpoint, ring=False)
+    assert plain.ring is None
+    n = E.ResultRing.SLOTS
+    first = g()
+    assert first.shape == () and first.dtype == t.float32
+    assert float(first) == float(plain())
+    assert abs(float(first) - ref) <= 1e-4 * abs(ref)
+    held = {"tensor": g(), "view": g().view(1), "detached": g().detach(), "item": g()[None]}
+    want = {k: float(v) for k, v in held.items()}
+    with t.no_grad():
+        for p in prob.Q.parameters():
+            p.add_(0.05)
+    later = [float(g()) for _ in range(3 * n + 5)]             # every slot comes round three times
+    assert all(v == later[0] for v in later) and abs(later[0] - want["tensor"]) > 1e-3 * abs(later[0])
+    assert float(plain()) == later[0]
+    assert {k: float(v) for k, v in held.items()} == want
+    assert float(first) == want["tensor"]
+    # a result that is dropped gives its slot back: no new memory on the way round
+    ptrs = [s.data_ptr() for s in g.ring.slots]
+    for _ in range(2 * n):
+        g()
+    assert [s.data_ptr() for s in g.ring.slots] == ptrs
+    # the host's idea of the position matches the device counter
+    t.cuda.synchronize()
+    assert int(g.ring.counter) == g.ring.pos
+
+
+@pytest.mark.gpu
+def test_ring_is_declined_for_results_that_are_not_one_fp32_value_from_one_workgroup():
+    from alan_amd import sample as S
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda")
+    sample = models.sample_from_fixture(prob, fx, "cuda")
+    assert S._GraphedELBO(sample, alan.no_checkpoint).ring is None        # fp64 observations: an fp64 result
+    prob.double()
+    from alan_amd.dims import PT
+
+    def dbl(tree):
+        return {k: (dbl(v) if isinstance(v, dict) else PT(v.x.double(), v.dims)) for k, v in tree.items()}
+
+    sample._pt_detached = dbl(sample._pt_detached)
+    g = S._GraphedELBO(sample, alan.no_checkpoint)
+    assert g.ring is None                                       # fp64 evaluation: copied out as before
+    assert g().dtype == t.float64
+
+
+@pytest.mark.gpu
 def test_plain_elbo_nograd_stays_eager_when_the_evaluation_cannot_be_captured():
     """MultivariateNormal.log_prob synchronises with the host: capture fails, the call quietly stays eager."""
     small = load_golden("e2e_small_models.pt")

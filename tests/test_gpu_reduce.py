@@ -715,3 +715,45 @@ def test_small_strided_view_into_a_huge_tensor_does_not_wrap_32_bit_offsets():
     t.testing.assert_close(o2.cpu().double(), vals.double().sum(0), rtol=2e-6, atol=2e-6)
     del big
     t.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_result_ring_c_abi_delivers_to_successive_slots_and_declines_other_shapes():
+    """alan_reduce_desc_t.ring_*: a one-value, one-workgroup call writes through ring_slots[*ring_counter] and advances
+    the counter modulo ring_n, leaving ``out`` alone; calls with several outputs, a plate stage or a two-launch plan
+    return ALAN_ERR_UNSUPPORTED having enqueued nothing; malformed rings are ALAN_ERR_BAD_DESC."""
+    g = t.Generator().manual_seed(3)
+    a = t.randn(30, 30, generator=g).cuda()
+    b = t.randn(30, generator=g).cuda()
+    ring = E.ResultRing(a.device)
+    sizes = {"i": 30, "j": 30}
+    roles = {"i": N.REDUCE, "j": N.REDUCE}
+    want = float(t.logsumexp((a.double() + b.double()[None, :]).reshape(-1), 0)) + 1.5
+    out = t.full((), 7.0, device="cuda")
+    for call in range(ring.n + 3):
+        assert E._launch(N.MODE_LSE, [(a, ("i", "j")), (b, ("j",))], sizes, roles, out, (), add_const=1.5, ring=ring)
+        t.cuda.synchronize()
+        assert int(ring.counter) == (call + 1) % ring.n
+        assert abs(float(ring.slots[call % ring.n]) - want) <= 2e-6 * abs(want)
+        ring.slots[call % ring.n].zero_()
+    assert float(out) == 7.0
+    assert all(float(s) == 0.0 for s in ring.slots)
+    # several outputs / a plate stage / a long reduce dim that is split into two launches: declined, nothing written
+    keep = t.empty(30, device="cuda")
+    assert not E._launch(N.MODE_LSE, [(a, ("i", "j"))], sizes, {"i": N.KEEP, "j": N.REDUCE}, keep, ("i",), ring=ring)
+    assert not E._launch(N.MODE_LSE, [(a, ("i", "j"))], sizes, {"i": N.PLATE, "j": N.REDUCE}, out, (), ring=ring)
+    long = t.randn(1 << 20, generator=g).cuda()
+    assert not E._launch(N.MODE_LSE, [(long, ("n",))], {"n": 1 << 20}, {"n": N.REDUCE}, out, (), ring=ring)
+    t.cuda.synchronize()
+    assert int(ring.counter) == 3 and float(out) == 7.0 and all(float(s) == 0.0 for s in ring.slots)
+    # SUM mode takes the ring too
+    assert E._launch(N.MODE_SUM, [(a, ("i", "j"))], sizes, roles, out, (), ring=ring)
+    t.testing.assert_close(ring.slots[3].cpu().double(), a.double().sum().cpu(), rtol=1e-5, atol=1e-4)
+    # malformed: slots without a counter
+    d = N.ReduceDesc()
+    d.mode, d.ndim, d.n_factors = N.MODE_LSE, 1, 1
+    d.size[0], d.role[0] = 30, N.REDUCE
+    N.fill_tensor(d.factor[0], b, [1])
+    N.fill_tensor(d.out, out, [0])
+    d.ring_slots, d.ring_n = ring.table.data_ptr(), ring.n
+    assert N.lib().alan_reduce(ctypes.byref(d), None, 0, None) == -1

@@ -25,14 +25,14 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 2
+    assert L.alan_abi_version() == 3
     assert L.alan_build_target() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
     # alan_tensor_t: ptr(8) + int32 + float + 8*int64 ; alan_reduce_desc_t per the header
     assert ctypes.sizeof(N.Tensor) == 8 + 4 + 4 + 8 * N.MAX_DIMS
-    expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8 + 16
+    expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8 + 16 + (8 + 8 + 4 + 4)
     assert ctypes.sizeof(N.ReduceDesc) == expect
     assert ctypes.sizeof(N.BackwardDesc) == expect + ctypes.sizeof(N.Tensor) * N.MAX_FACTORS
 
