@@ -32,6 +32,8 @@ struct NormalDesc {
     int32_t vstage_off;               // LDS offset (floats) of the value staging area
     float out_scale, add_const;       // out = out_scale * log_prob + add_const
     uint32_t out_bytes;               // bytes spanned by out (MFMA kernel: buffer descriptor range)
+    uint32_t ts_nk;                   // MFMA kernel, transposed stores: size of the value's innermost dim (a wave owns
+                                      // one index of the outer value dims); 0 = lanes store their own rows
     int64_t l_rs, s_rs;               // row strides of loc / scale (elements)
     int64_t l_os, s_os;               // out strides along the loc / scale dims
     FastDiv vdiv[MAXD];
@@ -208,11 +210,21 @@ __global__ __launch_bounds__(256) void normal_outer_kernel(const NormalDesc d) {
 // the output's contiguous dim in the plate step (K_z), so each store instruction writes two runs of up to 128 bytes.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int EH, int NST>      // EH = ceil(E / 2) MFMA steps; NST = tiles of 32 scale rows
+//
+// TS (transposed stores; NST = 1): when the value's innermost dim kz (<= 32 long) is also the output's, with the scale
+// dim next (the plate step's F[plate_1, K_mu, K_psi, K_z]), the [NS, kz] block a wave produces per loc row is ONE
+// contiguous run of the output.  The wave then owns exactly one index of the outer value dims (lanes = kz), passes
+// the tile through a private 4 KB of LDS in the output's own order and writes it with 16 bytes per lane: 4 store
+// instructions of up to 1 KB each instead of 16 of 2 x 120 bytes whose rows straddle cache lines.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EH, int NST, bool TS>      // EH = ceil(E / 2) MFMA steps; NST = tiles of 32 scale rows
 __global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
     constexpr int EP = 2 * EH, NSP = 32 * NST;
+    static_assert(!TS || NST == 1, "transposed stores: one scale tile");
     __shared__ float wt[NSP * EP];            // 0.5 / scale^2, zero padded to [NSP][EP]
     __shared__ float lgt[NSP * EP];           // log scale, zero padded; lgt[s * EP] becomes the row's log-normaliser
+    __shared__ __align__(16) float tbuf[TS ? 4 * 1024 : 4];   // TS: a [NS][kz] tile per wave
     extern __shared__ __align__(16) float mut[];   // [l_chunk][EP] this workgroup's loc rows, zero padded
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -245,10 +257,19 @@ __global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
     __syncthreads();
     if (tid < NSP) lgt[tid * EP] = rowsum + (float)E * 0.91893853320467274178f;
     __syncthreads();
-    const uint32_t v0 = (blockIdx.x * 4u + wave) * 32u;
-    if (v0 >= d.NV) return;                   // (no barriers below)
-    const uint32_t vr = v0 + j;
-    const bool active = vr < d.NV;
+    uint32_t vr;
+    bool active;
+    if (TS) {
+        const uint32_t w = blockIdx.x * 4u + wave;             // index over the outer value dims
+        if (w * d.ts_nk >= d.NV) return;
+        vr = w * d.ts_nk + (uint32_t)j;
+        active = (uint32_t)j < d.ts_nk;
+    } else {
+        const uint32_t v0 = (blockIdx.x * 4u + wave) * 32u;
+        if (v0 >= d.NV) return;                   // (no barriers below)
+        vr = v0 + j;
+        active = vr < d.NV;
+    }
     int64_t voff = 0, ooff = 0;
     {
         uint32_t o = active ? vr : d.NV - 1u;
@@ -296,6 +317,10 @@ __global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
     const uint32_t OOB = 0x80000000u;          // >= the descriptor's range with or without the SGPR offset added (out spans < 2 GiB)
     const uint32_t lane_boff = active ? (uint32_t)(ooff + 4 * h * d.s_os) * 4u : OOB;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, (int)d.out_bytes, 0x00020000);
+    // TS: the wave's block of the output starts at lane 0's element (kz = 0); n4 16-byte pieces, lane + 64 q each
+    float *tb = tbuf + (TS ? wave * 1024 : 0);
+    const uint32_t wave_boff = TS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)ooff * 4u)) : 0u;
+    const uint32_t n4 = TS ? (d.NS * d.ts_nk) >> 2 : 0u;
     for (uint32_t il = l0; il < l1; ++il) {
         const float *lp = mut + (size_t)(il - l0) * EP + h;
         float dd[EH];
@@ -321,6 +346,24 @@ __global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) q += acc[r];
                 if (q == 12345.678f) d.out[0] = q;
+            } else if (TS) {
+                const int rows_ok = (int)d.NS - 4 * h;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();               // the previous tile's reads are issued (LDS is in order)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2);
+                    if (active && row < rows_ok) tb[(row + 4 * h) * (int)d.ts_nk + j] = -acc[r] * d.out_scale + d.add_const;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t blk = wave_boff + (uint32_t)((int64_t)il * d.l_os) * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i4 = (uint32_t)lane + 64u * q;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(tb + 4 * (i4 < n4 ? i4 : 0u));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, i4 < n4 ? i4 * 16u : OOB, blk, 0);
+                }
             } else {
                 const int rows_ok = (int)d.NS - 32 * st - 4 * h;      // this lane's rows (r&3) + 8 (r>>2) below it exist
                 uint32_t vo = lane_boff;
@@ -340,12 +383,14 @@ __global__ __launch_bounds__(256) void normal_mfma_kernel(const NormalDesc d) {
 template <int EH>
 static void launch_normal_mfma(int nst, dim3 grid, hipStream_t stream, const EvPair &ev, const NormalDesc &d) {
     const uint32_t lds = d.l_chunk * 2u * EH * sizeof(float);        // the loc rows of a workgroup
-    if (nst == 1)
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+    if (nst == 1 && d.ts_nk)
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1, true>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+    else if (nst == 1)
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
     else if (nst == 2)
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 2>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 2, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
     else
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 4>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 4, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
 }
 
 // d is filled except for l_chunk.  Declines (false) outside E <= 32, NS <= 128.
@@ -366,7 +411,20 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
             if (d.v_os[k] < 0) return false;
     }
     const int nst = d.NS <= 32 ? 1 : d.NS <= 64 ? 2 : 4;
-    const uint32_t gx = (uint32_t)((NV + 127) / 128);
+    {   // transposed stores (see the kernel): the [NS, kz] block of one (outer value index, loc row) is one 16-byte
+        // aligned contiguous run of the output
+        static const int ts_knob = env_knob("ALAN_NORMAL_TS");                               // ablation knob
+        const int in = d.nv - 1;
+        // (worth it when the rows straddle cache lines and most lanes have one: measured 14.1 -> 12.8 us at kz = 30,
+        // but 13.3 -> 14.2 at kz = 32, whose 128-byte rows are already whole lines, and 4.5 -> 5.7 at kz = 10)
+        bool ts = ts_knob != 0 && nst == 1 && d.nv >= 1 && d.v_os[in] == 1 &&
+                  ((d.vdiv[in].d >= 24 && d.vdiv[in].d < 32) || (ts_knob == 2 && d.vdiv[in].d <= 32)) &&
+                  d.s_os == (int64_t)d.vdiv[in].d && (d.NS * d.vdiv[in].d) % 4 == 0 && d.l_os % 4 == 0 &&
+                  reinterpret_cast<uintptr_t>(d.out) % 16 == 0;
+        for (int k = 0; ts && k < in; ++k) ts = d.v_os[k] % 4 == 0;
+        d.ts_nk = ts ? d.vdiv[in].d : 0u;
+    }
+    const uint32_t gx = d.ts_nk ? (uint32_t)((NV / d.ts_nk + 3) / 4) : (uint32_t)((NV + 127) / 128);
     // ONE residency round: the workgroups that fit the chip at once (256 CUs x the waves per SIMD the kernel's
     // registers allow: 204 at NST = 4, 84 at NST = 1), each walking as many loc rows as that takes.  (600 workgroups on
     // 512 slots ran two rounds: 25 us of MFMA phase for 11 us of MFMAs.)

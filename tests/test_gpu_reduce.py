@@ -220,7 +220,8 @@ def test_chain_logmmexp_golden(case):
 
 # ------------------------------------------------------------------ fused Normal factor producer
 @pytest.mark.parametrize("M,K,E,dtype", [(7, 3, 18, t.float32), (40, 10, 18, t.float32), (300, 30, 18, t.float32),
-                                         (5, 4, 1, t.float64), (9, 5, 7, t.float32)])
+                                         (5, 4, 1, t.float64), (9, 5, 7, t.float32),
+                                         (301, 26, 5, t.float32), (13, 28, 31, t.float32)])   # (LDS-transposed stores)
 def test_normal_producer_matches_torch_distributions(M, K, E, dtype):
     """alan_reduce(mode NORMAL) == td.Normal(loc, scale).log_prob(x).sum(event) over the K cross product
     (TorchDimDist.py:127-162, utils.py:147-152), fp32 to 2e-5 relative."""
