@@ -49,6 +49,23 @@ struct SmallDesc {
     int32_t ring_n;
 };
 
+// Kernel argument of the linear-logits Bernoulli producer (ALAN_MODE_BERNOULLI_LINEAR): fp32, 32-bit offsets, at
+// most LIN_NK keep dims, LIN_NR summed dims and LIN_T terms; a term is a[...] or sum_e a[... + e ads] * b[... + e bds].
+constexpr int LIN_T = 3, LIN_NK = 4, LIN_NR = 2;
+
+struct LinDesc {
+    const float *val;
+    float *out;
+    const float *a[LIN_T], *b[LIN_T];           // b = nullptr: a plain term
+    uint32_t n_out, n_red;
+    int32_t nt;
+    float out_scale, add_const;
+    FastDiv kdiv[LIN_NK], rdiv[LIN_NR];         // right-aligned; unused leading slots: size 1
+    int32_t vks[LIN_NK], vrs[LIN_NR], oks[LIN_NK];
+    int32_t aks[LIN_T][LIN_NK], ars[LIN_T][LIN_NR], bks[LIN_T][LIN_NK], brs[LIN_T][LIN_NR];
+    int32_t len[LIN_T], ads[LIN_T], bds[LIN_T];
+};
+
 struct GroupLaunch {
     int logG;
     bool block;
@@ -95,7 +112,10 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
                      hipStream_t stream, const EvPair &ev);
 // The two halves of it, for alan_reduce_batch: fill a SmallDesc; launch up to SMALL_MULTI of them as one kernel.
 int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype, SmallDesc &sd);
-int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream);
+// `lin`: the LinDesc of the (at most one) problem whose mode[] entry is ALAN_MODE_BERNOULLI_LINEAR; its sd[] slot is unused
+int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
+                       const LinDesc *lin = nullptr);
+int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
 // fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the

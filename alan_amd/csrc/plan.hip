@@ -350,6 +350,130 @@ static bool split_long_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t 
 }
 
 // alan_reduce_batch: is this problem one launch of the small kernel?  Fills what that launch needs.
+// ALAN_MODE_BERNOULLI_LINEAR -> the kernel's argument and launch geometry.  ALAN_ERR_UNSUPPORTED: a well-formed problem
+// outside what the kernel takes (the caller evaluates the logits itself and uses ALAN_MODE_BERNOULLI).
+static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl) {
+    if (d.ndim < 0 || d.ndim > MAXD || d.n_factors < 2 || d.n_factors > MAXF) return ALAN_ERR_BAD_DESC;
+    if (d.lse_out.data || d.weight.data || d.ring_n || !d.out.data) return ALAN_ERR_BAD_DESC;
+    for (int f = 0; f < d.n_factors; ++f) {
+        if (!d.factor[f].data) return ALAN_ERR_BAD_DESC;
+        if (d.factor[f].dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    }
+    if (d.out.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    std::memset(&ld, 0, sizeof(ld));
+    int keep[MAXD], red[MAXD], nk = 0, nr = 0;
+    uint32_t dot = 0;
+    int64_t n_out = 1, n_red = 1;
+    for (int i = 0; i < d.ndim; ++i) {
+        if (d.size[i] < 1) return ALAN_ERR_BAD_DESC;
+        switch (d.role[i]) {
+            case ALAN_KEEP:
+                if (d.size[i] > 1) keep[nk++] = i;
+                n_out *= d.size[i];
+                break;
+            case ALAN_REDUCE:
+                if (d.size[i] > 1) red[nr++] = i;
+                n_red *= d.size[i];
+                break;
+            case ALAN_DOT: dot |= 1u << i; break;
+            default: return ALAN_ERR_BAD_DESC;
+        }
+        if (n_out >= (1ll << 31) || n_red >= (1ll << 31) || d.size[i] >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+    }
+    if (nk > LIN_NK || nr > LIN_NR) return ALAN_ERR_UNSUPPORTED;
+    // threads run along the output's innermost dim; lanes of a group along the value's
+    std::sort(keep, keep + nk, [&](int a, int b) { return d.out.stride[a] > d.out.stride[b]; });
+    std::sort(red, red + nr, [&](int a, int b) { return d.factor[0].stride[a] > d.factor[0].stride[b]; });
+    const int ko = LIN_NK - nk, ro = LIN_NR - nr;
+    for (int k = 0; k < LIN_NK; ++k) ld.kdiv[k] = make_fastdiv(k < ko ? 1u : (uint32_t)d.size[keep[k - ko]]);
+    for (int k = 0; k < LIN_NR; ++k) ld.rdiv[k] = make_fastdiv(k < ro ? 1u : (uint32_t)d.size[red[k - ro]]);
+    const int64_t lim = (1ll << 31) - 1;
+    bool fits = true;
+    // strides of one tensor over the keep / summed dims, with the int32 reach check of the kernel's offsets
+    auto lay = [&](const alan_tensor_t &x, int32_t *ks, int32_t *rs, int dot_dim) {
+        int64_t reach = 0;
+        for (int j = 0; j < nk; ++j) {
+            const int64_t st = x.stride[keep[j]];
+            reach += (d.size[keep[j]] - 1) * (st < 0 ? -st : st);
+            if (st > lim || st < -lim) fits = false; else ks[ko + j] = (int32_t)st;
+        }
+        for (int j = 0; rs && j < nr; ++j) {
+            const int64_t st = x.stride[red[j]];
+            reach += (d.size[red[j]] - 1) * (st < 0 ? -st : st);
+            if (st > lim || st < -lim) fits = false; else rs[ro + j] = (int32_t)st;
+        }
+        if (dot_dim >= 0) {
+            const int64_t st = x.stride[dot_dim];
+            reach += (d.size[dot_dim] - 1) * (st < 0 ? -st : st);
+            if (st > lim || st < -lim) fits = false;
+        }
+        if (reach > lim) fits = false;
+    };
+    auto dot_strides = [&](const alan_tensor_t &x) {
+        uint32_t m = 0;
+        for (int i = 0; i < d.ndim; ++i)
+            if (((dot >> i) & 1) && x.stride[i] != 0 && d.size[i] > 1) m |= 1u << i;
+        return m;
+    };
+    if (dot_strides(d.factor[0])) return ALAN_ERR_BAD_DESC;
+    lay(d.factor[0], ld.vks, ld.vrs, -1);
+    for (int j = 0; j < nr; ++j)
+        if (d.out.stride[red[j]] != 0) return ALAN_ERR_BAD_DESC;
+    lay(d.out, ld.oks, nullptr, -1);
+    ld.val = (const float *)d.factor[0].data;
+    ld.out = (float *)d.out.data;
+    // terms
+    int nt = 0, f = 1;
+    while (f < d.n_factors) {
+        if ((int)d.factor[f].scale != nt + 1) return ALAN_ERR_BAD_DESC;
+        if (nt == LIN_T) return ALAN_ERR_UNSUPPORTED;
+        const alan_tensor_t &a = d.factor[f];
+        const bool two = f + 1 < d.n_factors && (int)d.factor[f + 1].scale == nt + 1;
+        ld.a[nt] = (const float *)a.data;
+        if (!two) {
+            if (dot_strides(a)) return ALAN_ERR_BAD_DESC;
+            lay(a, ld.aks[nt], ld.ars[nt], -1);
+            ld.len[nt] = 1;
+            f += 1;
+        } else {
+            const alan_tensor_t &b = d.factor[f + 1];
+            const uint32_t m = dot_strides(a) | dot_strides(b);
+            if (m & (m - 1)) return ALAN_ERR_UNSUPPORTED;          // contracted over more than one dim
+            int dd = -1;
+            for (int i = 0; i < d.ndim; ++i)
+                if ((m >> i) & 1) dd = i;
+            lay(a, ld.aks[nt], ld.ars[nt], dd);
+            lay(b, ld.bks[nt], ld.brs[nt], dd);
+            ld.b[nt] = (const float *)b.data;
+            ld.len[nt] = dd >= 0 ? (int32_t)d.size[dd] : 1;
+            if (fits && dd >= 0) {
+                ld.ads[nt] = (int32_t)a.stride[dd];
+                ld.bds[nt] = (int32_t)b.stride[dd];
+            }
+            f += 2;
+        }
+        ++nt;
+    }
+    if (!fits) return ALAN_ERR_UNSUPPORTED;
+    ld.nt = nt;
+    ld.n_out = (uint32_t)n_out;
+    ld.n_red = (uint32_t)n_red;
+    ld.out_scale = d.out.scale;
+    ld.add_const = (float)d.add_const;
+    int logG = 0;
+    while (logG < 6 && (1ll << logG) < n_red) ++logG;
+    gl.block = logG == 6 && n_red >= 512 && n_out * 64 < 256ll * 256 * 4;
+    gl.logG = logG;
+    if (gl.block) {
+        gl.grid = (uint32_t)n_out;
+    } else {
+        const int64_t threads = n_out << logG;
+        if (threads >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+        gl.grid = (uint32_t)((threads + 255) / 256);
+    }
+    return ALAN_OK;
+}
+
 static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
     uint32_t keep, red, plate;
     if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
@@ -390,20 +514,33 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     // others one by one
     SmallDesc sd[SMALL_MULTI];
     GroupLaunch gl[SMALL_MULTI];
+    LinDesc lin;
+    bool have_lin = false;
     int mode[SMALL_MULTI], m = 0, lone = -1;
+    std::memset(sd, 0, sizeof(sd));
     auto flush_small = [&]() -> int {
         int rc = ALAN_OK;
         if (m >= 2)
-            rc = launch_small_multi(sd, gl, mode, m, stream);
+            rc = launch_small_multi(sd, gl, mode, m, stream, have_lin ? &lin : nullptr);
         else if (m == 1)
             rc = alan_reduce(descs[lone], nullptr, 0, stream_);
         m = 0;
+        have_lin = false;
         return rc;
     };
     bool other[64];
     if (n > 64) return ALAN_ERR_UNSUPPORTED;
     for (int i = 0; i < n; ++i) {
-        other[i] = !prepare_small(*descs[i], sd[m], gl[m], mode[m]);
+        if (descs[i]->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+            // one per multi launch (its argument has its own slot there); a second one goes out alone, below
+            other[i] = have_lin || descs[i]->ev_start || descs[i]->ev_stop || lin_prepare(*descs[i], lin, gl[m]) != ALAN_OK;
+            if (!other[i]) {
+                have_lin = true;
+                mode[m] = ALAN_MODE_BERNOULLI_LINEAR;
+            }
+        } else {
+            other[i] = !prepare_small(*descs[i], sd[m], gl[m], mode[m]);
+        }
         if (other[i]) continue;
         lone = i;
         if (++m == SMALL_MULTI) {
@@ -422,8 +559,20 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     return ALAN_OK;
 }
 
+extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
+    if (!d) return ALAN_ERR_BAD_DESC;
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+        LinDesc ld;
+        GroupLaunch gl;
+        return lin_prepare(*d, ld, gl);
+    }
+    uint32_t keep, red, plate;
+    return classify(*d, keep, red, plate);
+}
+
 extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) return 0;
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
     {
@@ -455,6 +604,16 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
 extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t workspace_bytes, void *stream_) {
     if (!d) return ALAN_ERR_BAD_DESC;
     hipStream_t stream = (hipStream_t)stream_;
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+        LinDesc ld;
+        GroupLaunch gl;
+        const int rc = lin_prepare(*d, ld, gl);
+        if (rc != ALAN_OK) return rc;
+        EvPair ev;
+        ev.start = (hipEvent_t)d->ev_start;
+        ev.stop = (hipEvent_t)d->ev_stop;
+        return launch_lin(ld, gl, stream, ev);
+    }
     uint32_t keep, red, plate;
     int rc = classify(*d, keep, red, plate);
     if (rc != ALAN_OK) return rc;
@@ -544,5 +703,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 3; }
+extern "C" int alan_abi_version(void) { return 4; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

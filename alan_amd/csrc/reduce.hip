@@ -302,6 +302,109 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
     small_body<MODE, BLOCK>(d, logG, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------
+// ALAN_MODE_BERNOULLI_LINEAR: the Bernoulli producer with its logits computed on the fly,
+//   l = sum_t ( a_t  |  sum_e a_t[e] * b_t[e] ),     out = out_scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const
+// (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
+// TorchDimDist.py:127-162).  A lane group per output element, lanes along the summed dims; each lane walks the dot
+// products of its element serially, four products in flight.
+template <bool BLOCK>
+__device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const uint32_t block_id) {
+    const uint32_t G = BLOCK ? 256u : (1u << logG);
+    uint32_t grp, gl;
+    if (BLOCK) {
+        grp = block_id;
+        gl = threadIdx.x;
+    } else {
+        const uint32_t gid = block_id * 256u + threadIdx.x;
+        grp = gid >> logG;
+        gl = gid & (G - 1u);
+    }
+    const bool active = grp < d.n_out;
+    uint32_t o = active ? grp : d.n_out - 1u;
+    int32_t abase[LIN_T], bbase[LIN_T], vbase = 0, obase = 0;
+#pragma unroll
+    for (int tm = 0; tm < LIN_T; ++tm) abase[tm] = bbase[tm] = 0;
+#pragma unroll
+    for (int k = LIN_NK - 1; k >= 0; --k) {
+        const uint32_t q = fd_div(o, d.kdiv[k]);
+        const int32_t idx = (int32_t)(o - q * d.kdiv[k].d);
+        o = q;
+#pragma unroll
+        for (int tm = 0; tm < LIN_T; ++tm) {
+            abase[tm] += idx * d.aks[tm][k];
+            bbase[tm] += idx * d.bks[tm][k];
+        }
+        vbase += idx * d.vks[k];
+        obase += idx * d.oks[k];
+    }
+    float s = 0.f, m = 0.f;
+    for (uint32_t r = gl; r < d.n_red; r += G) {
+        int32_t aoff[LIN_T], boff[LIN_T], voff = vbase;
+#pragma unroll
+        for (int tm = 0; tm < LIN_T; ++tm) {
+            aoff[tm] = abase[tm];
+            boff[tm] = bbase[tm];
+        }
+        uint32_t rr = r;
+#pragma unroll
+        for (int k = LIN_NR - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(rr, d.rdiv[k]);
+            const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+            rr = q;
+#pragma unroll
+            for (int tm = 0; tm < LIN_T; ++tm) {
+                aoff[tm] += idx * d.ars[tm][k];
+                boff[tm] += idx * d.brs[tm][k];
+            }
+            voff += idx * d.vrs[k];
+        }
+        const float y = d.val[voff];
+        float xl = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < LIN_T; ++tm) {
+            if (tm >= d.nt) continue;
+            if (d.b[tm] == nullptr) {
+                xl += d.a[tm][aoff[tm]];
+                continue;
+            }
+            const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
+            const int len = d.len[tm], as = d.ads[tm], bs = d.bds[tm];
+            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+            int e = 0;
+            for (; e + 4 <= len; e += 4) {
+                const float a0 = pa[(e + 0) * as], a1 = pa[(e + 1) * as], a2 = pa[(e + 2) * as], a3 = pa[(e + 3) * as];
+                const float b0 = pb[(e + 0) * bs], b1 = pb[(e + 1) * bs], b2 = pb[(e + 2) * bs], b3 = pb[(e + 3) * bs];
+                acc0 = fmaf(a0, b0, acc0);
+                acc1 = fmaf(a1, b1, acc1);
+                acc2 = fmaf(a2, b2, acc2);
+                acc3 = fmaf(a3, b3, acc3);
+            }
+            for (; e < len; ++e) acc0 = fmaf(pa[e * as], pb[e * bs], acc0);
+            xl += (acc0 + acc1) + (acc2 + acc3);
+        }
+        const float ls = (xl < 0.f ? xl : 0.f) - log1pf(expf(xl < 0.f ? xl : -xl));
+        s += ls - (1.f - y) * xl;
+    }
+    combine_lanes<float, ALAN_MODE_SUM, BLOCK>(m, s, G);
+    if (active && gl == 0) d.out[obase] = s * d.out_scale + d.add_const;
+}
+
+template <bool BLOCK>
+__global__ __launch_bounds__(256) void bernoulli_linear_kernel(const LinDesc d, const int logG) {
+    lin_body<BLOCK>(d, logG, blockIdx.x);
+}
+
+int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
+    if (gl.grid == 0) return ALAN_OK;
+    if (gl.block)
+        hipExtLaunchKernelGGL((bernoulli_linear_kernel<true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, ld, 8);
+    else
+        hipExtLaunchKernelGGL((bernoulli_linear_kernel<false>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0,
+                              ld, gl.logG);
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+}
+
 // Several INDEPENDENT small problems in one launch (alan_reduce_batch): the per-variable log-prob producers of a
 // plate are a handful of launch-latency-bound kernels (4-5 us each inside a replayed graph) that do not depend on
 // each other.  Workgroups are dealt to the problems in order; mode and lane-group shape are run-time here.
@@ -310,6 +413,7 @@ struct SmallMulti {
     int32_t mode[SMALL_MULTI], logG[SMALL_MULTI], block[SMALL_MULTI];
     uint32_t first_block[SMALL_MULTI + 1];
     SmallDesc d[SMALL_MULTI];
+    LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
 };
 
 template <int MODE>
@@ -339,15 +443,26 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
         case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
         case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
         case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM>(d, logG, block, bid); break;   // (per-factor backward launches)
+        case ALAN_MODE_BERNOULLI_LINEAR: {
+            const LinDesc &ld = *reinterpret_cast<const LinDesc *>(
+                (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallMulti, lin)));
+            if (block)
+                lin_body<true>(ld, 8, bid);
+            else
+                lin_body<false>(ld, logG, bid);
+            break;
+        }
         default: break;
     }
 }
 
-int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream) {
+int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
+                       const LinDesc *lin) {
     if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;
     SmallMulti m;
     std::memset(&m, 0, sizeof(m));
     m.n = n;
+    if (lin) m.lin = *lin;
     uint32_t blocks = 0;
     for (int i = 0; i < n; ++i) {
         m.mode[i] = mode[i];

@@ -222,6 +222,43 @@ class LazyNormalPT(PT):
         return self
 
 
+class LinearPT(PT):
+    """The value of a model lambda that is a sum of arguments and dot products of arguments (movielens' logits
+    ``lambda z, x: z @ x``; bus_breakdown's ``alpha + phi @ bus_company_name + psi @ run_type``), not evaluated yet:
+    ``.x`` evaluates it the usual way (``make``) the first time anyone asks, but a Bernoulli log-prob can hand the
+    terms to the producer kernel that computes the logits itself (alan_reduce mode BERNOULLI_LINEAR) -- no batched
+    GEMM, no adds, no logits tensor.  ``terms``: tuples of one PT (a plain summand, no positional dims) or two PTs
+    (contracted over their single positional dim).  Only built where no gradient is wanted."""
+    __slots__ = ("terms", "make", "_val")
+
+    def __init__(self, terms, dims, make):
+        self.terms, self.make = tuple(terms), make
+        self._val = None
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @property
+    def x(self):
+        if self._val is None:
+            self._val = self.make()
+            self.make = None
+        return self._val
+
+    @property
+    def materialised(self):
+        return self._val is not None
+
+    @property
+    def n_pos(self):
+        return 0
+
+    def size_of(self, dim_id):
+        return self.dims[self.ids.index(dim_id)].size
+
+    def detach(self):
+        return self
+
+
 def pt_order(pts, lead=(), last=()):
     """Ordered union of the dims of several PTs: ``lead`` dims first, ``last`` dims last, others between.
     Returns (dims, ids)."""

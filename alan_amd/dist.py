@@ -8,13 +8,14 @@ the plate recursion asks for  [plates..., parent Ks..., own K]  so that the K di
 eliminates is the CONTIGUOUS dim of the big factor -- the layout the rows kernel streams at HBM rate.
 """
 import inspect
+import math
 import types
 
 import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, LazyNormalPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, LinearPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -377,6 +378,13 @@ class TorchDimDist:
             return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, sx), out_dims)
         if kind == "bernoulli":
             logits = self.kwargs["logits"]
+            if isinstance(logits, LinearPT) and not logits.materialised and x.n_pos == 0 \
+                    and not (t.is_grad_enabled() and x.x.requires_grad):
+                # logits = a sum of arguments and dot products of arguments: the producer computes them itself
+                from . import engine as E
+                out = E.bernoulli_linear_logprob((x.x, x.dims), _producer_terms(x, logits.terms), out_dims, ab)
+                if out is not None:
+                    return PT(out, out_dims)
             spec = (x.dims, logits.dims, out_dims, ab)
             if not (t.is_grad_enabled() and (x.x.requires_grad or logits.x.requires_grad)):
                 from . import engine as E
@@ -437,6 +445,9 @@ class TorchDimDist:
                 args = (x, args[1], PT(sc.raw, sc.dims))
         elif self.dist is td.Bernoulli and set(self.kwargs) == {"logits"}:
             kind, args = "bernoulli", (x, self.kwargs["logits"])
+            lg = args[1]
+            if isinstance(lg, LinearPT) and not lg.materialised:     # look at its operands instead (fp32, on the GPU)
+                args = (x, *[p for term in lg.terms for p in term])
         else:
             return None
         ts = [p.x for p in args]
@@ -614,12 +625,131 @@ def _is_plain_exp(fn):
     return ok
 
 
+LINEAR_LOGITS = True
+"""A model lambda that is a sum of its arguments and of dot products of them (``z @ x``,
+``alpha + phi @ bus_company_name + psi @ run_type``) stays unevaluated where no gradient is wanted (dims.LinearPT): a
+Bernoulli(logits=...) log-prob then computes the logits inside its producer launch (alan_reduce mode BERNOULLI_LINEAR)."""
+
+_LINEAR_FORM = {}    # id(code object) -> (code object, terms or None)
+
+
+def _linear_form(fn):
+    """``fn``'s value as a sum of terms, each ("arg", i) or ("dot", i, j) over its positional arguments -- or None when
+    it is anything else.  Decided once per code object by symbolic tracing (only ``+`` and ``@`` / torch.matmul between
+    arguments are recognised; constants, closures, other operators: None)."""
+    code = getattr(fn, "__code__", None)
+    if code is None or code.co_argcount < 2 or getattr(fn, "__closure__", None):
+        return None
+    hit = _LINEAR_FORM.get(id(code))
+    if hit is not None and hit[0] is code:
+        return hit[1]
+    terms = None
+    try:
+        import operator
+        import torch.fx
+        nodes = list(torch.fx.symbolic_trace(fn).graph.nodes)
+        arg = {n: i for i, n in enumerate(n for n in nodes if n.op == "placeholder")}
+
+        def expr(n):
+            if n in arg:
+                return [("arg", arg[n])]
+            if not isinstance(n, torch.fx.Node) or n.kwargs or len(n.args) != 2:
+                raise ValueError
+            fnc, meth = n.op == "call_function", n.op == "call_method"
+            if (fnc and n.target in (operator.add, t.add)) or (meth and n.target == "add"):
+                return expr(n.args[0]) + expr(n.args[1])
+            if (fnc and n.target in (operator.matmul, t.matmul)) or (meth and n.target == "matmul"):
+                a, b = n.args
+                if a in arg and b in arg:
+                    return [("dot", arg[a], arg[b])]
+            raise ValueError
+
+        out = nodes[-1]
+        if out.op == "output" and len(out.args) == 1 and isinstance(out.args[0], torch.fx.Node):
+            found = expr(out.args[0])
+            if any(k[0] == "dot" for k in found):
+                terms = tuple(found)
+    except Exception:
+        terms = None
+    _LINEAR_FORM[id(code)] = (code, terms)
+    return terms
+
+
+def _linear_pt(fn, named_args, form, dimcache):
+    """The LinearPT of ``fn(*args)`` when the arguments have the shapes its form needs (dot operands: exactly one
+    positional dim of the same length; plain summands: none), else None."""
+    vals = [v for _, v in named_args]
+    terms = []
+    for k in form:
+        ops = tuple(vals[i] for i in k[1:])
+        if k[0] == "dot":
+            a, b = ops
+            if a.n_pos != 1 or b.n_pos != 1 or a.x.shape[-1] != b.x.shape[-1]:
+                return None
+        elif ops[0].n_pos != 0:
+            return None
+        terms.append(ops)
+    used = {i for k in form for i in k[1:]}
+    if used != set(range(len(vals))):
+        return None                               # (an unused argument still contributes its dims: leave that to torch)
+    for v in vals:
+        if not (v.x.is_cuda and v.x.dtype == t.float32) or (t.is_grad_enabled() and v.x.requires_grad):
+            return None
+    seen, count = {}, {}
+    for p in vals:
+        for d, i in zip(p.dims, p.ids):
+            seen.setdefault(i, d)
+            count[i] = count.get(i, 0) + 1
+    order = sorted(seen, key=lambda i: -count[i])                  # as _call_lambda_vmap lays its result out
+    return LinearPT(terms, [seen[i] for i in order], lambda: _call_lambda_vmap(fn, named_args, dimcache).x)
+
+
+def _dot_pt(a, b):
+    """sum over the single positional dim of a * b, broadcast over first-class dims, as one (batched) GEMM."""
+    letters = {}
+    sub = lambda p: "".join(letters.setdefault(i, chr(ord("a") + len(letters))) for i in p.ids)
+    sa, sb = sub(a), sub(b)
+    dims, ids = pt_order((a, b))
+    return PT(t.einsum(f"{sa}Z,{sb}Z->{''.join(letters[i] for i in ids)}", a.x, b.x), dims)
+
+
+def _producer_terms(value, terms):
+    """The (tensor, dims) terms handed to engine.bernoulli_linear_logprob.  The producer computes a dot product once
+    per element of the WHOLE index space; a product whose operands lack some of the dims (bus_breakdown's
+    ``phi @ bus_company_name`` has no K_alpha) would be recomputed for every index of those -- such a term is evaluated
+    once, the usual way (a batched GEMM), and enters as a plain summand: the launch still saves the adds."""
+    sizes = {}
+    for p in (value, *[p for term in terms for p in term]):
+        for d, i in zip(p.dims, p.ids):
+            sizes[i] = d.size
+    total = math.prod(sizes.values())
+    out = []
+    for term in terms:
+        if len(term) == 2:
+            own = {i for p in term for i in p.ids}
+            if math.prod(sizes[i] for i in own) < total:
+                term = (_dot_pt(*term),)
+        out.append(tuple((p.x, p.dims) for p in term))
+    return out
+
+
 def call_model_lambda(fn, named_args, dimcache=None):
     vals = [v for _, v in named_args]
     if len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_floating_point() and _is_plain_exp(fn):
         # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
         # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
         return ExpPT(vals[0].x, vals[0].dims)
+    if LINEAR_LOGITS and LAMBDA_BACKEND == "vmap" and len(vals) >= 2 and all(type(v) is PT for v in vals):
+        form = _linear_form(fn)
+        if form is not None:
+            lin = _linear_pt(fn, named_args, form, dimcache)
+            if lin is not None:
+                return lin
+    return _call_lambda_vmap(fn, named_args, dimcache)
+
+
+def _call_lambda_vmap(fn, named_args, dimcache=None):
+    vals = [v for _, v in named_args]
     if LAMBDA_BACKEND != "vmap" or not all(isinstance(v, PT) for v in vals):
         val = fn(*[_as_dim(v, n, dimcache) for n, v in named_args])
         if not is_tensor(val):

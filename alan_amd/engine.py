@@ -80,6 +80,18 @@ class ResultRing:
         """Read the device counter (once, after capture: warm-ups and the capture pass advanced it)."""
         self.pos = int(self.counter.item())
 
+    def settle(self, out):
+        """After the capture pass (``taken`` was zeroed before it) that returned ``out``: "ring" -- the evaluation's
+        result IS the ring's value, replays deliver through it; "copy" -- the last launch did not take the ring, the
+        graph's output buffer is copied out as usual; "recapture" -- a launch took it but the result was computed
+        from it afterwards: the graph must be captured again without a ring."""
+        if self.taken == 0:
+            return "copy"
+        if self.taken == 1 and out is self.placeholder:
+            self.sync_position()
+            return "ring"
+        return "recapture"
+
     def claim(self):
         """The tensor the next replay writes.  Call exactly once per replay, before it."""
         i = self.pos
@@ -569,6 +581,41 @@ def producer_grads(G, out_dims, args, wanted, kinds, log_scale=False, scale=1.0)
 def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):
     """log Bernoulli(value; logits=logits), summed like ``normal_logprob`` (alan_reduce mode BERNOULLI)."""
     return _produce(N.MODE_BERNOULLI, (value, logits), out_dims, affine)
+
+
+def bernoulli_linear_logprob(value, terms, out_dims, affine=(1.0, 0.0)):
+    """log Bernoulli(value; logits = sum of ``terms``) summed over every first-class dim missing from ``out_dims``, as
+    ONE launch that computes the logits itself (alan_reduce mode BERNOULLI_LINEAR): what the reference evaluates as the
+    model's lambda (a batched matmul and adds through torchdim) followed by TorchDimDist.py:127-162.  ``value``:
+    (tensor, dims) with no positional dims; a term: ((tensor, dims),) -- a plain summand, no positional dims -- or
+    ((a, dims), (b, dims)) -- contracted over their one trailing positional dim.  Returns the tensor laid out as
+    ``out_dims``, or None when the shape is not one the kernel takes (the caller then evaluates the lambda)."""
+    tok = _Tokens()
+    factors, scales, dots = [(value[0].detach(), tok.many(value[1]))], [1.0], []
+    for ti, term in enumerate(terms):
+        if len(term) == 1:
+            (x, d), = term
+            factors.append((x.detach(), tok.many(d)))
+        else:
+            e = tok(("_dot", ti))
+            dots.append(e)
+            for x, d in term:
+                factors.append((x.detach(), tok.many(d) + (e,)))
+        scales += [float(ti + 1)] * len(term)
+    if len(factors) > N.MAX_FACTORS or any(x.dtype != t.float32 for x, _ in factors):
+        return None
+    try:
+        sizes = _space(factors)
+    except Exception:               # operands whose sizes do not line up: the lambda's own error message is better
+        return None
+    if len(sizes) > N.MAX_DIMS:
+        return None
+    odims = tok.many(out_dims)
+    roles = {d: (N.DOT if d in dots else N.KEEP if d in odims else N.REDUCE) for d in sizes}
+    out = t.empty([sizes[d] for d in odims], dtype=t.float32, device=value[0].device)
+    ok = _launch(N.MODE_BERNOULLI_LINEAR, factors, sizes, roles, out, odims, out_scale=float(affine[0]),
+                 add_const=float(affine[1]), scales=scales)
+    return out if ok else None
 
 
 # --------------------------------------------------------------------------- elimination planner

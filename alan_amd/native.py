@@ -15,9 +15,10 @@ MAX_DIMS = 8
 MAX_FACTORS = 6
 
 F32, F64 = 0, 1
-KEEP, REDUCE, PLATE = 0, 1, 2
+KEEP, REDUCE, PLATE, DOT = 0, 1, 2, 3
 MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSCALE = 0, 1, 2, 3, 4, 5
 MODE_PRODUCER_GRAD = 6
+MODE_BERNOULLI_LINEAR = 7
 MODE_FUSED_FWD, MODE_FUSED_BWD = 100, 101      # (KernelTimer record tags of alan_normal_lse / _backward; not library modes)
 GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
 
@@ -104,6 +105,8 @@ def lib():
         L.alan_reduce.argtypes = [C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_reduce_workspace_bytes.restype = C.c_size_t
         L.alan_reduce_workspace_bytes.argtypes = [C.POINTER(ReduceDesc)]
+        L.alan_reduce_check.restype = C.c_int
+        L.alan_reduce_check.argtypes = [C.POINTER(ReduceDesc)]
         L.alan_reduce_batch.restype = C.c_int
         L.alan_reduce_batch.argtypes = [C.POINTER(C.POINTER(ReduceDesc)), C.c_int32, C.c_void_p]
         L.alan_reduce_backward.restype = C.c_int
@@ -155,7 +158,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ("alan_reduce", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
+EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
            "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
            "alan_chain_workspace_bytes",
@@ -270,9 +273,11 @@ def flush():
 
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
-    """Enqueue one alan_reduce call.  False only for a call with a result ring (desc.ring_n) that the library declines
-    -- nothing was enqueued, the caller launches again without the ring."""
+    """Enqueue one alan_reduce call.  False only for a call the library may decline -- one with a result ring
+    (desc.ring_n), or of mode BERNOULLI_LINEAR -- when it does: nothing was enqueued, the caller takes its other route."""
     L = lib()
+    if desc.mode == MODE_BERNOULLI_LINEAR and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
+        return False
     if (DEFER_SMALL_LAUNCHES and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and not desc.ring_n
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0

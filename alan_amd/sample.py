@@ -64,15 +64,11 @@ class _GraphedELBO:
             N._TIMER[0] = timer
             E._RING[0] = None
         if self.ring is not None:
-            taken = self.ring.taken
-            if taken == 1 and self.out is self.ring.placeholder:
-                self.ring.sync_position()
-            elif taken == 0:
-                self.ring = None                      # the last launch could not take it: results are copied out
-            else:
-                # the ring's value is not the evaluation's result (something was computed from it afterwards):
-                # capture again without
+            how = self.ring.settle(self.out)
+            if how == "recapture":
                 self.__init__(sample, strategy, ring=False)
+            elif how == "copy":
+                self.ring = None
 
     def __call__(self):
         if self.ring is None:

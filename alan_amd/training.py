@@ -112,27 +112,48 @@ class GraphedEval:
     as a HIP graph: sampling kernels (the generator's Philox state is registered with the graph), log-prob producers
     and the contraction all replay on the device."""
 
-    def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3):
+    def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3, ring=True):
         if problem.device.type != "cuda":
             raise Exception("GraphedEval needs the Problem on the GPU")
+        from . import engine as E
+        from . import sample as S
         self.problem, self.K, self.strategy = problem, K, computation_strategy
-        side = t.cuda.Stream()
-        side.wait_stream(t.cuda.current_stream())
-        with t.cuda.stream(side):
-            for _ in range(warmup):
-                self._iteration()
-        t.cuda.current_stream().wait_stream(side)
-        t.cuda.synchronize()
-        self.graph = t.cuda.CUDAGraph(keep_graph=True)
-        with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-            self.elbo = self._iteration()
+        # the evaluation's last launch delivers through a result ring (engine.ResultRing): no copy after a replay
+        self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING) else None
+        E._RING[0] = self.ring
+        try:
+            side = t.cuda.Stream()
+            side.wait_stream(t.cuda.current_stream())
+            with t.cuda.stream(side):
+                for _ in range(warmup):
+                    self._iteration()
+            t.cuda.current_stream().wait_stream(side)
+            t.cuda.synchronize()
+            if self.ring is not None:
+                self.ring.taken = 0
+            self.graph = t.cuda.CUDAGraph(keep_graph=True)
+            with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                self.elbo = self._iteration()
+        finally:
+            E._RING[0] = None
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedEval")
+        if self.ring is not None:
+            how = self.ring.settle(self.elbo)
+            if how == "recapture":
+                self.__init__(problem, K, computation_strategy, warmup, ring=False)
+            elif how == "copy":
+                self.ring = None
 
     def _iteration(self):
         with t.no_grad():
             return self.problem.sample(self.K, reparam=False).elbo_nograd(self.strategy)
 
     def __call__(self):
-        """Replay; returns a COPY of the ELBO (see GraphedStep.__call__)."""
+        """Replay; returns this replay's own ELBO tensor (a result-ring slot, or a copy of the graph's output buffer:
+        see GraphedStep.__call__)."""
+        if self.ring is None:
+            self.graph.replay()
+            return self.elbo.clone()
+        slot = self.ring.claim()
         self.graph.replay()
-        return self.elbo.clone()
+        return slot.detach()

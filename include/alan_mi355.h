@@ -53,7 +53,8 @@ typedef enum { ALAN_F32 = 0, ALAN_F64 = 1 } alan_dtype_t;
 typedef enum {
     ALAN_KEEP = 0,    /* survives into the output */
     ALAN_REDUCE = 1,  /* reduced by the mode's operator (log-sum-exp / sum / weighted exp-sum) */
-    ALAN_PLATE = 2    /* ALAN_MODE_LSE only: summed AFTER the log-sum-exp (logpq.py:149) */
+    ALAN_PLATE = 2,   /* ALAN_MODE_LSE only: summed AFTER the log-sum-exp (logpq.py:149) */
+    ALAN_DOT = 3      /* ALAN_MODE_BERNOULLI_LINEAR only: an event dim the logits are contracted over */
 } alan_role_t;
 
 typedef enum {
@@ -72,12 +73,21 @@ typedef enum {
                               R = event/batch dims and, for a data-only plate, the plate dims (logpq.py:149) */
     ALAN_MODE_NORMAL_LOGSCALE = 5, /* ALAN_MODE_NORMAL whose third factor is log(scale): the exp() transform of a
                               learned scale parameter (Param.py:18-25, transformation=t.exp) folded into the producer */
-    ALAN_MODE_PRODUCER_GRAD = 6 /* BACKWARD of a producer with respect to ONE of its arguments (what autograd derives
+    ALAN_MODE_PRODUCER_GRAD = 6, /* BACKWARD of a producer with respect to ONE of its arguments (what autograd derives
                               from TorchDimDist.py:127-162): factors = (G, value, loc, scale) or (G, value, logits), G
                               the upstream gradient laid out like the producer's output;  out = out.scale * sum_R
                               G * d log-prob / d argument, KEEP = that argument's dims.  Which one: factor[0].scale =
                               1: Normal d/d value, 2: d/d loc, 3: d/d scale (d/d log scale when factor[3].scale == 2),
                               4: Bernoulli d/d logits */
+    ALAN_MODE_BERNOULLI_LINEAR = 7 /* ALAN_MODE_BERNOULLI whose logits are a sum of terms computed in the launch instead
+                              of by the model's lambda beforehand (movielens `lambda z, x: z @ x`, bus_breakdown
+                              `alpha + phi @ bus_company_name + psi @ run_type`: TorchDimDist.py:127-162 evaluating
+                              the lambda through torchdim, then Bernoulli.log_prob).  factor[0] = value; the others
+                              are term operands, factor[i].scale = 1-based term number: a term with one operand is
+                              that operand (no ALAN_DOT strides); a term with two operands, adjacent in the list,
+                              is sum over ONE ALAN_DOT dim of their product.  At most 3 terms; fp32 only
+                              (ALAN_ERR_UNSUPPORTED otherwise: evaluate the logits and use ALAN_MODE_BERNOULLI).
+                              out = out.scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const */
 } alan_mode_t;
 /* Producer modes (NORMAL, NORMAL_LOGSCALE, BERNOULLI) write  out = out.scale * sum_R(log-prob) + add_const, so the
  * "-(log Q + log K)" of logpq.py:234-235 costs no extra pass; out.scale must be 1 in the other modes. */
@@ -116,6 +126,10 @@ typedef struct {
 
 /* Bytes of scratch alan_reduce() needs for this descriptor (0 is possible). */
 size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *desc);
+
+/* What alan_reduce() would return for this descriptor's shape, without enqueuing anything (a caller that queues
+ * launches for alan_reduce_batch asks first whether a ALAN_MODE_BERNOULLI_LINEAR problem is taken). */
+int alan_reduce_check(const alan_reduce_desc_t *desc);
 
 /* Enqueue the reduction.  `workspace` must be at least alan_reduce_workspace_bytes(desc) bytes,
  * 256-byte aligned, and stay alive until the stream has passed this call. */

@@ -1,0 +1,175 @@
+"""The Bernoulli producer that computes its own logits (alan_reduce mode BERNOULLI_LINEAR; engine.
+bernoulli_linear_logprob; dims.LinearPT): against torch (the lambda evaluated, then td.Bernoulli.log_prob, as
+TorchDimDist.py:127-162 does through torchdim) on the movielens and bus_breakdown shapes and on odd layouts; in a
+multi-problem launch; and end to end, switched on and off."""
+import ctypes
+import math
+
+import pytest
+import torch as t
+
+import alan_amd as alan
+import models
+from conftest import load_golden
+from alan_amd import engine as E
+from alan_amd import native as N
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(value, vdims, terms, out_dims):
+    """fp64 torch: named broadcast by einsum-free alignment."""
+    names = []
+    for _, d in [(value, vdims)] + [p for term in terms for p in term]:
+        for n in d:
+            if n not in names:
+                names.append(n)
+
+    def al(x, d, extra=0):
+        x = x.double()
+        perm = [d.index(n) for n in names if n in d]
+        x = x.permute(*perm, *range(len(d), x.ndim))
+        idx = tuple(slice(None) if n in d else None for n in names)
+        return x[idx]
+
+    logits = 0
+    for term in terms:
+        if len(term) == 1:
+            logits = logits + al(*term[0])
+        else:
+            (a, ad), (b, bd) = term
+            logits = logits + (al(a, ad) * al(b, bd)).sum(-1)
+    lp = t.distributions.Bernoulli(logits=logits).log_prob(al(value, vdims).expand(logits.shape))
+    drop = [i for i, n in enumerate(names) if n not in out_dims]
+    lp = lp.sum(drop) if drop else lp
+    left = [n for n in names if n in out_dims]
+    return lp.permute(*[left.index(n) for n in out_dims])
+
+
+@pytest.mark.parametrize("M,K,Nf,Ev", [(300, 30, 5, 18), (300, 100, 5, 18), (7, 3, 5, 18), (33, 10, 1, 1), (5, 4, 300, 3),
+                                       (2, 2, 1000, 7)])
+def test_movielens_logits_dot_matches_torch(M, K, Nf, Ev):
+    g = t.Generator().manual_seed(M + K)
+    z = t.randn(K, M, Ev, generator=g).to(DEV)                     # a sample: [K_z, plate_1, d_z]
+    x = t.randn(M, Nf, Ev, generator=g).to(DEV)
+    obs = (t.rand(M, Nf, generator=g) < 0.4).float().to(DEV)
+    val, terms = (obs, ("m", "n")), [((z, ("k", "m")), (x, ("m", "n")))]
+    for out_dims, aff in ((("m", "k"), (1.0, 0.0)), (("k", "m"), (-1.0, 0.25)), (("m", "k", "n"), (1.0, 0.0))):
+        got = E.bernoulli_linear_logprob(val, terms, out_dims, aff)
+        assert got is not None and got.shape == tuple({"m": M, "k": K, "n": Nf}[d] for d in out_dims)
+        want = aff[0] * _ref(obs.cpu(), ("m", "n"), [((z.cpu(), ("k", "m")), (x.cpu(), ("m", "n")))], out_dims) + aff[1]
+        t.testing.assert_close(got.cpu().double(), want, rtol=3e-6, atol=3e-5 * max(1, Nf * Ev) ** 0.5)
+
+
+def test_bus_breakdown_logits_sum_of_terms_and_strided_operands():
+    g = t.Generator().manual_seed(11)
+    Ka, Kg, Y, B, I, nb, nr = 6, 5, 2, 3, 150, 11, 4
+    alpha = t.randn(Ka, Y, B, generator=g).to(DEV)
+    phi = t.randn(Kg, nb, generator=g).to(DEV)
+    psi = t.randn(nr, Kg, generator=g).to(DEV).t()                 # a transposed view: dot stride Kg
+    bus = t.randn(Y, B, I, nb, generator=g).to(DEV)
+    run = t.randn(Y, B, I, 2 * nr, generator=g).to(DEV)[..., ::2]   # strided along the contracted dim
+    obs = (t.rand(I, B, Y, generator=g) < 0.5).float().to(DEV).permute(2, 1, 0)   # permuted storage
+    val = (obs, ("Y", "B", "I"))
+    terms = [((alpha, ("Ka", "Y", "B")),), ((phi, ("Kg",)), (bus, ("Y", "B", "I"))), ((psi, ("Kg",)), (run, ("Y", "B", "I")))]
+    out_dims = ("Ka", "Y", "B", "Kg")
+    got = E.bernoulli_linear_logprob(val, terms, out_dims)
+    cpu = lambda term: tuple((x.cpu(), d) for x, d in term)
+    want = _ref(obs.cpu(), val[1], [cpu(tm) for tm in terms], out_dims)
+    t.testing.assert_close(got.cpu().double(), want, rtol=3e-6, atol=2e-4)
+    # nothing summed: one value per element
+    got2 = E.bernoulli_linear_logprob(val, terms, ("Ka", "Y", "B", "Kg", "I"))
+    assert got2 is None or got2.shape == (Ka, Y, B, Kg, I)          # (5 keep dims: the library may decline)
+    keep4 = E.bernoulli_linear_logprob((obs[0], ("B", "I")), [((phi, ("Kg",)), (bus[0], ("B", "I")))], ("B", "Kg", "I"))
+    want4 = _ref(obs[0].cpu(), ("B", "I"), [((phi.cpu(), ("Kg",)), (bus[0].cpu(), ("B", "I")))], ("B", "Kg", "I"))
+    t.testing.assert_close(keep4.cpu().double(), want4, rtol=3e-6, atol=2e-5)
+
+
+def test_unsupported_shapes_are_declined_not_miscomputed():
+    g = t.Generator().manual_seed(2)
+    z, x = t.randn(4, 6, 3, generator=g).to(DEV), t.randn(6, 5, 3, generator=g).to(DEV)
+    obs = (t.rand(6, 5, generator=g) < 0.5).to(DEV)
+    term = [((z, ("k", "m")), (x, ("m", "n")))]
+    assert E.bernoulli_linear_logprob((obs.double(), ("m", "n")), term, ("m", "k")) is None          # fp64 value
+    assert E.bernoulli_linear_logprob((obs.float(), ("m", "n")), [((z.double(), ("k", "m")), (x.double(), ("m", "n")))],
+                                      ("m", "k")) is None
+    four = [((z, ("k", "m")), (x, ("m", "n")))] * 4                                                    # > 3 terms / > 6 factors
+    assert E.bernoulli_linear_logprob((obs.float(), ("m", "n")), four, ("m", "k")) is None
+    # the C entry point: malformed descriptors
+    d = N.ReduceDesc()
+    d.mode, d.ndim, d.n_factors = N.MODE_BERNOULLI_LINEAR, 1, 1
+    d.size[0], d.role[0] = 6, N.KEEP
+    assert N.lib().alan_reduce_check(ctypes.byref(d)) == -1                                            # value only
+    d.n_factors = 2
+    N.fill_tensor(d.factor[0], obs.float(), [5])
+    N.fill_tensor(d.factor[1], z, [3], 2.0)                                                            # terms must count from 1
+    N.fill_tensor(d.out, t.empty(6, device=DEV), [1])
+    assert N.lib().alan_reduce_check(ctypes.byref(d)) == -1
+    d.role[0] = N.DOT                                                                                   # value on a DOT dim
+    d.factor[1].scale = 1.0
+    assert N.lib().alan_reduce_check(ctypes.byref(d)) == -1
+
+
+def test_in_a_multi_problem_launch_the_values_are_those_of_a_lone_launch():
+    from alan_amd.dims import Dim
+    g = t.Generator().manual_seed(4)
+    M, K, Nf, Ev = 300, 30, 5, 18
+    z = t.randn(K, M, Ev, generator=g).to(DEV)
+    x = t.randn(M, Nf, Ev, generator=g).to(DEV)
+    obs = (t.rand(M, Nf, generator=g) < 0.4).float().to(DEV)
+    mu, sc = t.randn(M, Ev, generator=g).to(DEV), t.rand(M, Ev, generator=g).to(DEV) + 0.5
+    calls = [
+        lambda: E.normal_logprob((z, ("k", "m")), (mu, ("m",)), (sc, ("m",)), ("m", "k"), affine=(-1.0, -math.log(K))),
+        lambda: E.bernoulli_linear_logprob((obs, ("m", "n")), [((z, ("k", "m")), (x, ("m", "n")))], ("m", "k")),
+        lambda: E.normal_logprob((z[:, 0], ("k",)), (mu[0], ()), (sc[0], ()), ("k",)),
+        lambda: E.bernoulli_linear_logprob((obs, ("m", "n")), [((z, ("k", "m")), (x, ("m", "n")))], ("k", "m")),   # a second one
+    ]
+    want = [c() for c in calls]
+    t.cuda.synchronize()
+    with t.no_grad(), N.deferring():
+        with N.may_defer():
+            got = [c() for c in calls]
+            assert N.n_pending() == len(calls)
+        N.flush()
+    for a, b in zip(got, want):
+        assert t.equal(a, b)
+
+
+@pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown"),
+                                           ("e2e_movielens_K30.pt", "movielens"), ("e2e_bus_breakdown_K30.pt", "bus_breakdown")])
+def test_end_to_end_the_elbo_is_the_same_with_the_logits_computed_in_the_producer(fixture, model, monkeypatch):
+    """fp32 observations (the fixtures' are fp64, which keeps the evaluated-lambda route): the ELBO with the lambda left
+    to the producer equals the ELBO with the lambda evaluated by torch, and both the reference's."""
+    from alan_amd import dist as D
+    fx = load_golden(fixture)
+    prob = models.BUILDERS[model](fx).to(DEV).float()
+    sample = models.sample_from_fixture(prob, fx, DEV)
+    ref = float(fx["elbo"]["no_checkpoint"])
+    taken = []
+    orig = E.bernoulli_linear_logprob
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        taken.append(out is not None)
+        return out
+
+    monkeypatch.setattr(E, "bernoulli_linear_logprob", spy)
+    strategies = [alan.no_checkpoint, alan.checkpoint]
+    if model == "movielens":
+        strategies.append(alan.Split("plate_1", 38))
+    for strat in strategies:
+        on = float(sample.elbo_nograd(strat, graph=False))
+        assert taken and all(taken), taken
+        monkeypatch.setattr(D, "LINEAR_LOGITS", False)
+        n = len(taken)
+        off = float(sample.elbo_nograd(strat, graph=False))
+        assert len(taken) == n                      # the lambda was evaluated by torch
+        monkeypatch.setattr(D, "LINEAR_LOGITS", True)
+        assert abs(on - off) <= 2e-6 * abs(off), (on, off)
+        assert abs(on - ref) <= 1e-4 * abs(ref), (on, ref)
+    # replayed graphs and gradient-carrying evaluations agree as well (RWS: the likelihood's operands carry no gradient)
+    g1 = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
+    assert abs(g1 - float(sample.elbo_nograd(alan.no_checkpoint, graph=False))) <= 1e-6 * abs(g1)
+    rws = float(sample.elbo_rws(alan.no_checkpoint))
+    assert abs(rws - g1) <= 2e-6 * abs(g1)
