@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -496,6 +497,155 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Up to FIVE rounds of the tree in one launch for K <= 32, fp32, one WAVE per product (the K x K x K contraction is 16
+// v_mfma_f32_32x32x2_f32 on operands held in registers).  A workgroup of 16 waves takes 32 consecutive nodes: 16
+// products side by side in its first round, then 8, 4, 2, 1; T = 1000 is 2 launches (5 + 5 rounds) instead of the 4 of
+// chain_tree_kernel, whose rounds each cost several barriers and an LDS-operand vector product.
+//   * operand layouts: lane (i, h) of the LEFT child holds P[i][k(r, h)], lane (j, h) of the RIGHT child holds
+//     C[k(r, h)][j], r = 0..15, with k(r, h) = (r & 3) + 8 (r >> 2) + 4 h -- the row a lane's accumulator register r
+//     stands for.  The order of k inside the contraction is free as long as A and B agree, so step r of the MFMA chain
+//     takes the pair k(r, 0), k(r, 1).
+//   * a product's result goes to an LDS tile [32][33] (read next round in either layout, conflict-free both ways) and,
+//     fire-and-forget, into the tree in global memory for the backward; pads (row or column >= K) are kept at -inf.
+// Same normalisation, eps and bracketing as utils.py:503-507; an odd leftover passes through (utils.py:488-495).
+constexpr int WAVE_ROUNDS = 5, WAVE_TILE = 32 * 33;
+
+struct WaveOuts {
+    float *o[WAVE_ROUNDS];
+    int n[WAVE_ROUNDS];
+};
+
+template <int NADD>         // further terms added to the input on load (ChainAdd), 0..2
+__global__ __launch_bounds__(1024) void chain_wave_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
+                                                          int64_t sCol, int n_in, int K, int rounds, const WaveOuts outs,
+                                                          float *vec_out, const ChainAdd<float> ad) {
+    extern __shared__ __align__(16) float wl[];
+    const int NW = blockDim.x >> 6;                      // waves = products of the first round = 2^(rounds - 1)
+    float *tiles = wl;                                   // NW tiles written by rounds 0, 2, 4, then NW / 2 by rounds 1, 3
+    float *pmv = wl + (NW + NW / 2 + 1) * WAVE_TILE;     // [NW][32]: the row maxima of a wave's left operand
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h4 = (lane >> 5) * 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: branches on it are scalar, pointers SGPRs
+    const int64_t b = blockIdx.y;
+    const int seg = blockIdx.x, W = 1 << rounds;
+    const float NINF = -__builtin_huge_valf();
+    const uint32_t OOB = 0x80000000u;
+    ms += b * sB;
+    int m = min(W, n_in - seg * W);                      // nodes entering the current round, in this workgroup
+#define KROW(r) (((r) & 3) + 8 * ((r) >> 2) + h4)
+
+    for (int l = 0; l < rounds; ++l) {
+        const int nprod = NW >> l;                       // waves with a node to make this round
+        const bool exists = w < nprod && 2 * w < m, pair = w < nprod && 2 * w + 1 < m;
+        const float *src_tiles = tiles + ((l & 1) ? 0 : NW * WAVE_TILE);      // what round l - 1 wrote
+        float *dst = tiles + ((l & 1) ? NW * WAVE_TILE : 0) + w * WAVE_TILE;
+        // this node in the tree (global memory, for the backward): a buffer of K * K floats; lanes outside the matrix
+        // get an offset beyond it and the hardware drops their stores
+        const bool store = exists && outs.o[l] != nullptr;
+        const float *node = store ? outs.o[l] + ((b * outs.n[l]) + (int64_t)seg * (W >> (l + 1)) + w) * (int64_t)(K * K) : ms;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(node), 0, store ? K * K * 4 : 0, 0x00020000);
+        const uint32_t lane_boff = (j < K) ? (uint32_t)((h4 * K + j) * 4) : OOB;
+        float pa[16], pb[16];
+        if (exists) {
+            // ---- operands: round 0 from global memory (pads -> -inf), later rounds from the tiles
+            if (l == 0) {
+                // 32-bit element offsets from wave-uniform bases (the host checked that a matrix spans < 2^31 elements)
+                auto load_node = [&](int64_t tn, bool rowwise, float(&dstv)[16]) {
+                    const float *p0 = ms + tn * sT;
+                    const float *p1 = NADD > 0 ? ad.p[0] + b * ad.sB[0] + tn * ad.sT[0] : p0;
+                    const float *p2 = NADD > 1 ? ad.p[1] + b * ad.sB[1] + tn * ad.sT[1] : p0;
+                    const int r0 = (int)sRow, c0 = (int)sCol, r1 = (int)ad.sR[0], c1 = (int)ad.sC[0], r2 = (int)ad.sR[1],
+                              c2 = (int)ad.sC[1];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = KROW(r);
+                        const bool ok = j < K && k < K;
+                        const int ii = ok ? (rowwise ? j : k) : 0, jj = ok ? (rowwise ? k : j) : 0;
+                        float v = p0[ii * r0 + jj * c0];
+                        if (NADD > 0) v += p1[ii * r1 + jj * c1];
+                        if (NADD > 1) v += p2[ii * r2 + jj * c2];
+                        dstv[r] = ok ? v : NINF;
+                    }
+                };
+                const int64_t ta = (int64_t)seg * W + 2 * w;
+                load_node(ta, pair, pa);                 // (a leftover is read like a right child: the tile layout)
+                if (pair) load_node(ta + 1, false, pb);
+            } else {
+                const float *TL = src_tiles + (2 * w) * WAVE_TILE, *TR = TL + WAVE_TILE;
+                const float *la = pair ? TL + j * 33 + h4 : TL + h4 * 33 + j;       // row-wise (left child) / tile layout
+                const int stepa = pair ? 1 : 33;
+                const float *lb = TR + h4 * 33 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kc = (r & 3) + 8 * (r >> 2);
+                    pa[r] = la[kc * stepa];
+                    if (pair) pb[r] = lb[kc * 33];
+                }
+            }
+        }
+        if (pair) {
+            float pm = pa[0], cm = pb[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) pm = fmaxf(pm, pa[r]), cm = fmaxf(cm, pb[r]);
+            pm = fmaxf(pm, __shfl_xor(pm, 32));
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            chain_f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)                  // utils.py:503-505 (pads: exp(-inf - finite) = 0)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Num<float>::exp(pa[r] - pm), Num<float>::exp(pb[r] - cm), acc, 0,
+                                                           0, 0);
+            if (h4 == 0) pmv[w * 32 + j] = pm;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const chain_f32x4 *pm4 = reinterpret_cast<const chain_f32x4 *>(pmv + w * 32 + h4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const chain_f32x4 pmq = pm4[2 * q];       // rows 8 q + h4 .. + 3
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int r = 4 * q + c, kc = c + 8 * q;
+                    float v = __logf(acc[r] + Num<float>::eps) + pmq[c] + cm;     // utils.py:506-507 (acc + eps >= eps: v_log_f32 is exact to 1 ulp there)
+                    const bool in = kc + h4 < K && j < K;
+                    v = in ? v : NINF;
+                    dst[(kc + h4) * 33 + j] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc,
+                                                          kc + h4 < K ? lane_boff : OOB, kc * K * 4, 0);
+                }
+            }
+        } else if (exists) {                              // the leftover of this round passes through (utils.py:488-495)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kc = (r & 3) + 8 * (r >> 2);
+                dst[(kc + h4) * 33 + j] = pa[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, pa[r]), rsrc,
+                                                      kc + h4 < K ? lane_boff : OOB, kc * K * 4, 0);
+            }
+        }
+        __syncthreads();
+        m = (m + 1) >> 1;
+    }
+#undef KROW
+    if (vec_out && w == 0) {                             // torch.logsumexp(lp, -1)  (logpq.py:139): no eps
+        // lane (i, h): row i, columns 16 h .. 16 h + 15; the halves are merged by one exchange
+        const float *R = tiles + (((rounds - 1) & 1) ? NW * WAVE_TILE : 0) + j * 33 + 4 * h4;
+        float x[16], mx = NINF;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            x[c] = R[c];                                  // (pads hold -inf)
+            mx = fmaxf(mx, x[c]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mref = (mx == NINF || mx == -NINF) ? 0.f : mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sum += expf(x[c] - mref);
+        sum += __shfl_xor(sum, 32);
+        if (lane < K) vec_out[b * K + lane] = logf(sum) + mref;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The tree in memory: round r = 1..L holds n_r = ceil(n_{r-1} / 2) matrices per chain ([B][n_r][K][K], each round
 // 256-byte aligned), n_0 = T, n_L = 1 (the root = chain_logmmexp(ms)); T = 1 has one round holding a copy of ms[0].
 struct TreeLayout {
@@ -547,7 +697,57 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
     const T *src = (const T *)ms_;
     int64_t cB = sB, cT = sT, cR = sRow, cC = sCol;
     static const bool per_round = env_knob("ALAN_CHAIN_PER_ROUND") != ENV_UNSET;  // ablation: one round per launch
-    if (K <= 32 && !per_round) {
+    static const bool no_wave = env_knob("ALAN_CHAIN_WAVE") == 0;                     // ablation: chain_tree_kernel instead
+    bool fits32 = true;                                   // the wave kernel's 32-bit offsets inside one matrix
+    {
+        auto span = [&](int64_t r, int64_t c) { return ((r < 0 ? -r : r) + (c < 0 ? -c : c)) * (K - 1) < (1ll << 31) - 1; };
+        fits32 = span(sRow, sCol);
+        for (int q = 0; q < n_more; ++q) fits32 = fits32 && span(ad0.sR[q], ad0.sC[q]);
+    }
+    // (below K ~ 12 the vector-unit tree kernel is as fast or faster: a 32 x 32 MFMA tile is mostly padding there)
+    if (K > 12 && K <= 32 && !per_round && !no_wave && fits32 && std::is_same<T, float>::value) {
+        const size_t wsmem = (size_t)(25 * WAVE_TILE + 16 * 32) * sizeof(float);     // the largest launch (5 rounds)
+        for (auto fn : {(const void *)chain_wave_kernel<0>, (const void *)chain_wave_kernel<1>, (const void *)chain_wave_kernel<2>})
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsmem) != hipSuccess)
+                return ALAN_ERR_LAUNCH;
+        ChainAdd<float> adf, nonef;
+        std::memcpy(&adf, &ad0, sizeof(adf));             // (T is float here)
+        std::memset(&nonef, 0, sizeof(nonef));
+        // rounds per launch: 2^(rounds - 1) waves per workgroup, so few rounds while there are many nodes (the first
+        // round of a launch runs 2^(rounds - 3) products per SIMD) and all the rest in the last launch
+        static const int sched_knob = env_knob("ALAN_CHAIN_SCHED");                      // tuning knob: e.g. 334 = 3, 3, 4
+        int digits[12], nd = 0;
+        if (sched_knob != ENV_UNSET && sched_knob > 0)
+            for (int v = sched_knob; v > 0 && nd < 12; v /= 10) digits[nd++] = v % 10;
+        for (int r = 0, li = 0; r < tl.L; ++li) {
+            int rounds = std::min(WAVE_ROUNDS, tl.L - r);
+            if (nd) {
+                const int want = li < nd ? digits[nd - 1 - li] : WAVE_ROUNDS;
+                rounds = std::min(std::max(1, std::min(want, WAVE_ROUNDS)), tl.L - r);
+            } else if (tl.n[r] * B > 64) {
+                rounds = std::min(3, tl.L - r);
+            }
+            const int nw = 1 << (rounds - 1);
+            const size_t lsmem = (size_t)((nw + nw / 2 + 1) * WAVE_TILE + nw * 32) * sizeof(float);
+            const int64_t nseg = (tl.n[r] + (1 << rounds) - 1) >> rounds;
+            WaveOuts wo;
+            std::memset(&wo, 0, sizeof(wo));
+            for (int q = 0; q < rounds; ++q) wo.o[q] = (float *)((char *)ws + tl.off[r + 1 + q]), wo.n[q] = (int)tl.n[r + 1 + q];
+            const bool last = r + rounds == tl.L;
+            const int nadd = r == 0 ? n_more : 0;
+            auto wk = nadd == 0 ? chain_wave_kernel<0> : nadd == 1 ? chain_wave_kernel<1> : chain_wave_kernel<2>;
+            hipLaunchKernelGGL(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
+                               (const float *)src, cB, cT, cR, cC, (int)tl.n[r], (int)K, rounds, wo,
+                               last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef);
+            if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            r += rounds;
+            src = (const T *)wo.o[rounds - 1];
+            cB = tl.n[r] * K * K;
+            cT = K * K;
+            cR = K;
+            cC = 1;
+        }
+    } else if (K <= 32 && !per_round) {
         const size_t slot = (KP * (KP + 4) + KP * KP + 2 * KP) * sizeof(T);
         auto tk = chain_tree_kernel<T>;
         if (hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * slot)) != hipSuccess)
