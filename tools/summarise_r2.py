@@ -15,8 +15,8 @@ csv.field_size_limit(1 << 30)
 
 def one(pattern):
     hits = glob.glob(os.path.join(RAW, pattern), recursive=True)
-    assert len(hits) == 1, (pattern, hits)
-    return hits[0]
+    assert hits, pattern
+    return max(hits, key=os.path.getmtime)        # (gpurun merges into the local copy: older collections may linger)
 
 
 bench = json.load(open(os.path.join(RAW, "bench_full.json")))
