@@ -403,6 +403,20 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     int64_t nch = std::max<int64_t>(1, std::min<int64_t>(a.M, target / std::max<int64_t>(1, gx)));
     nch = std::min<int64_t>(nch, 65535);
     p.m_chunk = (int)((a.M + nch - 1) / nch);
+    if (blocks_knob == ENV_UNSET) {
+        // Balance: workgroups spread evenly over the 256 CUs, so the launch lasts as long as the CU with the most of
+        // them -- ceil(workgroups / 256) x (plate elements per workgroup).  Among the chunkings that keep the chip
+        // between ~2 and ~4 waves per SIMD take the cheapest, fewer workgroups on a tie (K=100, M=75: 475 workgroups of
+        // 4 users instead of 625 of 3 -- 98 against 112 us; M=300 and the K=30 launch keep their measured optimum).
+        int64_t best = -1, best_cost = 0;
+        for (int64_t mc = a.M; mc >= 1; --mc) {
+            const int64_t chunks = (a.M + mc - 1) / mc, wgs = gx * chunks;
+            if (chunks > 65535 || wgs < 450 || wgs > 1100) continue;
+            const int64_t cost = ((wgs + 255) / 256) * mc;
+            if (best < 0 || cost < best_cost) best = mc, best_cost = cost;
+        }
+        if (best > 0) p.m_chunk = (int)best;
+    }
     p.n_chunks = (int)((a.M + p.m_chunk - 1) / p.m_chunk);
     p.part_bytes = (size_t)p.n_chunks * a.NL * a.NS * sizeof(float);
     p.grid = dim3((uint32_t)gx, (uint32_t)p.n_chunks);
