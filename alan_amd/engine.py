@@ -60,10 +60,10 @@ class ResultRing:
     def __init__(self, device):
         self.device = device
         self.n = self.SLOTS
-        self.slots = [t.zeros((), dtype=t.float32, device=device) for _ in range(self.n)]
+        self.slots = [t.empty((), dtype=t.float32, device=device) for _ in range(self.n)]
         self.table = t.tensor([s.data_ptr() for s in self.slots], dtype=t.int64, device=device)
         self.counter = t.zeros((), dtype=t.int32, device=device)
-        self.placeholder = t.zeros((), dtype=t.float32, device=device)     # stands for "the current slot" while tracing
+        self.placeholder = t.empty((), dtype=t.float32, device=device)     # stands for "the current slot" while tracing
         self.idle = _use_count(self.slots[0])      # references to a slot's storage when only the ring holds it
         self.pos = 0
         self.taken = 0          # launches that wrote through the ring since reset()

@@ -503,6 +503,16 @@ def test_replayed_results_are_delivered_through_the_ring_and_outlive_their_slot(
     # the host's idea of the position matches the device counter
     t.cuda.synchronize()
     assert int(g.ring.counter) == g.ring.pos
+    # more live results than slots, every one a different value: none is overwritten
+    kept, want_kept = [], []
+    for i in range(2 * n + 7):
+        with t.no_grad():
+            next(iter(prob.Q.parameters())).add_(0.01)
+        kept.append(g())
+        want_kept.append(float(plain()))
+    assert len(set(want_kept)) > n
+    assert [float(v) for v in kept] == want_kept
+    assert len({v.data_ptr() for v in kept}) == len(kept)
 
 
 @pytest.mark.gpu

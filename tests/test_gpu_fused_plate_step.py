@@ -19,7 +19,8 @@ DEV = "cuda"
 @pytest.mark.parametrize("M,NK,NL,NS,Ev,n_small,log_scale", [
     (300, 30, 30, 30, 18, 2, False), (38, 100, 100, 100, 18, 2, False), (7, 5, 4, 3, 3, 0, False),
     (11, 33, 9, 70, 20, 1, True), (5, 8, 40, 31, 1, 3, True), (3, 64, 2, 32, 32, 4, False), (4, 16, 5, 128, 9, 1, False),
-    (6, 10, 7, 50, 18, 2, True), (3, 9, 5, 200, 2, 1, False), (9, 97, 3, 33, 17, 2, False), (2, 130, 2, 5, 31, 0, True), (5, 12, 6, 40, 32, 2, False)])
+    (6, 10, 7, 50, 18, 2, True), (3, 9, 5, 200, 2, 1, False), (9, 97, 3, 33, 17, 2, False), (2, 130, 2, 5, 31, 0, True), (5, 12, 6, 40, 32, 2, False),
+    (4, 40, 3, 100, 18, 1, False), (3, 72, 2, 64, 5, 2, True), (3, 41, 2, 64, 7, 0, False), (5, 37, 4, 128, 18, 3, True)])   # (last k tile of <= 8 rows: vector-unit tail)
 def test_fused_plate_step_matches_the_two_launch_route_and_the_oracle(M, NK, NL, NS, Ev, n_small, log_scale):
     g = t.Generator().manual_seed(M + NK + NS)
     pl, K, dl, ds = Dim("plate", M), Dim("K", NK), Dim("Kl", NL), Dim("Ks", NS)

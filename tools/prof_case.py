@@ -12,8 +12,9 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 if which in ("vi", "rws"):
     prob = bench.build_problem("cuda")
-    opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, maximize=True) if which == "rws"
-           else t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True))
+    # as bench.py's training_iteration leg: fused=True = one multi-tensor kernel per Adam step
+    opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, fused=True, maximize=True) if which == "rws"
+           else t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True, fused=True))
     step = GraphedStep(prob, K, opt, method=which)
     for _ in range(n):
         v = step()
