@@ -61,8 +61,16 @@ constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530
 // read from the wave's LDS tile.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int EH, int NST, bool STAGE, int NLW = 1, bool RAG = false>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
+//
+// FLAT (STAGE, NLW = 1, NK > 32 not a multiple of 32, plate elements contiguous in memory): the k rows of a wave's
+// plate elements are walked as ONE run of (m1 - m0) * NK rows in tiles of 32, so only the run's last tile is padded --
+// per-element tiles leave the last of ceil(NK / 32) mostly empty (NK = 100: 4 rows of 32; a quarter of the launch).  A
+// tile then holds the end of one plate element (rows below `bnd`) and the start of the next: two log-sum-exp states
+// per unit, rows assigned by a compare per group of four accumulator registers (NK % 4 == 0), the finished element's
+// state retired after the tile.
+template <int EH, int NST, bool STAGE, int NLW = 1, bool RAG = false, bool FLAT = false>   // EH: MFMA steps >= ceil((E + 1) / 2) -- the event dim plus the small-factor slot
 __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
+    static_assert(!FLAT || (STAGE && NLW == 1), "flat row tiling: staged loads, one loc row per wave");
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -127,7 +135,8 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         lgn16 = lg + (float)E * 0.91893853320467274178f;
     }
     const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
-    const int n_tiles = wave_on ? (m1 - m0) * nkt : 0;
+    const int rows_total = (m1 - m0) * NK;            // FLAT: the wave's run of k rows
+    const int n_tiles = wave_on ? (FLAT ? (rows_total + 31) >> 5 : (m1 - m0) * nkt) : 0;
     // Tile t = (plate element m0 + t / nkt, k tile t % nkt), walked with counters (no division in the loop).  Everything
     // that addresses a tile is the same for all four waves (they share blockIdx.y): a scalar base plus a 32-bit lane
     // offset.  Loads are issued from clamped, always valid addresses, all of them before anything waits; masks are
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     float *tile = lds + wave * (32 * 33);
     uint32_t soff[NX];                                // STAGE: LDS slot of float lane + 64 q: row * (E + 1) + column
     if (STAGE) {
-        if (NK & 31)                                  // rows beyond NK are never written: keep them finite
+        if (FLAT || (NK & 31))                        // rows beyond NK are never written: keep them finite
             for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;
         // (row, column) of float lane + 64 q, stepped by 64 floats = (64 / E) rows + (64 % E) columns: one division
         const int r64 = 64 / E, c64 = 64 - r64 * E;
@@ -171,24 +180,62 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         }
         asm volatile("" ::: "memory");
     };
+    // FLAT: tile tt = rows 32 tt .. of the run; (pm, pk) = the plate element and k of the FIRST row of the tile being
+    // loaded (wave-uniform), advanced by 32 rows per tile (NK > 32: at most one wrap; a lane's row wraps once more)
+    int pm = m0, pk = 0;
+    auto load_flat = [&](int tt, float (&x)[NX], float (&hs)[4]) {
+        const float *vp = d.val + (int64_t)m0 * d.v_sm + (int64_t)(32 * tt) * E;          // (uniform)
+        const int rows = min(32, rows_total - 32 * tt);
+        const uint32_t lim = (uint32_t)(rows * E - 1);
+#pragma unroll
+        for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        int lm = pm, lk = pk + j;                     // this lane's row
+        if (lk >= NK) lk -= NK, ++lm;
+        const bool in = lm < m1;
+        const uint32_t mm = (uint32_t)((in ? lm : m1 - 1) - m0), kk = (uint32_t)(in ? lk : NK - 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float *sp = d.small[f] + (int64_t)m0 * d.small_sm[f];                      // (uniform)
+            hs[f] = sp[mm * (uint32_t)d.small_sm[f] + kk * (uint32_t)d.small_sk[f]];
+        }
+        pk += 32;
+        if (pk >= NK) pk -= NK, ++pm;
+        asm volatile("" ::: "memory");
+    };
     float zc[NX], zn[NX], hc[4], hn[4];
-    if (n_tiles > 0) load_tile(m0, 0, zc, hc);
+    if (n_tiles > 0) {
+        if (FLAT)
+            load_flat(0, zc, hc);
+        else
+            load_tile(m0, 0, zc, hc);
+    }
     constexpr int NU = NLW * NST;                     // units of work per value tile: (loc row, scale tile) pairs
     float accm[NU], mn[NU], sm[NU];                   // plate sum; running minimum of D (= -max, base 2) and sum 2^(mn - D)
 #pragma unroll
     for (int u = 0; u < NU; ++u) accm[u] = 0.f, mn[u] = inf, sm[u] = 0.f;
+    int rem_a = NK;                                   // FLAT: rows the current plate element still has to come
     const float n_small_mask[4] = {d.n_small > 0 ? 1.f : 0.f, d.n_small > 1 ? 1.f : 0.f, d.n_small > 2 ? 1.f : 0.f,
                                    d.n_small > 3 ? 1.f : 0.f};
     int kt = 0, m = m0;
     for (int t = 0; t < n_tiles; ++t) {
-        {
+        if (FLAT) {
+            if (t + 1 < n_tiles) load_flat(t + 1, zn, hn);
+        } else {
             int kt_n = kt + 1, m_n = m;
             if (kt_n == nkt) kt_n = 0, ++m_n;
             if (t + 1 < n_tiles) load_tile(m_n, kt_n, zn, hn);
         }
+        // FLAT: rows of this tile, and how many of them belong to the current plate element (the rest start the next)
+        const int valid = FLAT ? min(32, rows_total - 32 * t) : 32;
+        const int bnd = FLAT ? min(rem_a, valid) : 32;
+        const bool split = FLAT && bnd < valid;       // (wave-uniform)
+        // the state of the plate element that begins inside this tile (it becomes the current one when the tile is done)
+        float mnb[NU], smb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) mnb[u] = inf, smb[u] = 0.f;
         // A operand.  No masks: pad events meet a zero in B; rows beyond NK (and plate elements' -inf small factors)
         // put +inf into the small-factor slot, which makes their whole row of D +inf = a log-prob of -inf
-        const bool k_ok = 32 * kt + j < NK;
+        const bool k_ok = FLAT ? j < valid : 32 * kt + j < NK;
         float hsum = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) hsum += n_small_mask[f] != 0.f ? hc[f] : 0.f;
@@ -227,6 +274,33 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tmin = fminf(tmin, acc4[b][r]);
             }
+            if (split) {
+                // rows 16 b + 4 q4 + r below bnd end the current plate element, the others begin the next
+                float ta = inf, tb = inf;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool isa = 16 * b + 4 * q4 < bnd;            // (NK % 4 == 0: a lane's four rows go together)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ta = isa ? fminf(ta, acc4[b][r]) : ta;
+                        tb = isa ? tb : fminf(tb, acc4[b][r]);
+                    }
+                }
+                const float mnew = fminf(mn[u], ta);
+                const float mfa = mnew == inf ? 0.f : mnew, mfb = tb == inf ? 0.f : tb;
+                float ssa = sm[u] * __builtin_amdgcn_exp2f(mfa - (mn[u] == inf ? mfa : mn[u])), ssb = 0.f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool isa = 16 * b + 4 * q4 < bnd;
+                    const float mfx = isa ? mfa : mfb;
+                    float part = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part += __builtin_amdgcn_exp2f(mfx - acc4[b][r]);
+                    ssa += isa ? part : 0.f;
+                    ssb += isa ? 0.f : part;
+                }
+                mn[u] = mnew, sm[u] = ssa, mnb[u] = tb, smb[u] = ssb;
+            } else {
             const float mnew = fminf(mn[u], tmin);
             const float mf = mnew == inf ? 0.f : mnew;
             float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
@@ -235,6 +309,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc4[b][r]);
             mn[u] = mnew, sm[u] = ssum;
+            }
         }
 #pragma unroll
         for (int u = 0; u < NU - (RAG ? 1 : 0); ++u) {
@@ -254,6 +329,31 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             // acc[r] = -log2(e) (log-prob + small) of row k = 32 kt + (r & 3) + 8 (r >> 2) + 4 h (normaliser apart):
             // online log-sum-exp down the registers, branch-free (an infinite minimum is replaced by 0 where it
             // enters a difference: 2^(0 - inf) = 0, and the sum it would scale is 0)
+            if (split) {
+                // rows (r & 3) + 8 (r >> 2) + 4 h below bnd end the current plate element, the others begin the next
+                float ta = inf, tb = inf;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                 // (NK % 4 == 0: the four rows of a register group go together)
+                    const bool isa = 8 * g + 4 * h < bnd;
+                    const float t4 = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+                    ta = isa ? fminf(ta, t4) : ta;
+                    tb = isa ? tb : fminf(tb, t4);
+                }
+                const float mnew = fminf(mn[u], ta);
+                const float mfa = mnew == inf ? 0.f : mnew, mfb = tb == inf ? 0.f : tb;
+                float ssa = sm[u] * __builtin_amdgcn_exp2f(mfa - (mn[u] == inf ? mfa : mn[u])), ssb = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const bool isa = 8 * g + 4 * h < bnd;
+                    const float mfx = isa ? mfa : mfb;
+                    float part = 0.f;
+#pragma unroll
+                    for (int r = 4 * g; r < 4 * g + 4; ++r) part += __builtin_amdgcn_exp2f(mfx - acc[r]);
+                    ssa += isa ? part : 0.f;
+                    ssb += isa ? 0.f : part;
+                }
+                mn[u] = mnew, sm[u] = ssa, mnb[u] = tb, smb[u] = ssb;
+            } else {
             float tmin = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
@@ -263,8 +363,10 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc[r]);
             mn[u] = mnew, sm[u] = ssum;
+            }
         }
-        if (++kt == nkt) {                            // plate element done: join the two half-waves, add to the plate sum
+        if (FLAT) rem_a -= bnd;
+        if (FLAT ? rem_a == 0 : ++kt == nkt) {        // plate element done: join the two half-waves, add to the plate sum
             if (RAG) {                                // (the 16-wide tile's rows are spread over the four lane quarters)
                 constexpr int u = NU - 1;
                 float mm = mn[u], tot = sm[u];
@@ -281,7 +383,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
                 if (mm == inf || mm == -inf) lse_m = __builtin_nanf("");
                 accm[u] += lse_m;
                 if (d.lse && lane < 16 && s16 < NS) d.lse[((int64_t)m * d.NL + l) * NS + s16] = lse_m;
-                mn[u] = inf, sm[u] = 0.f;
+                mn[u] = mnb[u], sm[u] = smb[u];           // (empty unless the tile was split)
             }
 #pragma unroll
             for (int u = 0; u < NU - (RAG ? 1 : 0); ++u) {
@@ -297,9 +399,10 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
                 accm[u] += lse_m;
                 const int s = 32 * (sg * NST + st) + j;
                 if (d.lse && h == 0 && s < NS && l + lw < d.NL) d.lse[((int64_t)m * d.NL + l + lw) * NS + s] = lse_m;
-                mn[u] = inf, sm[u] = 0.f;
+                mn[u] = mnb[u], sm[u] = smb[u];
             }
             kt = 0, ++m;
+            if (FLAT) rem_a = NK - (valid - bnd);     // (the rows of this tile that already belong to the next element)
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) zc[i] = zn[i];
@@ -468,8 +571,18 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
-#define NL_PICK(EHV, NSTV) (rag && NSTV > 1 ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1)>) \
-                            : stage ? launch(normal_lse_mfma_kernel<EHV, NSTV, true>) : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
+    // flat row tiling (see the kernel): the plate elements' k rows as one run
+    static const int flat_knob = env_knob("ALAN_NLSE_FLAT");                          // ablation knob: 0 = off
+    bool flat = stage && p.nlw == 1 && a->NK > 32 && (a->NK & 31) != 0 && (a->NK & 3) == 0 && a->v_sm == a->NK * a->E &&
+                flat_knob != 0;                   // (NK % 4: a lane's groups of four accumulator rows never straddle two elements)
+    for (int f = 0; f < a->n_small; ++f)          // (32-bit lane offsets into a small factor, inside one chunk of the plate)
+        flat = flat && a->small_sm[f] >= 0 && a->small_sk[f] >= 0 &&
+               (int64_t)p.m_chunk * a->small_sm[f] + a->NK * a->small_sk[f] < (1ll << 31);
+#define NL_PICK(EHV, NSTV) (rag && NSTV > 1 ? (flat ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1), true>) \
+                                                    : launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1)>)) \
+                            : stage ? (flat ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, false, true>) \
+                                            : launch(normal_lse_mfma_kernel<EHV, NSTV, true>)) \
+                                    : launch(normal_lse_mfma_kernel<EHV, NSTV, false>))
 #define NL_PICK2(EHV) (stage ? launch(normal_lse_mfma_kernel<EHV, 1, true, 2>) : launch(normal_lse_mfma_kernel<EHV, 1, false, 2>))
 #define NL_CASE(EHV)                                                                                   \
     case EHV:                                                                                          \
