@@ -70,6 +70,8 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
         const T y = val[0], xl = val[1];
         const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
         s += ok ? ls - (T(1) - y) * xl : T(0);
+    } else if (MODE == ALAN_MODE_DOT) {
+        s += ok ? val[0] * val[1] : T(0);
     } else {
         T x = T(0);
 #pragma unroll
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
         case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
         case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
         case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM>(d, logG, block, bid); break;   // (per-factor backward launches)
+        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT>(d, logG, block, bid); break;
         case ALAN_MODE_BERNOULLI_LINEAR: {
             const LinDesc &ld = *reinterpret_cast<const LinDesc *>(
                 (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallMulti, lin)));
@@ -579,6 +582,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
         case ALAN_MODE_LSE: launch_small_T<ALAN_MODE_LSE>(sd, gl, stream, ev); break;
         case ALAN_MODE_SUM: launch_small_T<ALAN_MODE_SUM>(sd, gl, stream, ev); break;
         case ALAN_MODE_WEXPSUM: launch_small_T<ALAN_MODE_WEXPSUM>(sd, gl, stream, ev); break;
+        case ALAN_MODE_DOT: launch_small_T<ALAN_MODE_DOT>(sd, gl, stream, ev); break;
         case ALAN_MODE_NORMAL: launch_small_T<ALAN_MODE_NORMAL>(sd, gl, stream, ev); break;
         case ALAN_MODE_NORMAL_LOGSCALE: launch_small_T<ALAN_MODE_NORMAL_LOGSCALE>(sd, gl, stream, ev); break;
         case ALAN_MODE_BERNOULLI: launch_small_T<ALAN_MODE_BERNOULLI>(sd, gl, stream, ev); break;
@@ -608,6 +612,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_LSE: return launch_group_T<T, ALAN_MODE_LSE>(gd, gl, stream, ev);  \
         case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream, ev);  \
         case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream, ev); \
+        case ALAN_MODE_DOT: return launch_group_T<T, ALAN_MODE_DOT>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
         case ALAN_MODE_BERNOULLI: return launch_group_T<T, ALAN_MODE_BERNOULLI>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL_LOGSCALE: return launch_group_T<T, ALAN_MODE_NORMAL_LOGSCALE>(gd, gl, stream, ev); \

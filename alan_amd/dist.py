@@ -705,11 +705,17 @@ def _linear_pt(fn, named_args, form, dimcache):
 
 
 def _dot_pt(a, b):
-    """sum over the single positional dim of a * b, broadcast over first-class dims, as one (batched) GEMM."""
+    """sum over the single positional dim of a * b, broadcast over first-class dims: one launch of the library's own
+    (mode DOT -- it may sit in the queue of small producer launches), or a (batched) GEMM for dtypes it does not take."""
+    dims, ids = pt_order((a, b))
+    if a.x.dtype == t.float32 and b.x.dtype == t.float32:
+        from . import engine as E
+        from . import native as N
+        with N.may_defer():
+            return PT(E.dot_sum((a.x, a.dims), (b.x, b.dims), dims), dims)
     letters = {}
     sub = lambda p: "".join(letters.setdefault(i, chr(ord("a") + len(letters))) for i in p.ids)
     sa, sb = sub(a), sub(b)
-    dims, ids = pt_order((a, b))
     return PT(t.einsum(f"{sa}Z,{sb}Z->{''.join(letters[i] for i in ids)}", a.x, b.x), dims)
 
 
@@ -723,13 +729,17 @@ def _producer_terms(value, terms):
         for d, i in zip(p.dims, p.ids):
             sizes[i] = d.size
     total = math.prod(sizes.values())
-    out = []
+    out, flush = [], False
     for term in terms:
         if len(term) == 2:
             own = {i for p in term for i in p.ids}
             if math.prod(sizes[i] for i in own) < total:
                 term = (_dot_pt(*term),)
+                flush = True
         out.append(tuple((p.x, p.dims) for p in term))
+    if flush:
+        from . import native as N
+        N.flush()              # the producer launch that reads these terms may be queued too: they go out first
     return out
 
 

@@ -583,6 +583,13 @@ def bernoulli_logprob(value, logits, out_dims, affine=(1.0, 0.0)):
     return _produce(N.MODE_BERNOULLI, (value, logits), out_dims, affine)
 
 
+def dot_sum(a, b, out_dims):
+    """sum over the trailing positional dim(s) -- and any first-class dim missing from ``out_dims`` -- of a * b, as one
+    launch (alan_reduce mode DOT; small ones ride in a queued multi-problem launch): a term ``phi @ bus_company_name`` of
+    a model lambda, evaluated once.  Each argument is (tensor, leading first-class dims)."""
+    return _produce(N.MODE_DOT, (a, b), out_dims)
+
+
 def bernoulli_linear_logprob(value, terms, out_dims, affine=(1.0, 0.0)):
     """log Bernoulli(value; logits = sum of ``terms``) summed over every first-class dim missing from ``out_dims``, as
     ONE launch that computes the logits itself (alan_reduce mode BERNOULLI_LINEAR): what the reference evaluates as the

@@ -79,7 +79,7 @@ typedef enum {
                               G * d log-prob / d argument, KEEP = that argument's dims.  Which one: factor[0].scale =
                               1: Normal d/d value, 2: d/d loc, 3: d/d scale (d/d log scale when factor[3].scale == 2),
                               4: Bernoulli d/d logits */
-    ALAN_MODE_BERNOULLI_LINEAR = 7 /* ALAN_MODE_BERNOULLI whose logits are a sum of terms computed in the launch instead
+    ALAN_MODE_BERNOULLI_LINEAR = 7, /* ALAN_MODE_BERNOULLI whose logits are a sum of terms computed in the launch instead
                               of by the model's lambda beforehand (movielens `lambda z, x: z @ x`, bus_breakdown
                               `alpha + phi @ bus_company_name + psi @ run_type`: TorchDimDist.py:127-162 evaluating
                               the lambda through torchdim, then Bernoulli.log_prob).  factor[0] = value; the others
@@ -88,6 +88,9 @@ typedef enum {
                               is sum over ONE ALAN_DOT dim of their product.  At most 3 terms; fp32 only
                               (ALAN_ERR_UNSUPPORTED otherwise: evaluate the logits and use ALAN_MODE_BERNOULLI).
                               out = out.scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const */
+    ALAN_MODE_DOT = 8      /* out = sum_R factor_0 * factor_1 (+ add_const): exactly 2 factors.  A term of such logits whose
+                              operands lack some dim of the likelihood's index space, evaluated once (what the lambda's
+                              `phi @ bus_company_name` is); small ones join alan_reduce_batch launches */
 } alan_mode_t;
 /* Producer modes (NORMAL, NORMAL_LOGSCALE, BERNOULLI) write  out = out.scale * sum_R(log-prob) + add_const, so the
  * "-(log Q + log K)" of logpq.py:234-235 costs no extra pass; out.scale must be 1 in the other modes. */

@@ -173,3 +173,21 @@ def test_end_to_end_the_elbo_is_the_same_with_the_logits_computed_in_the_produce
     assert abs(g1 - float(sample.elbo_nograd(alan.no_checkpoint, graph=False))) <= 1e-6 * abs(g1)
     rws = float(sample.elbo_rws(alan.no_checkpoint))
     assert abs(rws - g1) <= 2e-6 * abs(g1)
+
+
+@pytest.mark.parametrize("dtype", [t.float32, t.float64])
+def test_dot_sum_matches_einsum(dtype):
+    """alan_reduce mode DOT: sum over the event dim of a * b, broadcast over first-class dims (a lambda's `phi @ x`)."""
+    g = t.Generator().manual_seed(9)
+    phi = t.randn(7, 11, generator=g, dtype=dtype).to(DEV)
+    bus = t.randn(2, 3, 150, 11, generator=g, dtype=dtype).to(DEV)
+    out = E.dot_sum((phi, ("Kg",)), (bus, ("Y", "B", "I")), ("Kg", "Y", "B", "I"))
+    want = t.einsum("kz,ybiz->kybi", phi.double(), bus.double())
+    t.testing.assert_close(out.double(), want, rtol=3e-6 if dtype == t.float32 else 1e-12, atol=1e-5 if dtype == t.float32 else 1e-12)
+    # strided operands, a shared first-class dim, another output order, a first-class dim summed as well
+    a = t.randn(5, 4, 6, generator=g, dtype=dtype).to(DEV).transpose(0, 1)          # dims (m, k), event 6
+    b = t.randn(4, 9, 12, generator=g, dtype=dtype).to(DEV)[..., ::2]               # dims (m, n), event 6 strided
+    out2 = E.dot_sum((a, ("m", "k")), (b, ("m", "n")), ("n", "k", "m"))
+    t.testing.assert_close(out2.double(), t.einsum("mkz,mnz->nkm", a.double(), b.double()), rtol=3e-6, atol=1e-5)
+    out3 = E.dot_sum((a, ("m", "k")), (b, ("m", "n")), ("k",))
+    t.testing.assert_close(out3.double(), t.einsum("mkz,mnz->k", a.double(), b.double()), rtol=3e-6, atol=1e-4)
