@@ -456,7 +456,7 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
 int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,
                             const EvPair &ev, bool dry) {
     if (c.nf != 3 || c.nr != 1) return ALAN_ERR_UNSUPPORTED;
-    if (c.f[0].scale != 1.f || c.f[2].scale == 2.f) return ALAN_ERR_UNSUPPORTED;   // weighted / flagged terms: generic kernel
+    if (c.f[0].scale != 1.f || c.f[1].scale != 1.f || c.f[2].scale == 2.f) return ALAN_ERR_UNSUPPORTED;   // weighted / scaled / flagged terms: generic kernel
     for (int f = 0; f < 3; ++f)
         if (c.f[f].dtype != ALAN_F32 || c.f[f].rs[0] != 1) return ALAN_ERR_UNSUPPORTED;
     if (c.o.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
 #pragma unroll
         for (int tm = 0; tm < MAXF / 3; ++tm) {
             if (3 * tm < nf) {
-                const T z = val[3 * tm] - val[3 * tm + 1];
+                const T z = val[3 * tm] - (T)scale[3 * tm + 1] * val[3 * tm + 1];      // (loc's scale field: loc = c * raw)
                 const T sc = val[3 * tm + 2];
                 const bool logsc = MODE == ALAN_MODE_NORMAL_LOGSCALE || scale[3 * tm + 2] == 2.f;
                 const T one = logsc

@@ -179,6 +179,39 @@ class ExpPT(PT):
         return ExpPT(self.raw.detach(), self.dims)
 
 
+class ScaledPT(PT):
+    """The value of a model lambda ``c * v`` (a timeseries transition's ``lambda prev: 0.9 * prev``), not evaluated:
+    ``.x`` multiplies on first use, a fused Normal producer takes ``raw`` and the constant instead (the loc factor's
+    scale field) and the multiply launch never happens.  Only built where no gradient is wanted."""
+    __slots__ = ("raw", "mul", "_val")
+
+    def __init__(self, raw, mul, dims=()):
+        self.raw, self.mul = raw, float(mul)
+        self._val = None
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @property
+    def x(self):
+        if self._val is None:
+            self._val = self.raw * self.mul
+        return self._val
+
+    @property
+    def materialised(self):
+        return self._val is not None
+
+    @property
+    def n_pos(self):
+        return self.raw.ndim - len(self.dims)
+
+    def size_of(self, dim_id):
+        return self.raw.shape[self.ids.index(dim_id)]
+
+    def detach(self):
+        return self
+
+
 class LazyNormalPT(PT):
     """The log-prob factor of a Normal whose value / loc / scale carry disjoint dims (the big [plate, K, K, K]
     tensor of a hierarchical model), not computed yet: ``.x`` produces it (alan_reduce mode NORMAL) the first time

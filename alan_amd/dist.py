@@ -15,7 +15,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, LazyNormalPT, LinearPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ScaledPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -360,7 +360,8 @@ class TorchDimDist:
             lazy = isinstance(scale, ExpPT) and not scale.materialised
             spec = (x.dims, loc.dims, scale.dims, out_dims, lazy, ab)
             sx = scale.raw if lazy else scale.x
-            nograd = not (t.is_grad_enabled() and (x.x.requires_grad or loc.x.requires_grad or sx.requires_grad))
+            lx = loc.raw if isinstance(loc, ScaledPT) and not loc.materialised else loc.x
+            nograd = not (t.is_grad_enabled() and (x.x.requires_grad or lx.requires_grad or sx.requires_grad))
             vi, li, si = set(x.ids), set(loc.ids), set(scale.ids)
             if FUSE_PLATE_STEP and ab == (1.0, 0.0) and not drop and li and si \
                     and not (vi & li) and not (vi & si) and not (li & si):
@@ -373,6 +374,9 @@ class TorchDimDist:
                 return LazyNormalPT(PT(x.x, x.dims), PT(loc.x, loc.dims), PT(sx, scale.dims), lazy, out_dims, grad=True)
             if nograd:
                 from . import engine as E           # nothing to record: skip the autograd.Function round trip
+                if isinstance(loc, ScaledPT) and not loc.materialised:      # loc = c * raw: the producer multiplies
+                    return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.raw.detach(), loc.dims), (sx.detach(), scale.dims),
+                                               out_dims, log_scale=lazy, affine=ab, loc_scale=loc.mul), out_dims)
                 return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.x.detach(), loc.dims), (sx.detach(), scale.dims),
                                            out_dims, log_scale=lazy, affine=ab), out_dims)
             return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, sx), out_dims)
@@ -443,6 +447,8 @@ class TorchDimDist:
             sc = args[2]
             if isinstance(sc, ExpPT) and not sc.materialised:        # look at the raw parameter instead
                 args = (x, args[1], PT(sc.raw, sc.dims))
+            if isinstance(args[1], ScaledPT) and not args[1].materialised:
+                args = (x, PT(args[1].raw, args[1].dims), args[2])
         elif self.dist is td.Bernoulli and set(self.kwargs) == {"logits"}:
             kind, args = "bernoulli", (x, self.kwargs["logits"])
             lg = args[1]
@@ -625,6 +631,41 @@ def _is_plain_exp(fn):
     return ok
 
 
+LAZY_SCALED = True
+"""``lambda v: c * v`` stays unevaluated where no gradient is wanted (dims.ScaledPT); a fused Normal producer folds the
+constant into its location operand."""
+
+_SCALED = {}         # id(code object) -> (code object, constant or None)
+
+
+def _scaled_form(fn):
+    """The constant c when ``fn`` is exactly ``lambda v: c * v`` / ``v * c`` with a numeric literal c, else None.
+    Decided once per code object by symbolic tracing."""
+    code = getattr(fn, "__code__", None)
+    if code is None or code.co_argcount != 1 or getattr(fn, "__closure__", None):
+        return None
+    hit = _SCALED.get(id(code))
+    if hit is not None and hit[0] is code:
+        return hit[1]
+    c = None
+    try:
+        import operator
+        import torch.fx
+        nodes = list(torch.fx.symbolic_trace(fn).graph.nodes)
+        if len(nodes) == 3 and nodes[0].op == "placeholder" and nodes[2].op == "output" and nodes[2].args == (nodes[1],):
+            n = nodes[1]
+            is_mul = (n.op == "call_function" and n.target in (operator.mul, t.mul)) or \
+                     (n.op == "call_method" and n.target == "mul")
+            if is_mul and not n.kwargs and len(n.args) == 2:
+                others = [a for a in n.args if a is not nodes[0]]
+                if len(others) == 1 and type(others[0]) in (int, float):
+                    c = float(others[0])
+    except Exception:
+        c = None
+    _SCALED[id(code)] = (code, c)
+    return c
+
+
 LINEAR_LOGITS = True
 """A model lambda that is a sum of its arguments and of dot products of them (``z @ x``,
 ``alpha + phi @ bus_company_name + psi @ run_type``) stays unevaluated where no gradient is wanted (dims.LinearPT): a
@@ -749,6 +790,13 @@ def call_model_lambda(fn, named_args, dimcache=None):
         # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
         # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
         return ExpPT(vals[0].x, vals[0].dims)
+    if LAZY_SCALED and len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_cuda and vals[0].x.dtype == t.float32 \
+            and not (t.is_grad_enabled() and vals[0].x.requires_grad):
+        c = _scaled_form(fn)
+        if c is not None:
+            # a constant multiple of one variable: lazy (dims.ScaledPT) -- a fused Normal producer takes it as the
+            # location's scale field and the multiply launch never happens; anyone else reading .x gets c * v
+            return ScaledPT(vals[0].x, c, vals[0].dims)
     if LINEAR_LOGITS and LAMBDA_BACKEND == "vmap" and len(vals) >= 2 and all(type(v) is PT for v in vals):
         form = _linear_form(fn)
         if form is not None:

@@ -355,7 +355,7 @@ def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None):
     return out
 
 
-def normal_logprob(value, loc, scale, out_dims, log_scale=False, affine=(1.0, 0.0)):
+def normal_logprob(value, loc, scale, out_dims, log_scale=False, affine=(1.0, 0.0), loc_scale=1.0):
     """log N(value; loc, scale) summed over every positional (sample/batch/event) dim -- and over any
     first-class dim missing from ``out_dims`` (a data-only plate's sum, logpq.py:149) -- as ONE launch
     (alan_reduce mode NORMAL): the [.., K, K, K, d] broadcast the reference materialises
@@ -364,7 +364,8 @@ def normal_logprob(value, loc, scale, out_dims, log_scale=False, affine=(1.0, 0.
     ``log_scale``: the third argument holds log(scale) (a learned scale's raw parameter, Param.py:18-25);
     ``affine = (a, b)``: the launch writes a * log_prob + b (the -(log Q + log K) of logpq.py:234-235)."""
     mode = N.MODE_NORMAL_LOGSCALE if log_scale else N.MODE_NORMAL
-    return _produce(mode, (value, loc, scale), out_dims, affine)
+    scales = None if loc_scale == 1.0 else [1.0, float(loc_scale), 1.0]     # (``loc_scale``: the location is c * loc)
+    return _produce(mode, (value, loc, scale), out_dims, affine, scales)
 
 
 def normal_logprob_pq(value, p, q, out_dims, affine=(1.0, 0.0)):

@@ -65,7 +65,8 @@ typedef enum {
                               3 factors (value, loc, scale), or 6 = two such terms (log P and log Q of one variable);
                               out = sum_t value_t.scale * sum_R [ -(value-loc)^2 / (2 scale^2) - log(scale) - log(sqrt(2 pi)) ],
                               R = the event/batch dims; the [..., K, K, K, d] broadcast is never materialised.
-                              A scale factor whose own .scale field is 2 holds log(scale) (see NORMAL_LOGSCALE). */
+                              A scale factor whose own .scale field is 2 holds log(scale) (see NORMAL_LOGSCALE); a loc
+                              factor's .scale field c multiplies it (loc = c * stored value: a lambda `c * prev`). */
     ALAN_MODE_BERNOULLI = 4, /* fused factor PRODUCER for td.Bernoulli(logits=...) (same reference lines):
                               exactly 2 factors (value, logits);
                               out = sum_R [ logsigmoid(logits) - (1 - value) * logits ]

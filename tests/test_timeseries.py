@@ -350,3 +350,32 @@ def test_timeseries_posterior_reference_mode_runs_end_to_end(monkeypatch):
     isamp = prob.sample(50, reparam=False).importance_sample(500)
     d = isamp.dump()["ts"]
     assert set(d.names) == {"N", "T"} and bool(t.isfinite(d.rename(None)).all())
+
+
+@pytest.mark.gpu
+def test_constant_multiple_lambda_is_folded_into_the_normal_producer(monkeypatch):
+    """``lambda prev: 0.9 * prev`` (the Kalman model's transition mean) stays lazy on gradient-free evaluations: the
+    Normal producer multiplies the location itself (factor scale field).  Same ELBO as with the lambda evaluated."""
+    from alan_amd import dist as D, engine as E
+    prob, _ = kalman_problem(50)
+    prob.to("cuda")
+    t.manual_seed(3)
+    sample = prob.sample(10, reparam=False)
+    seen = []
+    orig = E.normal_logprob
+
+    def spy(*a, **k):
+        seen.append(k.get("loc_scale", 1.0))
+        return orig(*a, **k)
+
+    monkeypatch.setattr(E, "normal_logprob", spy)
+    lazy = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert any(abs(c - 0.9) < 1e-12 for c in seen), seen
+    monkeypatch.setattr(D, "LAZY_SCALED", False)
+    seen.clear()
+    plain = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert all(c == 1.0 for c in seen)
+    assert abs(lazy - plain) <= 2e-6 * abs(plain), (lazy, plain)
+    monkeypatch.setattr(D, "LAZY_SCALED", True)
+    assert abs(float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) - lazy) <= 1e-6 * abs(lazy)
+    assert D._scaled_form(lambda v: v * v) is None and D._scaled_form(lambda v: 2 * v + 1) is None
