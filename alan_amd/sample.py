@@ -155,8 +155,9 @@ class Sample:
             from .model import empty_tree
             extra = empty_tree(self.P.plate)
         from . import native as N
-        # gradient-free evaluations may queue their small independent producer launches (native.deferring)
-        with (contextlib.nullcontext() if t.is_grad_enabled() else N.deferring()):
+        # the small independent producer launches may be queued and leave together (native.deferring); with gradients
+        # recorded that is the launches inside the producers' autograd.Function.forward (grad mode is off in there)
+        with N.deferring():
             lp, *_ = logPQ_plate(
                 name=None, P=self.P.plate, Q=self.Q.plate, sample=self._as_pt(sample),
                 inputs_params=problem.inputs_params_pt(), data=problem.data_pt(),
