@@ -272,6 +272,64 @@ OUTER_BACKWARD = True
 """Use the two-GEMM backward of the Normal producer when value / loc / scale carry disjoint dims."""
 
 
+FUSE_REPARAM = True
+"""Reparameterised Normal samples (problem.sample(K, reparam=True)) through one autograd node whose backward is two
+small library launches (the sums of G and of G * eps over the broadcast dims, alan_reduce modes SUM / DOT, issued
+together) instead of the five or six torch kernels autograd derives from exp, addcmul and the broadcasts."""
+
+
+def _sum_to(G, other, shape):
+    """sum of G (or of G * other) over the dims along which a parameter of shape ``shape`` was broadcast to G's."""
+    pad = G.ndim - len(shape)
+    keep = [i for i in range(G.ndim) if i >= pad and shape[i - pad] != 1]
+    if len(keep) == G.ndim:
+        return (G if other is None else G * other).reshape(shape)
+    if G.is_cuda and G.dtype == t.float32 and (other is None or other.dtype == t.float32):
+        from . import engine as E
+        from . import native as N
+        axes = tuple(range(G.ndim))
+        with N.may_defer():
+            if other is None:
+                out = E._produce(N.MODE_SUM, [(G, axes)], tuple(keep))
+            else:
+                out = E._produce(N.MODE_DOT, [(G, axes), (other.expand_as(G), axes)], tuple(keep))
+        return out.reshape(shape)
+    red = [i for i in range(G.ndim) if i not in keep]
+    return (G if other is None else G * other).sum(red).reshape(shape)
+
+
+class _ReparamNormal(t.autograd.Function):
+    """x = loc + eps * scale with eps ~ N(0, 1) drawn inside (TorchDimDist.py: d.rsample(), i.e. torch's
+    Normal.rsample).  ``raw`` given: scale = exp(raw), the OptParam(transformation=torch.exp) idiom, and the gradient is
+    returned with respect to raw.  backward: d loc = sum_b G, d scale = sum_b G * eps (d raw = that times scale), b = the
+    dims the parameter was broadcast along -- two reductions issued as one multi-problem launch."""
+
+    @staticmethod
+    def forward(ctx, loc, scale, raw, shape):
+        s = raw.exp() if raw is not None else scale
+        eps = t.empty(shape, dtype=loc.dtype, device=loc.device).normal_()
+        ctx.save_for_backward(eps, s)
+        ctx.shapes = (tuple(loc.shape), tuple((raw if raw is not None else scale).shape))
+        ctx.is_log = raw is not None
+        return t.addcmul(loc, eps, s)
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, G):
+        from . import native as N
+        eps, s = ctx.saved_tensors
+        G = G.contiguous()
+        gl = gs = None
+        with N.deferring():
+            if ctx.needs_input_grad[0]:
+                gl = _sum_to(G, None, ctx.shapes[0])
+            if ctx.needs_input_grad[2 if ctx.is_log else 1]:
+                gs = _sum_to(G, eps, ctx.shapes[1])
+        if gs is not None and ctx.is_log:
+            gs = gs * s                                       # d/d raw = d/d scale * exp(raw)
+        return gl, (None if ctx.is_log else gs), (gs if ctx.is_log else None), None
+
+
 class TorchDimDist:
     """A torch.distributions distribution whose parameters are torchdim tensors (or PTs)."""
 
@@ -310,8 +368,23 @@ class TorchDimDist:
                             "by PyTorch (likely because it is a distribution over discrete random variables).")
         have = set(self.all_arg_ids)
         extra = [d for d in sample_dims if id(d) not in have]
-        d = self._build(self.all_arg_ids)
         shape = t.Size([*sample_shape, *[e.size for e in extra]])
+        if reparam and FUSE_REPARAM and self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"} and t.is_grad_enabled():
+            loc, scale = self.kwargs["loc"], self.kwargs["scale"]
+            lazy = isinstance(scale, ExpPT) and not scale.materialised
+            sv = PT(scale.raw, scale.dims) if lazy else scale
+            if loc.x.is_cuda and loc.x.dtype == sv.x.dtype == t.float32 and (loc.x.requires_grad or sv.x.requires_grad):
+                # one autograd node: exp of the raw scale, the noise and the affine map inside; its backward is two
+                # small library reductions (see _ReparamNormal)
+                la = pt_align(loc, self.all_arg_ids, self.sample_batch_ndim - self.arg_batch_ndim["loc"])
+                sa = pt_align(sv, self.all_arg_ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
+                full = t.Size([*shape, *t.broadcast_shapes(la.shape, sa.shape)])
+                x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full)
+                ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)
+                if ns and nd:
+                    x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
+                return PT(x, (*extra, *self.all_arg_dims))
+        d = self._build(self.all_arg_ids)
 
         def draw():
             if self.dist is td.Normal:

@@ -549,3 +549,30 @@ def test_plain_elbo_nograd_stays_eager_when_the_evaluation_cannot_be_captured():
     assert list(sample._auto.values()) == [False]
     # (found by the synchronisation watch of the first call, not by a failed capture)
     assert all(w.startswith("synchronises") for w in sample._auto_why.values()), sample._auto_why
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown"),
+                                           ("e2e_model1.pt", "model1")])
+def test_reparameterised_sampling_through_one_autograd_node_gives_the_same_vi_gradients(fixture, model, monkeypatch):
+    """problem.sample(K, reparam=True) -> elbo_vi -> backward with dist.FUSE_REPARAM (exp, noise and affine map in one
+    node, backward = two library reductions) against plain torch autograd through exp / addcmul: same seed, so the same
+    particles; same ELBO and the same parameter gradients."""
+    from alan_amd import dist as D
+    fx = load_golden(fixture)
+
+    def run(fuse):
+        monkeypatch.setattr(D, "FUSE_REPARAM", fuse)
+        prob = models.BUILDERS[model](fx).to("cuda").float()
+        t.manual_seed(11)
+        sample = prob.sample(int(fx["K"]), reparam=True)
+        elbo = sample.elbo_vi(alan.no_checkpoint)
+        elbo.backward()
+        return float(elbo), {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None}
+
+    (e1, g1), (e0, g0) = run(True), run(False)
+    assert abs(e1 - e0) <= 1e-6 * abs(e0), (e1, e0)
+    assert g1.keys() == g0.keys() and len(g0) >= 2
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
