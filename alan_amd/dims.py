@@ -179,6 +179,20 @@ class ExpPT(PT):
         return ExpPT(self.raw.detach(), self.dims)
 
 
+class ReparamPT(PT):
+    """A reparameterised Normal sample x = loc + eps * scale, with a key of the parameter tensors that made it (address,
+    layout, version: dist._tkey).  A log-prob of x under that very distribution then knows log q(x) = -eps^2 / 2 -
+    log scale - const: its total gradient reaches the scale only (dist._OwnSampleLogProb)."""
+    __slots__ = ("src",)
+
+    def __init__(self, x, dims, src):
+        PT.__init__(self, x, dims)
+        self.src = src
+
+    def detach(self):
+        return PT(self.x.detach(), self.dims)
+
+
 class ScaledPT(PT):
     """The value of a model lambda ``c * v`` (a timeseries transition's ``lambda prev: 0.9 * prev``), not evaluated:
     ``.x`` multiplies on first use, a fused Normal producer takes ``raw`` and the constant instead (the loc factor's

@@ -15,7 +15,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ScaledPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ReparamPT, ScaledPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -330,6 +330,45 @@ class _ReparamNormal(t.autograd.Function):
         return gl, (None if ctx.is_log else gs), (gs if ctx.is_log else None), None
 
 
+def _tkey(x):
+    """Identity of a tensor's contents for as long as nobody writes to it: address, layout, version counter."""
+    return (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version)
+
+
+class _OwnSampleLogProb(t.autograd.Function):
+    """log N(x; loc, scale) (times a, plus b) for x = loc + eps * scale drawn from THIS distribution (_ReparamNormal):
+    as a function of the parameters it is -eps^2 / 2 - log scale - const, so its total derivative is -1 with respect to
+    log scale and nothing with respect to loc -- what autograd finds by sending -eps / scale back through x and adding
+    the explicit partials (TorchDimDist.py:127-162 under elbo_vi), three producer-gradient launches and as many
+    accumulations per variable.  forward: the ordinary producer launch; backward: one small sum of G."""
+
+    @staticmethod
+    def forward(ctx, spec, value, loc, scale):
+        from . import engine as E
+        vd, ld, sd, od, log_scale, affine = spec
+        out = E.normal_logprob((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd), od,
+                               log_scale=log_scale, affine=affine)
+        ctx.spec = spec
+        ctx.save_for_backward(scale)
+        return out
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, G):
+        from . import engine as E
+        from . import native as N
+        vd, ld, sd, od, log_scale, affine = ctx.spec
+        (scale,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[3]:
+            return None, None, None, None
+        g = E._produce(N.MODE_SUM, [(G.contiguous(), tuple(id(d) for d in od))], tuple(id(d) for d in sd))
+        g = g.reshape(tuple(g.shape) + (1,) * (scale.ndim - len(sd))).expand(scale.shape)      # every event element alike
+        a = float(affine[0])
+        if log_scale:
+            return None, None, None, (g if a == -1.0 else g * (-a))
+        return None, None, None, g * (-a) / scale
+
+
 class TorchDimDist:
     """A torch.distributions distribution whose parameters are torchdim tensors (or PTs)."""
 
@@ -383,7 +422,9 @@ class TorchDimDist:
                 ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)
                 if ns and nd:
                     x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
-                return PT(x, (*extra, *self.all_arg_dims))
+                # (the tensors themselves are kept: while the sample lives nothing else can take their addresses)
+                src = (_tkey(loc.x), loc.ids, _tkey(sv.x), sv.ids, lazy, loc.x, sv.x)
+                return ReparamPT(x, (*extra, *self.all_arg_dims), src)
         d = self._build(self.all_arg_ids)
 
         def draw():
@@ -452,6 +493,11 @@ class TorchDimDist:
                                                out_dims, log_scale=lazy, affine=ab, loc_scale=loc.mul), out_dims)
                 return PT(E.normal_logprob((x.x.detach(), x.dims), (loc.x.detach(), loc.dims), (sx.detach(), scale.dims),
                                            out_dims, log_scale=lazy, affine=ab), out_dims)
+            if FUSE_REPARAM and isinstance(x, ReparamPT) and not drop \
+                    and x.src[:5] == (_tkey(loc.x), loc.ids, _tkey(sx), scale.ids, lazy):
+                # x is this distribution's own reparameterised sample: the log-prob's total gradient reaches the
+                # (log) scale only
+                return PT(_OwnSampleLogProb.apply(spec, x.x, loc.x, sx), out_dims)
             return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, sx), out_dims)
         if kind == "bernoulli":
             logits = self.kwargs["logits"]
@@ -659,7 +705,8 @@ class Dist(nn.Module):
         p = self.tdd(scope, dimcache).sample_pt(reparam, want, self.sample_shape)
         ids = tuple(id(d) for d in want)
         if p.ids != ids:
-            p = PT(pt_align(p, ids).contiguous(), want)
+            x = pt_align(p, ids).contiguous()
+            p = ReparamPT(x, want, p.src) if isinstance(p, ReparamPT) else PT(x, want)
         return p
 
     def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=(), affine=None):
