@@ -305,13 +305,17 @@ class _ReparamNormal(t.autograd.Function):
     dims the parameter was broadcast along -- two reductions issued as one multi-problem launch."""
 
     @staticmethod
-    def forward(ctx, loc, scale, raw, shape):
+    def forward(ctx, loc, scale, raw, shape, perm=None):
+        """``perm``: the noise is drawn with shape ``shape`` (the order torch's rsample would use, so the particles are
+        the same ones) and read through ``.permute(perm)``: the sample is written contiguously in that order."""
         s = raw.exp() if raw is not None else scale
         eps = t.empty(shape, dtype=loc.dtype, device=loc.device).normal_()
+        if perm is not None:
+            eps = eps.permute(perm)
         ctx.save_for_backward(eps, s)
         ctx.shapes = (tuple(loc.shape), tuple((raw if raw is not None else scale).shape))
         ctx.is_log = raw is not None
-        return t.addcmul(loc, eps, s)
+        return t.addcmul(loc, eps, s, out=t.empty(eps.shape, dtype=loc.dtype, device=loc.device))
 
     @staticmethod
     @t.autograd.function.once_differentiable
@@ -327,7 +331,7 @@ class _ReparamNormal(t.autograd.Function):
                 gs = _sum_to(G, eps, ctx.shapes[1])
         if gs is not None and ctx.is_log:
             gs = gs * s                                       # d/d raw = d/d scale * exp(raw)
-        return gl, (None if ctx.is_log else gs), (gs if ctx.is_log else None), None
+        return gl, (None if ctx.is_log else gs), (gs if ctx.is_log else None), None, None
 
 
 def _tkey(x):
@@ -415,15 +419,28 @@ class TorchDimDist:
             if loc.x.is_cuda and loc.x.dtype == sv.x.dtype == t.float32 and (loc.x.requires_grad or sv.x.requires_grad):
                 # one autograd node: exp of the raw scale, the noise and the affine map inside; its backward is two
                 # small library reductions (see _ReparamNormal)
-                la = pt_align(loc, self.all_arg_ids, self.sample_batch_ndim - self.arg_batch_ndim["loc"])
-                sa = pt_align(sv, self.all_arg_ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
+                # (the tensors themselves are kept: while the sample lives nothing else can take their addresses)
+                src = (_tkey(loc.x), loc.ids, _tkey(sv.x), sv.ids, lazy, loc.x, sv.x)
+                pl = self.sample_batch_ndim - self.arg_batch_ndim["loc"]
+                ps = self.sample_batch_ndim - self.arg_batch_ndim["scale"]
+                if not sample_shape:
+                    # drawn directly in the caller's dim order (plates outermost, K innermost): no re-layout copy after
+                    la, sa = pt_align(loc, ids, pl), pt_align(sv, ids, ps)
+                    n = len(ids)
+                    rest = t.broadcast_shapes(la.shape[n:], sa.shape[n:])
+                    drawn = [*extra, *self.all_arg_dims]                       # the order rsample draws in
+                    full = t.Size([*[d.size for d in drawn], *rest])
+                    pos = {id(d): k for k, d in enumerate(drawn)}
+                    perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
+                    x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full,
+                                             None if perm == list(range(len(perm))) else perm)
+                    return ReparamPT(x, sample_dims, src)
+                la, sa = pt_align(loc, self.all_arg_ids, pl), pt_align(sv, self.all_arg_ids, ps)
                 full = t.Size([*shape, *t.broadcast_shapes(la.shape, sa.shape)])
                 x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full)
                 ns, nd = len(sample_shape), len(extra) + len(self.all_arg_dims)
                 if ns and nd:
                     x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
-                # (the tensors themselves are kept: while the sample lives nothing else can take their addresses)
-                src = (_tkey(loc.x), loc.ids, _tkey(sv.x), sv.ids, lazy, loc.x, sv.x)
                 return ReparamPT(x, (*extra, *self.all_arg_dims), src)
         d = self._build(self.all_arg_ids)
 
