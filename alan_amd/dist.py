@@ -442,6 +442,22 @@ class TorchDimDist:
                 if ns and nd:
                     x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
                 return ReparamPT(x, (*extra, *self.all_arg_dims), src)
+        if self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"} and not sample_shape \
+                and not (reparam and t.is_grad_enabled()):
+            # gradient-free Normal draw, written directly in the caller's dim order (plates outermost, K innermost) from
+            # noise drawn in rsample's order -- the same particles, no re-layout copy afterwards
+            loc, scale = self.kwargs["loc"], self.kwargs["scale"]
+            with t.no_grad():
+                la = pt_align(loc, ids, self.sample_batch_ndim - self.arg_batch_ndim["loc"])
+                sa = pt_align(scale, ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
+                n = len(ids)
+                rest = t.broadcast_shapes(la.shape[n:], sa.shape[n:])
+                drawn = [*extra, *self.all_arg_dims]
+                pos = {id(d_): k for k, d_ in enumerate(drawn)}
+                perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
+                eps = t.empty([*[d_.size for d_ in drawn], *rest], dtype=la.dtype, device=la.device).normal_().permute(perm)
+                x = t.addcmul(la, eps, sa, out=t.empty(eps.shape, dtype=la.dtype, device=la.device))
+            return PT(x, sample_dims)
         d = self._build(self.all_arg_ids)
 
         def draw():
