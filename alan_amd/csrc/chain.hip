@@ -29,18 +29,38 @@ struct alignas(4 * sizeof(T)) Vec4 {
 // Further terms of the chain's input: the factors of a timeseries plate are ADDED into one [T, K, K] tensor before the
 // chain (reduce_Ks with no K to sum, logpq.py:128) -- here the first round adds them on load instead (strides may be
 // 0: a factor without the K_init dim).  n = 0 on every later round.
+// One of the terms may be the TRANSITION log-prob itself, computed on load instead of read (norm != 0): log N(value;
+// lmul * loc, scale) with value / loc / scale each a [B, T, K_init, K] view (stride 0 where it lacks a dim) -- for a
+// timeseries `ts ~ Normal(lambda prev: c * prev, sigma)` (Timeseries.py:205-245 + TorchDimDist.py:127-162) the
+// [T, K_init, K] factor is then never written: value = x[t, k], loc = prev[t, k_init].  norm = 2: `scale` holds log(scale).
 template <typename T>
 struct ChainAdd {
     const T *p[2];
     int64_t sB[2], sT[2], sR[2], sC[2];
     int32_t n;
+    int32_t norm;
+    const T *nv, *nl, *ns;
+    int64_t nvs[4], nls[4], nss[4];         // (sB, sT, sRow, sCol) of value / loc / scale
+    T lmul;
 };
+
+template <typename T>
+__device__ __forceinline__ T chain_normal_term(const ChainAdd<T> &ad, int64_t b, int64_t t, int i, int j) {
+    const T v = ad.nv[b * ad.nvs[0] + t * ad.nvs[1] + i * ad.nvs[2] + j * ad.nvs[3]];
+    const T l = ad.nl[b * ad.nls[0] + t * ad.nls[1] + i * ad.nls[2] + j * ad.nls[3]];
+    const T sc = ad.ns[b * ad.nss[0] + t * ad.nss[1] + i * ad.nss[2] + j * ad.nss[3]];
+    const T z = v - ad.lmul * l;
+    // torch.distributions.Normal.log_prob, as the producer kernels evaluate it (reduce.hip accumulate<NORMAL>)
+    return ad.norm == 2 ? -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178)
+                        : -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
+}
 
 template <typename T>
 __device__ __forceinline__ T chain_in(const T *ms, int64_t off, const ChainAdd<T> &ad, int64_t b, int64_t t, int i, int j) {
     T v = ms[off];
     if (ad.n > 0) v += ad.p[0][b * ad.sB[0] + t * ad.sT[0] + i * ad.sR[0] + j * ad.sC[0]];
     if (ad.n > 1) v += ad.p[1][b * ad.sB[1] + t * ad.sT[1] + i * ad.sR[1] + j * ad.sC[1]];
+    if (ad.norm) v += chain_normal_term(ad, b, t, i, j);
     return v;
 }
 
@@ -515,7 +535,7 @@ struct WaveOuts {
     int n[WAVE_ROUNDS];
 };
 
-template <int NADD>         // further terms added to the input on load (ChainAdd), 0..2
+template <int NADD, bool NORM = false>   // further terms added to the input on load (ChainAdd): 0..2 tensors, the Normal term
 __global__ __launch_bounds__(1024) void chain_wave_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
                                                           int64_t sCol, int n_in, int K, int rounds, const WaveOuts outs,
                                                           float *vec_out, const ChainAdd<float> ad) {
@@ -555,6 +575,23 @@ __global__ __launch_bounds__(1024) void chain_wave_kernel(const float *ms, int64
                     const float *p2 = NADD > 1 ? ad.p[1] + b * ad.sB[1] + tn * ad.sT[1] : p0;
                     const int r0 = (int)sRow, c0 = (int)sCol, r1 = (int)ad.sR[0], c1 = (int)ad.sC[0], r2 = (int)ad.sR[1],
                               c2 = (int)ad.sC[1];
+                    // the Normal term's operands, likewise: uniform bases, 32-bit offsets
+                    const float *qv = NORM ? ad.nv + b * ad.nvs[0] + tn * ad.nvs[1] : p0;
+                    const float *ql = NORM ? ad.nl + b * ad.nls[0] + tn * ad.nls[1] : p0;
+                    const float *qs = NORM ? ad.ns + b * ad.nss[0] + tn * ad.nss[1] : p0;
+                    // (host-checked: the value varies along the columns only, the location along the rows only -- a
+                    // transition's x[t, k] and prev[t, k_init] -- so one of the two is fixed per lane)
+                    const int vc = (int)ad.nvs[3], lr = (int)ad.nls[2];
+                    const int jc = j < K ? j : 0;
+                    const float fixed = !NORM ? 0.f : rowwise ? ad.lmul * ql[jc * lr] : qv[jc * vc];
+                    // (the scale does not vary inside a matrix -- the host checked: the usual scalar -- so its weight
+                    // 1 / (2 scale^2) and log-normaliser are taken once per node)
+                    float w_uni = 0.f, lg_uni = 0.f;
+                    if (NORM) {
+                        const float sc = qs[0];
+                        w_uni = ad.norm == 2 ? 0.5f * expf(-2.f * sc) : 0.5f / (sc * sc);
+                        lg_uni = (ad.norm == 2 ? sc : logf(sc)) + 0.91893853320467274178f;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int k = KROW(r);
@@ -564,6 +601,18 @@ __global__ __launch_bounds__(1024) void chain_wave_kernel(const float *ms, int64
                         if (NADD > 0) v += p1[ii * r1 + jj * c1];
                         if (NADD > 1) v += p2[ii * r2 + jj * c2];
                         dstv[r] = ok ? v : NINF;
+                    }
+                    if (NORM) {
+                        // a pass of its own (pads stay -inf: -inf + finite), its loads kept apart from the ones above:
+                        // sixteen elements of four tensors in flight at once do not fit the 128 registers of a 16-wave group
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int k = KROW(r);
+                            const int kc = k < K ? k : 0;
+                            const float z = rowwise ? qv[kc * vc] - fixed : fixed - ad.lmul * ql[kc * lr];     // value - loc
+                            dstv[r] += -(z * z) * w_uni - lg_uni;
+                        }
                     }
                 };
                 const int64_t ta = (int64_t)seg * W + 2 * w;
@@ -672,11 +721,20 @@ static TreeLayout tree_layout(int64_t B, int64_t T, int64_t K, size_t elt) {
 template <typename T>
 static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
                      int64_t sCol, void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream,
-                     const void *const *more = nullptr, const int64_t *more_strides = nullptr, int n_more = 0) {
+                     const void *const *more = nullptr, const int64_t *more_strides = nullptr, int n_more = 0,
+                     const alan_chain_normal_t *normal = nullptr) {
     ChainAdd<T> ad0, none;
     std::memset(&ad0, 0, sizeof(ad0));
     std::memset(&none, 0, sizeof(none));
     if (n_more < 0 || n_more > 2) return ALAN_ERR_UNSUPPORTED;
+    if (normal) {
+        if (!normal->value || !normal->loc || !normal->scale) return ALAN_ERR_BAD_DESC;
+        ad0.norm = normal->log_scale ? 2 : 1;
+        ad0.nv = (const T *)normal->value, ad0.nl = (const T *)normal->loc, ad0.ns = (const T *)normal->scale;
+        for (int q = 0; q < 4; ++q)
+            ad0.nvs[q] = normal->v_stride[q], ad0.nls[q] = normal->l_stride[q], ad0.nss[q] = normal->s_stride[q];
+        ad0.lmul = (T)normal->loc_mul;
+    }
     for (int q = 0; q < n_more; ++q) {
         if (!more || !more[q] || !more_strides) return ALAN_ERR_BAD_DESC;
         ad0.p[q] = (const T *)more[q];
@@ -703,11 +761,18 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         auto span = [&](int64_t r, int64_t c) { return ((r < 0 ? -r : r) + (c < 0 ? -c : c)) * (K - 1) < (1ll << 31) - 1; };
         fits32 = span(sRow, sCol);
         for (int q = 0; q < n_more; ++q) fits32 = fits32 && span(ad0.sR[q], ad0.sC[q]);
+        // (the wave kernel takes the Normal term's scale once per matrix: it must not vary inside one)
+        // and its value along the columns only, its location along the rows only (one of them is then fixed per lane)
+        if (normal)
+            fits32 = fits32 && span(0, ad0.nvs[3]) && span(ad0.nls[2], 0) && ad0.nss[2] == 0 && ad0.nss[3] == 0 &&
+                     ad0.nvs[2] == 0 && ad0.nls[3] == 0;
     }
     // (below K ~ 12 the vector-unit tree kernel is as fast or faster: a 32 x 32 MFMA tile is mostly padding there)
     if (K > 12 && K <= 32 && !per_round && !no_wave && fits32 && std::is_same<T, float>::value) {
         const size_t wsmem = (size_t)(25 * WAVE_TILE + 16 * 32) * sizeof(float);     // the largest launch (5 rounds)
-        for (auto fn : {(const void *)chain_wave_kernel<0>, (const void *)chain_wave_kernel<1>, (const void *)chain_wave_kernel<2>})
+        for (auto fn : {(const void *)chain_wave_kernel<0>, (const void *)chain_wave_kernel<1>, (const void *)chain_wave_kernel<2>,
+                        (const void *)chain_wave_kernel<0, true>, (const void *)chain_wave_kernel<1, true>,
+                        (const void *)chain_wave_kernel<2, true>})
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsmem) != hipSuccess)
                 return ALAN_ERR_LAUNCH;
         ChainAdd<float> adf, nonef;
@@ -736,6 +801,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             const bool last = r + rounds == tl.L;
             const int nadd = r == 0 ? n_more : 0;
             auto wk = nadd == 0 ? chain_wave_kernel<0> : nadd == 1 ? chain_wave_kernel<1> : chain_wave_kernel<2>;
+            if (r == 0 && normal)
+                wk = nadd == 0 ? chain_wave_kernel<0, true> : nadd == 1 ? chain_wave_kernel<1, true> : chain_wave_kernel<2, true>;
             hipLaunchKernelGGL(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
                                (const float *)src, cB, cT, cR, cC, (int)tl.n[r], (int)K, rounds, wo,
                                last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef);
@@ -959,20 +1026,28 @@ extern "C" int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_
     return ALAN_ERR_BAD_DESC;
 }
 
-extern "C" int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
-                                         int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
-                                         void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                                const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T,
+                                                int64_t K, void *out_chain, void *out_vec, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
     if (!terms || !strides || n_terms < 1 || n_terms > 3 || !terms[0] || B < 1 || T < 1 || K < 1 ||
         (!out_chain && !out_vec))
         return ALAN_ERR_BAD_DESC;
     if (T >= (1ll << 31) || B > 65535) return ALAN_ERR_UNSUPPORTED;
     if (dtype == ALAN_F32)
         return chain_run<float>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
-                                workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1);
+                                workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1, normal);
     if (dtype == ALAN_F64)
         return chain_run<double>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
-                                 workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1);
+                                 workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1, normal);
     return ALAN_ERR_BAD_DESC;
+}
+
+extern "C" int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
+                                         int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
+                                         void *workspace, size_t workspace_bytes, void *stream) {
+    return alan_chain_logmmexp_terms_normal(terms, strides, n_terms, nullptr, dtype, B, T, K, out_chain, out_vec, workspace,
+                                            workspace_bytes, stream);
 }
 
 extern "C" int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,

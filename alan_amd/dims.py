@@ -231,12 +231,15 @@ class LazyNormalPT(PT):
     tensor of a hierarchical model), not computed yet: ``.x`` produces it (alan_reduce mode NORMAL) the first time
     anyone asks, but the plate recursion can hand the ingredients to the fused plate-step kernel instead
     (engine.normal_lse) and never materialise it."""
-    __slots__ = ("value", "loc", "scale", "log_scale", "grad", "_val")
+    __slots__ = ("value", "loc", "scale", "log_scale", "grad", "loc_mul", "_val")
 
-    def __init__(self, value, loc, scale, log_scale, dims, grad=False):
+    def __init__(self, value, loc, scale, log_scale, dims, grad=False, loc_mul=1.0):
         """``scale`` holds log(scale) when ``log_scale``.  ``grad``: the arguments are attached to the autograd graph
-        (elbo_vi / elbo_rws): materialising then goes through the producer's autograd function."""
+        (elbo_vi / elbo_rws): materialising then goes through the producer's autograd function.  ``loc_mul``: the
+        location is loc_mul * loc (a timeseries transition ``lambda prev: c * prev``; that factor's dims are NOT disjoint
+        -- value and loc share the time dim -- and its consumer is the chain's first round, logpq._chain_of_terms)."""
         self.value, self.loc, self.scale, self.log_scale, self.grad = value, loc, scale, log_scale, grad
+        self.loc_mul = float(loc_mul)
         self._val = None
         self.dims = tuple(dims)
         self.ids = tuple(id(d) for d in self.dims)
@@ -251,7 +254,8 @@ class LazyNormalPT(PT):
             else:
                 from . import engine as E
                 self._val = E.normal_logprob((self.value.x, self.value.dims), (self.loc.x, self.loc.dims),
-                                             (self.scale.x, self.scale.dims), self.dims, log_scale=self.log_scale)
+                                             (self.scale.x, self.scale.dims), self.dims, log_scale=self.log_scale,
+                                             loc_scale=self.loc_mul)
         return self._val
 
     @property

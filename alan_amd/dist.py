@@ -482,7 +482,7 @@ class TorchDimDist:
             x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
         return PT(x, (*extra, *self.all_arg_dims))
 
-    def log_prob_pt(self, x, dim_order=None, sum_dims=(), affine=None):
+    def log_prob_pt(self, x, dim_order=None, sum_dims=(), affine=None, unevaluated_ok=False):
         """log p(x) as a PT over (x's dims) U (parameter dims); positional sample/batch dims are summed
         out (utils.py:147-152).  ``dim_order = (lead, last)`` fixes the storage order of the result:
         ``lead`` dims outermost, ``last`` dims innermost, any others in between.  ``sum_dims``: first-class
@@ -519,6 +519,13 @@ class TorchDimDist:
                     return LazyNormalPT(PT(x.x.detach(), x.dims), PT(loc.x.detach(), loc.dims),
                                         PT(sx.detach(), scale.dims), lazy, out_dims)
                 return LazyNormalPT(PT(x.x, x.dims), PT(loc.x, loc.dims), PT(sx, scale.dims), lazy, out_dims, grad=True)
+            if nograd and unevaluated_ok and LAZY_TRANSITION and ab == (1.0, 0.0) and not drop \
+                    and x.x.dtype == lx.dtype == sx.dtype == t.float32:
+                # asked for by the caller (a timeseries transition, whose consumer is the chain's first round,
+                # logpq._chain_of_terms): unevaluated; anyone else reading .x gets it made
+                mul = loc.mul if isinstance(loc, ScaledPT) and not loc.materialised else 1.0
+                return LazyNormalPT(PT(x.x.detach(), x.dims), PT(lx.detach(), loc.dims), PT(sx.detach(), scale.dims),
+                                    lazy, out_dims, loc_mul=mul)
             if nograd:
                 from . import engine as E           # nothing to record: skip the autograd.Function round trip
                 if isinstance(loc, ScaledPT) and not loc.materialised:      # loc = c * raw: the producer multiplies
@@ -742,9 +749,11 @@ class Dist(nn.Module):
             p = ReparamPT(x, want, p.src) if isinstance(p, ReparamPT) else PT(x, want)
         return p
 
-    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=(), affine=None):
+    def log_prob(self, x, scope, T_dim=None, K_dim=None, dim_order=None, dimcache=None, sum_dims=(), affine=None,
+                 unevaluated_ok=False):
         """-> (PT, None)   [the None mirrors Timeseries.log_prob's K_init slot]"""
-        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order, sum_dims=sum_dims, affine=affine), None
+        return self.tdd(scope, dimcache).log_prob_pt(x, dim_order=dim_order, sum_dims=sum_dims, affine=affine,
+                                                     unevaluated_ok=unevaluated_ok), None
 
 
 LAMBDA_BACKEND = "vmap"
@@ -783,6 +792,10 @@ def _is_plain_exp(fn):
     _PLAIN_EXP[id(code)] = (code, ok)
     return ok
 
+
+LAZY_TRANSITION = True
+"""The Normal transition factor of a timeseries stays unevaluated on gradient-free evaluations (dims.LazyNormalPT): the
+chain's first round computes it on load (alan_chain_logmmexp_terms_normal), the [T, K_init, K] tensor is never written."""
 
 LAZY_SCALED = True
 """``lambda v: c * v`` stays unevaluated where no gradient is wanted (dims.ScaledPT); a fused Normal producer folds the

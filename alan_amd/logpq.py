@@ -88,7 +88,7 @@ def _fused_plate_step(lps, Ks, plate):
     if len(lazy) != 1 or len(plate) != 1 or len(Ks) != 1:
         return None
     z, pl, K = lazy[0], plate[0], Ks[0]
-    if set(z.value.ids) != {id(pl), id(K)} or len(z.loc.dims) != 1 or len(z.scale.dims) != 1:
+    if set(z.value.ids) != {id(pl), id(K)} or len(z.loc.dims) != 1 or len(z.scale.dims) != 1 or z.loc_mul != 1.0:
         return None
     smalls = []
     for lp in lps:
@@ -108,9 +108,25 @@ def _chain_of_terms(lps, Ks, core):
     3.6 MB tensor written and read back at T=1000, K=30).  Gradient-free, <= 3 factors, at most one batch dim."""
     if Ks or t.is_grad_enabled() or not 1 <= len(lps) <= 3 or N._TIMER[0] is not None:
         return None
-    if any(lp.n_pos for lp in lps) or any(isinstance(lp, LazyNormalPT) for lp in lps):
+    # at most one factor may be an unevaluated Normal with scalar events (the transition, timeseries.py): the chain's
+    # first round computes it on load (alan_chain_logmmexp_terms_normal) and the [T, K_init, K] tensor is never written
+    lazy = [lp for lp in lps if isinstance(lp, LazyNormalPT) and not lp.materialised]
+    if len(lazy) > 1 or (lazy and (len(lps) < 2 or lazy[0].grad or
+                                   any(p.n_pos for p in (lazy[0].value, lazy[0].loc, lazy[0].scale)))):
+        lazy = []                                         # (reading .x below evaluates them the usual way)
+    # (only where the chain takes one round per launch, K > 32: the multi-round kernels for smaller K hold a wave's two
+    # operands in registers and have none to spare for a third and fourth tensor's loads -- measured slower)
+    if lazy and core[1].size <= 32:
+        with N.may_defer():
+            lazy[0].x                                     # (evaluated here: the launch may queue -- the chain call flushes)
+        lazy = []
+    trans = lazy[0] if lazy else None
+    lps = [lp for lp in lps if lp is not trans]
+    if any(lp.n_pos for lp in lps):
         return None
     xs = [lp.x for lp in lps]
+    if trans is not None and not all(p.x.is_cuda and p.x.dtype == xs[0].dtype for p in (trans.value, trans.loc, trans.scale)):
+        lps, xs, trans = [*lps, trans], [*xs, trans.x], None
     if not all(x.is_cuda and x.dtype == xs[0].dtype for x in xs) or xs[0].dtype not in (t.float32, t.float64):
         return None
     K = core[1].size
@@ -119,19 +135,26 @@ def _chain_of_terms(lps, Ks, core):
         return None
     core_ids = [id(d) for d in core]
     batch = []
-    for lp in lps:
+    every = [*lps, *([trans] if trans is not None else [])]
+    for lp in every:
         for d in lp.dims:
             if id(d) not in core_ids and all(d is not b for b in batch):
                 batch.append(d)
-    if len(batch) > 1 or not all(any(lp.has(c) for lp in lps) for c in core):
+    if len(batch) > 1 or not all(any(lp.has(c) for lp in every) for c in core):
+        if trans is not None:
+            trans.x                                       # (evaluated: the caller contracts the usual way)
         return None
     ids = [id(d) for d in (*batch, *core)]
     shape = [d.size for d in (*batch, *core)]
-    terms = []
-    for lp in lps:
+
+    def view(lp):
         x = pt_align(lp, ids).expand(shape)                     # stride 0 where the factor lacks a dim
-        terms.append(x if batch else x.unsqueeze(0))
-    vec = N.chain_logmmexp_terms(terms)
+        return x if batch else x.unsqueeze(0)
+
+    normal = None
+    if trans is not None:
+        normal = (view(trans.value), view(trans.loc), view(trans.scale), trans.loc_mul, trans.log_scale)
+    vec = N.chain_logmmexp_terms([view(lp) for lp in lps], normal)
     return PT(vec if batch else vec[0], (*batch, core[1]))
 
 

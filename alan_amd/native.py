@@ -66,6 +66,12 @@ class ReduceDesc(C.Structure):
     ]
 
 
+class ChainNormal(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("loc", C.c_void_p), ("scale", C.c_void_p),
+                ("v_stride", C.c_int64 * 4), ("l_stride", C.c_int64 * 4), ("s_stride", C.c_int64 * 4),
+                ("loc_mul", C.c_double), ("log_scale", C.c_int32)]
+
+
 class BackwardDesc(C.Structure):
     _fields_ = [("fwd", ReduceDesc), ("grad", Tensor * MAX_FACTORS)]
 
@@ -141,6 +147,10 @@ def lib():
         L.alan_chain_logmmexp_terms.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
                                                 C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
+        L.alan_chain_logmmexp_terms_normal.restype = C.c_int
+        L.alan_chain_logmmexp_terms_normal.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                                                       C.POINTER(ChainNormal), C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_chain_backward_batched_workspace_bytes.restype = C.c_size_t
         L.alan_chain_backward_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp_backward_batched.restype = C.c_int
@@ -165,6 +175,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
+           "alan_chain_logmmexp_terms_normal",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
            "alan_abi_version", "alan_build_target")
@@ -409,9 +420,11 @@ def chain_logmmexp(ms, want_chain=False):
     return vec, chain, tree
 
 
-def chain_logmmexp_terms(terms):
+def chain_logmmexp_terms(terms, normal=None):
     """logsumexp(chain_logmmexp(sum of terms), -1) with the sum taken on load: ``terms`` = up to 3 device tensors
-    [B,T,K,K] (expanded / stride-0 views welcome).  -> vec [B,K]."""
+    [B,T,K,K] (expanded / stride-0 views welcome).  ``normal`` = (value, loc, scale, loc_mul, log_scale), three more
+    such views: one further term log N(value; loc_mul * loc, scale) computed on load (the transition factor of a
+    timeseries, never written).  -> vec [B,K]."""
     L = lib()
     flush()
     assert 1 <= len(terms) <= 3
@@ -428,9 +441,18 @@ def chain_logmmexp_terms(terms):
     tree = t.empty(max(nbytes, 1), dtype=t.uint8, device=device)
     ptrs = (C.c_void_p * len(terms))(*[x.data_ptr() for x in terms])
     strides = (C.c_int64 * (4 * len(terms)))(*[s for x in terms for s in x.stride()])
-    rc = L.alan_chain_logmmexp_terms(ptrs, strides, len(terms), code, B, T, K, None, vec.data_ptr(), tree.data_ptr(),
-                                     nbytes, current_stream(device))
-    check(rc, "alan_chain_logmmexp_terms")
+    nd = None
+    if normal is not None:
+        v, l, sc, mul, log_scale = normal
+        assert all(x.shape == terms[0].shape and x.dtype == terms[0].dtype for x in (v, l, sc))
+        nd = ChainNormal()
+        nd.value, nd.loc, nd.scale = v.data_ptr(), l.data_ptr(), sc.data_ptr()
+        for q in range(4):
+            nd.v_stride[q], nd.l_stride[q], nd.s_stride[q] = v.stride(q), l.stride(q), sc.stride(q)
+        nd.loc_mul, nd.log_scale = float(mul), int(bool(log_scale))
+    rc = L.alan_chain_logmmexp_terms_normal(ptrs, strides, len(terms), C.byref(nd) if nd is not None else None, code,
+                                            B, T, K, None, vec.data_ptr(), tree.data_ptr(), nbytes, current_stream(device))
+    check(rc, "alan_chain_logmmexp_terms_normal")
     return vec
 
 

@@ -94,6 +94,7 @@ class Timeseries(nn.Module):
         if dim_order is not None:
             lead, last = dim_order
             order = ([d for d in lead if d not in {Kinit, K_dim}], [Kinit, K_dim])
-        lp, _ = self.trans.log_prob(PT.of(sample), scope, dim_order=order, dimcache=dimcache)
+        # (the factor may come back unevaluated: the chain's first round then computes it on load)
+        lp, _ = self.trans.log_prob(PT.of(sample), scope, dim_order=order, dimcache=dimcache, unevaluated_ok=True)
         assert lp.has(Kinit) and lp.has(K_dim) and lp.has(T_dim)
         return lp, Kinit

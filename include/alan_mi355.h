@@ -263,6 +263,20 @@ int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_
 int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
                               int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* The same with one MORE term that is computed on load instead of read: the transition log-prob of a timeseries
+ * `ts ~ Normal(c * prev, scale)` (Timeseries.py:205-245 evaluating TorchDimDist.py:127-162 on the [T, K_init, K] cross
+ * product): log N(value; loc_mul * loc, scale), each operand a [B, T, K_init, K] view given by four element strides
+ * (0 where it lacks a dim: value = x[t, k] has no K_init stride, loc = prev[t, k_init] no K stride).  That factor --
+ * 40 MB at T=1000, K=100 -- is then never written.  normal == NULL: alan_chain_logmmexp_terms. */
+typedef struct {
+    const void *value, *loc, *scale;      /* dtype as the terms */
+    int64_t v_stride[4], l_stride[4], s_stride[4];     /* (sB, sT, sRow, sCol) */
+    double loc_mul;
+    int32_t log_scale;                    /* `scale` holds log(scale) */
+} alan_chain_normal_t;
+int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                     const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T, int64_t K,
+                                     void *out_chain, void *out_vec, void *workspace, size_t workspace_bytes, void *stream);
 size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                          int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,

@@ -379,3 +379,38 @@ def test_constant_multiple_lambda_is_folded_into_the_normal_producer(monkeypatch
     monkeypatch.setattr(D, "LAZY_SCALED", True)
     assert abs(float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) - lazy) <= 1e-6 * abs(lazy)
     assert D._scaled_form(lambda v: v * v) is None and D._scaled_form(lambda v: 2 * v + 1) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [10, 40])
+def test_transition_factor_computed_on_load_by_the_chain_equals_the_materialised_one(K, monkeypatch):
+    """Above K = 32 the Normal transition factor of a timeseries stays unevaluated and the chain's first round computes
+    it on load (alan_chain_logmmexp_terms_normal): same ELBO as with the [T, K_init, K] factor written by the producer,
+    and as the CPU oracle on the same particles."""
+    from alan_amd import dist as D, native as N
+    from oracle import backend
+    prob, _ = kalman_problem(64)
+    prob.to("cuda")
+    t.manual_seed(4)
+    sample = prob.sample(K, reparam=False)
+    used = []
+    orig = N.chain_logmmexp_terms
+
+    def spy(terms, normal=None):
+        used.append(normal is not None)
+        return orig(terms, normal)
+
+    monkeypatch.setattr(N, "chain_logmmexp_terms", spy)
+    lazy = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert used == [K > 32], used
+    monkeypatch.setattr(D, "LAZY_TRANSITION", False)
+    plain = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert used[-1] is False
+    assert abs(lazy - plain) <= 2e-6 * abs(plain), (lazy, plain)
+    monkeypatch.setattr(D, "LAZY_TRANSITION", True)
+    assert abs(float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) - lazy) <= 1e-6 * abs(lazy)
+    cpu_prob, _ = kalman_problem(64)
+    cs = _same_sample_on_cpu(sample, cpu_prob, K)
+    with backend.installed():
+        cpu = float(cs.elbo_nograd(alan.no_checkpoint))
+    assert abs(lazy - cpu) <= 1e-4 * abs(cpu) + 1e-3, (lazy, cpu)
