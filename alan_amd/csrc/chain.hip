@@ -535,8 +535,10 @@ struct WaveOuts {
     int n[WAVE_ROUNDS];
 };
 
-template <int NADD, bool NORM = false>   // further terms added to the input on load (ChainAdd): 0..2 tensors, the Normal term
-__global__ __launch_bounds__(1024) void chain_wave_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
+// MAXT: the largest workgroup the instantiation is launched with (launches of <= 3 rounds: 256 threads -- one wave per
+// SIMD, so the loads of the on-load terms have registers to be in flight in)
+template <int NADD, bool NORM = false, int MAXT = 1024>   // further terms added to the input on load (ChainAdd): 0..2 tensors, the Normal term
+__global__ __launch_bounds__(MAXT) void chain_wave_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
                                                           int64_t sCol, int n_in, int K, int rounds, const WaveOuts outs,
                                                           float *vec_out, const ChainAdd<float> ad) {
     extern __shared__ __align__(16) float wl[];
@@ -771,8 +773,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
     if (K > 12 && K <= 32 && !per_round && !no_wave && fits32 && std::is_same<T, float>::value) {
         const size_t wsmem = (size_t)(25 * WAVE_TILE + 16 * 32) * sizeof(float);     // the largest launch (5 rounds)
         for (auto fn : {(const void *)chain_wave_kernel<0>, (const void *)chain_wave_kernel<1>, (const void *)chain_wave_kernel<2>,
-                        (const void *)chain_wave_kernel<0, true>, (const void *)chain_wave_kernel<1, true>,
-                        (const void *)chain_wave_kernel<2, true>})
+                        (const void *)chain_wave_kernel<0, true, 256>, (const void *)chain_wave_kernel<1, true, 256>,
+                        (const void *)chain_wave_kernel<2, true, 256>})
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wsmem) != hipSuccess)
                 return ALAN_ERR_LAUNCH;
         ChainAdd<float> adf, nonef;
@@ -789,9 +791,10 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             if (nd) {
                 const int want = li < nd ? digits[nd - 1 - li] : WAVE_ROUNDS;
                 rounds = std::min(std::max(1, std::min(want, WAVE_ROUNDS)), tl.L - r);
-            } else if (tl.n[r] * B > 64) {
-                rounds = std::min(3, tl.L - r);
+            } else if (tl.n[r] * B > 64 || (r == 0 && normal)) {
+                rounds = std::min(3, tl.L - r);           // (the Normal term's instantiation is built for <= 256 threads)
             }
+            if (r == 0 && normal) rounds = std::min(rounds, 3);
             const int nw = 1 << (rounds - 1);
             const size_t lsmem = (size_t)((nw + nw / 2 + 1) * WAVE_TILE + nw * 32) * sizeof(float);
             const int64_t nseg = (tl.n[r] + (1 << rounds) - 1) >> rounds;
@@ -802,7 +805,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             const int nadd = r == 0 ? n_more : 0;
             auto wk = nadd == 0 ? chain_wave_kernel<0> : nadd == 1 ? chain_wave_kernel<1> : chain_wave_kernel<2>;
             if (r == 0 && normal)
-                wk = nadd == 0 ? chain_wave_kernel<0, true> : nadd == 1 ? chain_wave_kernel<1, true> : chain_wave_kernel<2, true>;
+                wk = nadd == 0 ? chain_wave_kernel<0, true, 256> : nadd == 1 ? chain_wave_kernel<1, true, 256>
+                                                                              : chain_wave_kernel<2, true, 256>;
             hipLaunchKernelGGL(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
                                (const float *)src, cB, cT, cR, cC, (int)tl.n[r], (int)K, rounds, wo,
                                last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef);

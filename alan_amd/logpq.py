@@ -114,12 +114,6 @@ def _chain_of_terms(lps, Ks, core):
     if len(lazy) > 1 or (lazy and (len(lps) < 2 or lazy[0].grad or
                                    any(p.n_pos for p in (lazy[0].value, lazy[0].loc, lazy[0].scale)))):
         lazy = []                                         # (reading .x below evaluates them the usual way)
-    # (only where the chain takes one round per launch, K > 32: the multi-round kernels for smaller K hold a wave's two
-    # operands in registers and have none to spare for a third and fourth tensor's loads -- measured slower)
-    if lazy and core[1].size <= 32:
-        with N.may_defer():
-            lazy[0].x                                     # (evaluated here: the launch may queue -- the chain call flushes)
-        lazy = []
     trans = lazy[0] if lazy else None
     lps = [lp for lp in lps if lp is not trans]
     if any(lp.n_pos for lp in lps):
