@@ -367,7 +367,7 @@ __global__ __launch_bounds__(TREE_THREADS) void chain_tree_kernel(
 typedef float chain_f32x16 __attribute__((ext_vector_type(16)));
 typedef float chain_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KT, int NTW>
+template <int KT, int NTW, bool ADD = true>     // ADD: further terms on load (the first round only: every load then carries their branches)
 __global__ __launch_bounds__(64 * KT * KT / NTW) void chain_pair_mfma_kernel(
     const float *ms, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_src, int K,
     float *out, float *vec_out, const ChainAdd<float> ad) {
@@ -401,8 +401,9 @@ __global__ __launch_bounds__(64 * KT * KT / NTW) void chain_pair_mfma_kernel(
                 const int jj = lane + 64 * c;
                 const bool in = i < K && jj < K;
                 const int ic = min(i, K - 1), jc = min(jj, K - 1);
-                pv[rr][c] = chain_in(ms, (int64_t)t0 * sT + ic * sRow + jc * sCol, ad, b, (int64_t)t0, ic, jc);
-                cv[rr][c] = pair ? chain_in(ms, (int64_t)t1 * sT + ic * sRow + jc * sCol, ad, b, (int64_t)t1, ic, jc) : NINF;
+                const int64_t o0 = (int64_t)t0 * sT + ic * sRow + jc * sCol, o1 = (int64_t)t1 * sT + ic * sRow + jc * sCol;
+                pv[rr][c] = ADD ? chain_in(ms, o0, ad, b, (int64_t)t0, ic, jc) : ms[o0];
+                cv[rr][c] = !pair ? NINF : ADD ? chain_in(ms, o1, ad, b, (int64_t)t1, ic, jc) : ms[o1];
                 if (!in) pv[rr][c] = NINF, cv[rr][c] = NINF;
             }
         }
@@ -513,6 +514,8 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
                            vec_out, ad);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
+    const bool add = ad.n > 0 || ad.norm != 0;
+    if (!add) return kt == 2 ? go(chain_pair_mfma_kernel<2, 1, false>, 256) : go(chain_pair_mfma_kernel<4, 2, false>, 512);
     return kt == 2 ? go(chain_pair_mfma_kernel<2, 1>, 256) : go(chain_pair_mfma_kernel<4, 2>, 512);
 }
 
