@@ -493,6 +493,141 @@ __global__ __launch_bounds__(64 * KT * KT / NTW) void chain_pair_mfma_kernel(
     }
 }
 
+// The same product split over KT workgroups, one per tile ROW of the result (blockIdx.z): each loads its 32 rows of P
+// and ALL of C (whose column maxima it needs anyway), so nothing is exchanged between workgroups.  For the late rounds
+// of the tree, where a launch holds a handful of products and lasts as long as ONE of them: the exp pass over P, the
+// MFMA phase and the log epilogue shrink by KT, the loads of C do not (early rounds keep one workgroup per product:
+// there the launch is throughput-bound and reading C KT times would cost more than it saves).  No on-load terms.
+template <int KT>
+__global__ __launch_bounds__(64 * KT * 2) void chain_pair_stripe_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
+                                                                        int64_t sCol, int n_src, int K, float *out,
+                                                                        float *vec_out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int KP = 32 * KT, S = KP + 4, NTH = 64 * KT * 2, NW = NTH / 64, NC = KP / 64, RPW = KP / NW, RPS = 32 / NW;
+    float *Pe = reinterpret_cast<float *>(smem_raw);      // [32][S]   this workgroup's rows of P
+    float *Ce = Pe + 32 * S;                              // [KP][S]
+    float *pm = Ce + KP * S, *cm = pm + 32;               // row maxima of the stripe, column maxima of C
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int64_t b = blockIdx.y, node = blockIdx.x;
+    const int sr = blockIdx.z, row0 = 32 * sr;
+    const int t0 = 2 * (int)node, t1 = t0 + 1, KK = K * K;
+    const float NINF = -__builtin_huge_valf();
+    ms += b * sB;
+    float *o = out ? out + (b * gridDim.x + node) * (int64_t)KK : nullptr;
+    const bool pair = t1 < n_src;
+    for (int i = tid; i < 32 + KP; i += NTH) pm[i] = NINF;
+    __syncthreads();
+    {
+        float pv[RPS][NC], cv[RPW][NC];
+#pragma unroll
+        for (int rr = 0; rr < RPS; ++rr) {
+            const int ic = min(row0 + wave + NW * rr, K - 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) pv[rr][c] = ms[(int64_t)t0 * sT + ic * sRow + min(lane + 64 * c, K - 1) * sCol];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int ic = min(wave + NW * rr, K - 1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                cv[rr][c] = pair ? ms[(int64_t)t1 * sT + ic * sRow + min(lane + 64 * c, K - 1) * sCol] : NINF;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RPS; ++rr) {
+            const int li = wave + NW * rr, i = row0 + li;
+            float rmax = NINF;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int jj = lane + 64 * c;
+                const float v = (i < K && jj < K) ? pv[rr][c] : NINF;
+                if (i < K && jj < K) Pe[li * S + jj] = v;
+                rmax = fmaxf(rmax, v);
+            }
+#pragma unroll
+            for (int o_ = 32; o_ >= 1; o_ >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o_));
+            if (lane == 0 && i < K) pm[li] = rmax;
+        }
+        if (pair) {
+            float cmax[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cmax[c] = NINF;
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int i = wave + NW * rr;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int jj = lane + 64 * c;
+                    if (i < K && jj < K) {
+                        Ce[i * S + jj] = cv[rr][c];
+                        cmax[c] = fmaxf(cmax[c], cv[rr][c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (lane + 64 * c < K) lds_max(&cm[lane + 64 * c], cmax[c]);
+        }
+    }
+    __syncthreads();
+    if (pair) {
+        for (int e = tid; e < 32 * KP; e += NTH) {        // utils.py:503-505, pads -> 0
+            const int li = e / KP, jj = e - li * KP;
+            const bool in = row0 + li < K && jj < K;
+            Pe[li * S + jj] = in ? Num<float>::exp(Pe[li * S + jj] - pm[li]) : 0.f;
+        }
+        for (int e = tid; e < KP * KP; e += NTH) {
+            const int i = e / KP, jj = e - i * KP;
+            const bool in = i < K && jj < K;
+            Ce[i * S + jj] = in ? Num<float>::exp(Ce[i * S + jj] - cm[jj]) : 0.f;
+        }
+        __syncthreads();
+        chain_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (wave < KT) {                                  // one tile of the stripe per wave: tile column = wave
+            const float *prow = Pe + j * S;
+            const int nq4 = (K + 3) >> 2;
+            for (int q4 = 0; q4 < nq4; ++q4) {
+                const chain_f32x4 a4 = *reinterpret_cast<const chain_f32x4 *>(prow + 4 * q4);
+                const float a_lo = h ? a4[1] : a4[0], a_hi = h ? a4[3] : a4[2];
+                const float *c_lo = Ce + (4 * q4 + h) * S + 32 * wave + j, *c_hi = c_lo + 2 * S;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, c_lo[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, c_hi[0], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading Pe: R goes into Pe
+        if (wave < KT) {                                   // R = log(Pe @ Ce + eps) + pm + cm (utils.py:506-507)
+            const int col = 32 * wave + j;
+            const float cmj = col < K ? cm[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int li = (r & 3) + 8 * (r >> 2) + 4 * h, row = row0 + li;
+                if (row < K && col < K) {
+                    const float v = Num<float>::log(acc[r] + Num<float>::eps) + pm[li] + cmj;
+                    Pe[li * S + col] = v;
+                    if (o) o[row * K + col] = v;
+                }
+            }
+        }
+    } else if (o) {                                        // the leftover of this round passes through
+        for (int e = tid; e < 32 * K; e += NTH) {
+            const int li = e / K, jj = e - li * K;
+            if (row0 + li < K) o[(row0 + li) * K + jj] = Pe[li * S + jj];
+        }
+    }
+    if (vec_out) {                                         // torch.logsumexp(lp, -1)  (logpq.py:139): no eps
+        __syncthreads();
+        if (tid < 32 && row0 + tid < K) {
+            float mx = NINF;
+            for (int jj = 0; jj < K; ++jj) mx = fmaxf(mx, Pe[tid * S + jj]);
+            float sum = 0.f;
+            const float mref = (mx == NINF || mx == -NINF) ? 0.f : mx;
+            for (int jj = 0; jj < K; ++jj) sum += Num<float>::exp(Pe[tid * S + jj] - mref);
+            vec_out[b * K + row0 + tid] = Num<float>::log(sum) + mref;
+        }
+    }
+}
+
 // (the launcher of the kernel above: fp32 only)
 template <typename T>
 static int launch_pair_mfma(int64_t, uint32_t, uint32_t, hipStream_t, const T *, int64_t, int64_t, int64_t, int64_t, int,
@@ -515,6 +650,21 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
     const bool add = ad.n > 0 || ad.norm != 0;
+    static const int stripe_knob = env_knob("ALAN_CHAIN_STRIPE");                     // tuning knob: products per launch below which a product is split
+    const uint32_t stripe_below = stripe_knob != ENV_UNSET ? (uint32_t)std::max(0, stripe_knob) : 96u;
+    if (!add && (uint64_t)n_out * B < stripe_below) {
+        // a launch of few products lasts as long as one of them: one workgroup per tile row of each
+        const size_t ssm = (size_t)((32 + 32 * kt) * (32 * kt + 4) + 32 + 32 * kt) * sizeof(float);
+        auto gos = [&](auto kern, int threads) {
+            if (ssm > 64 * 1024)
+                if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm) != hipSuccess)
+                    return ALAN_ERR_LAUNCH;
+            hipLaunchKernelGGL(kern, dim3(n_out, B, (uint32_t)kt), dim3(threads), ssm, stream, src, cB, cT, cR, cC, n_src,
+                               (int)K, dst, vec_out);
+            return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+        };
+        return kt == 2 ? gos(chain_pair_stripe_kernel<2>, 256) : gos(chain_pair_stripe_kernel<4>, 512);
+    }
     if (!add) return kt == 2 ? go(chain_pair_mfma_kernel<2, 1, false>, 256) : go(chain_pair_mfma_kernel<4, 2, false>, 512);
     return kt == 2 ? go(chain_pair_mfma_kernel<2, 1>, 256) : go(chain_pair_mfma_kernel<4, 2>, 512);
 }
