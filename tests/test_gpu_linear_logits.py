@@ -29,9 +29,9 @@ def _ref(value, vdims, terms, out_dims):
     def al(x, d, extra=0):
         x = x.double()
         perm = [d.index(n) for n in names if n in d]
-        x = x.permute(*perm, *range(len(d), x.ndim))
+        x = x.permute([*perm, *range(len(d), x.ndim)])
         idx = tuple(slice(None) if n in d else None for n in names)
-        return x[idx]
+        return x[idx] if idx else x
 
     logits = 0
     for term in terms:
@@ -40,11 +40,12 @@ def _ref(value, vdims, terms, out_dims):
         else:
             (a, ad), (b, bd) = term
             logits = logits + (al(a, ad) * al(b, bd)).sum(-1)
-    lp = t.distributions.Bernoulli(logits=logits).log_prob(al(value, vdims).expand(logits.shape))
+    v, logits = t.broadcast_tensors(al(value, vdims), logits)
+    lp = t.distributions.Bernoulli(logits=logits).log_prob(v)
     drop = [i for i, n in enumerate(names) if n not in out_dims]
     lp = lp.sum(drop) if drop else lp
     left = [n for n in names if n in out_dims]
-    return lp.permute(*[left.index(n) for n in out_dims])
+    return lp.permute([left.index(n) for n in out_dims])
 
 
 @pytest.mark.parametrize("M,K,Nf,Ev", [(300, 30, 5, 18), (300, 100, 5, 18), (7, 3, 5, 18), (33, 10, 1, 1), (5, 4, 300, 3),
@@ -191,3 +192,88 @@ def test_dot_sum_matches_einsum(dtype):
     t.testing.assert_close(out2.double(), t.einsum("mkz,mnz->nkm", a.double(), b.double()), rtol=3e-6, atol=1e-5)
     out3 = E.dot_sum((a, ("m", "k")), (b, ("m", "n")), ("k",))
     t.testing.assert_close(out3.double(), t.einsum("mkz,mnz->k", a.double(), b.double()), rtol=3e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_linear_logits_and_dot_against_torch(seed):
+    """Random index spaces, term structures, storage orders and strides: alan_reduce modes BERNOULLI_LINEAR and DOT
+    against fp64 torch on the materialised broadcast."""
+    import random
+    rnd = random.Random(seed)
+    g = t.Generator().manual_seed(100 + seed)
+    names = ["a", "b", "c", "d", "e"][: rnd.randint(2, 5)]
+    size = {n: rnd.choice([1, 2, 3, 5, 7, 33]) for n in names}
+
+    def tensor(dims, extra=()):
+        """A random tensor over ``dims`` (+ trailing ``extra`` positional sizes), stored in a random dim order, sometimes
+        as a strided slice of a larger one."""
+        order = list(range(len(dims)))
+        rnd.shuffle(order)
+        shape = [size[dims[i]] for i in order] + list(extra)
+        if rnd.random() < 0.3 and shape:
+            big = t.randn([2 * s for s in shape], generator=g).to(DEV)
+            x = big[tuple(slice(None, None, 2) for _ in shape)]
+        else:
+            x = t.randn(shape, generator=g).to(DEV)
+        inv = [order.index(i) for i in range(len(dims))]
+        return x.permute([*inv, *range(len(dims), x.ndim)])
+
+    def some(k_min=0):
+        k = rnd.randint(k_min, len(names))
+        return tuple(rnd.sample(names, k))
+
+    vdims = some(1)
+    value = ((t.rand([size[n] for n in vdims], generator=g) < 0.5).float().to(DEV), vdims)
+    terms, used = [], set(vdims)
+    for _ in range(rnd.randint(1, 3)):
+        if rnd.random() < 0.6 and len(terms) * 2 + 3 <= 5:
+            L = rnd.choice([1, 2, 4, 9, 18])
+            da, db = some(), some()
+            terms.append(((tensor(da, (L,)), da), (tensor(db, (L,)), db)))
+            used |= set(da) | set(db)
+        else:
+            dp = some()
+            terms.append(((tensor(dp), dp),))
+            used |= set(dp)
+    if sum(len(tm) for tm in terms) > 5 or not any(len(tm) == 2 for tm in terms):
+        L = 3
+        terms = [((tensor(vdims, (L,)), vdims), (tensor(vdims[:1], (L,)), vdims[:1]))]
+        used = set(vdims)
+    every = [n for n in names if n in used]
+    keep = tuple(n for n in every if rnd.random() < 0.6)[:4]
+    out_dims = tuple(rnd.sample(keep, len(keep)))
+    n_sum = len([n for n in every if n not in keep and size[n] > 1])
+    got = E.bernoulli_linear_logprob(value, terms, out_dims, (1.0, 0.0))
+    if got is None:
+        assert n_sum > 2 or len([n for n in keep if size[n] > 1]) > 4 or len(every) + sum(len(tm) == 2 for tm in terms) > N.MAX_DIMS
+        return
+    cpu = lambda tm: tuple((x.cpu(), d) for x, d in tm)
+    want = _ref(value[0].cpu(), vdims, [cpu(tm) for tm in terms], out_dims)
+    scale = float(want.abs().max()) + 1.0
+    t.testing.assert_close(got.cpu().double(), want.reshape(got.shape), rtol=1e-5, atol=3e-6 * scale)
+    # the first dot term alone, through mode DOT
+    (a, da), (b, db) = next(tm for tm in terms if len(tm) == 2)
+    dd = tuple(dict.fromkeys((*da, *db)))
+    od = tuple(rnd.sample(dd, len(dd)))
+    dot = E.dot_sum((a, da), (b, db), od)
+    letters = {n: chr(ord("a") + i) for i, n in enumerate(names)}
+    ref = t.einsum(f"{''.join(letters[n] for n in da)}z,{''.join(letters[n] for n in db)}z->{''.join(letters[n] for n in od)}",
+                   a.double().cpu(), b.double().cpu())
+    t.testing.assert_close(dot.cpu().double(), ref, rtol=1e-5, atol=1e-5 * (float(ref.abs().max()) + 1.0))
+
+
+def test_chain_terms_normal_rejects_malformed_descriptors():
+    L = N.lib()
+    x = t.zeros(1, 4, 3, 3, device=DEV)
+    ptrs = (ctypes.c_void_p * 1)(x.data_ptr())
+    strides = (ctypes.c_int64 * 4)(*x.stride())
+    vec = t.empty(1, 3, device=DEV)
+    nbytes = L.alan_chain_batched_workspace_bytes(1, 4, 3, 0)
+    ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=DEV)
+    nd = N.ChainNormal()                                                 # null operands
+    assert L.alan_chain_logmmexp_terms_normal(ptrs, strides, 1, ctypes.byref(nd), 0, 1, 4, 3, None, vec.data_ptr(),
+                                              ws.data_ptr(), nbytes, None) == -1
+    assert L.alan_chain_logmmexp_terms_normal(None, strides, 1, None, 0, 1, 4, 3, None, vec.data_ptr(), ws.data_ptr(),
+                                              nbytes, None) == -1
+    assert L.alan_chain_logmmexp_terms_normal(ptrs, strides, 1, None, 0, 1, 4, 3, None, None, ws.data_ptr(), nbytes,
+                                              None) == -1
