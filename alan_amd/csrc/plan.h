@@ -66,6 +66,26 @@ struct LinDesc {
     int32_t len[LIN_T], ads[LIN_T], bds[LIN_T];
 };
 
+// Kernel argument of the small log-sum-exp + plate-sum kernel: out[keep] = sum_plate LSE_red(sum_f factor_f) + add_const
+// in ONE launch (reduce_Ks.py:249-251 then logpq.py:149) for problems too small for the rows kernel -- a lane group per
+// output walks the plate elements one after the other.  fp32, 32-bit offsets, <= SP_NK keep, SP_NP plate, SP_NR reduce dims.
+constexpr int SP_NK = 3, SP_NP = 2, SP_NR = 2;
+struct GroupLaunch;
+struct EvPair;
+
+struct SmallPlateDesc {
+    const float *f[MAXF];
+    float *out, *lse;                           // lse: optional per-(keep, plate) log-sum-exp values (the backward's input)
+    uint32_t n_out, n_plate, n_red;
+    int32_t nf;
+    float add_const;
+    FastDiv kdiv[SP_NK], pdiv[SP_NP], rdiv[SP_NR];     // right-aligned; unused leading slots: size 1
+    int32_t fks[MAXF][SP_NK], fps[MAXF][SP_NP], frs[MAXF][SP_NR];
+    int32_t oks[SP_NK], lks[SP_NK], lps[SP_NP];
+    float fscale[MAXF];
+};
+int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);
+
 struct GroupLaunch {
     int logG;
     bool block;

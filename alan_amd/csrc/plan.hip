@@ -475,6 +475,89 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     return ALAN_OK;
 }
 
+// LSE over REDUCE then sum over PLATE as one small launch (SmallPlateDesc), or false when the problem is not small /
+// not fp32 / has more dims than the kernel walks.
+static bool small_plate_prepare(const alan_reduce_desc_t &d, SmallPlateDesc &sd, GroupLaunch &gl) {
+    if (d.mode != ALAN_MODE_LSE || d.ndim < 0 || d.ndim > MAXD || d.n_factors < 1 || d.n_factors > MAXF) return false;
+    if (d.weight.data || d.ring_n || !d.out.data || d.out.dtype != ALAN_F32) return false;
+    if (d.lse_out.data && d.lse_out.dtype != ALAN_F32) return false;
+    for (int f = 0; f < d.n_factors; ++f)
+        if (!d.factor[f].data || d.factor[f].dtype != ALAN_F32) return false;
+    std::memset(&sd, 0, sizeof(sd));
+    int keep[MAXD], pl[MAXD], red[MAXD], nk = 0, np = 0, nr = 0;
+    int64_t n_out = 1, n_plate = 1, n_red = 1;
+    for (int i = 0; i < d.ndim; ++i) {
+        if (d.size[i] < 1) return false;
+        if (d.size[i] == 1) continue;
+        switch (d.role[i]) {
+            case ALAN_KEEP: keep[nk++] = i, n_out *= d.size[i]; break;
+            case ALAN_PLATE: pl[np++] = i, n_plate *= d.size[i]; break;
+            case ALAN_REDUCE: red[nr++] = i, n_red *= d.size[i]; break;
+            default: return false;
+        }
+        if (n_out * n_plate * n_red > (1ll << 22)) return false;        // bigger ones: the rows kernel / two launches
+    }
+    if (nk > SP_NK || np > SP_NP || nr > SP_NR || np == 0 || nr == 0 || n_plate > 4096) return false;
+    std::sort(keep, keep + nk, [&](int a, int b) { return d.out.stride[a] > d.out.stride[b]; });
+    int dom = 0;                                          // lanes run along the largest factor's innermost reduce dim
+    for (int f = 1; f < d.n_factors; ++f) {
+        auto ext = [&](int g) {
+            int64_t e = 1;
+            for (int i = 0; i < d.ndim; ++i)
+                if (d.factor[g].stride[i] != 0) e *= d.size[i];
+            return e;
+        };
+        if (ext(f) > ext(dom)) dom = f;
+    }
+    std::sort(red, red + nr, [&](int a, int b) { return d.factor[dom].stride[a] > d.factor[dom].stride[b]; });
+    const int ko = SP_NK - nk, po = SP_NP - np, ro = SP_NR - nr;
+    for (int k = 0; k < SP_NK; ++k) sd.kdiv[k] = make_fastdiv(k < ko ? 1u : (uint32_t)d.size[keep[k - ko]]);
+    for (int k = 0; k < SP_NP; ++k) sd.pdiv[k] = make_fastdiv(k < po ? 1u : (uint32_t)d.size[pl[k - po]]);
+    for (int k = 0; k < SP_NR; ++k) sd.rdiv[k] = make_fastdiv(k < ro ? 1u : (uint32_t)d.size[red[k - ro]]);
+    const int64_t lim = (1ll << 31) - 1;
+    bool fits = true;
+    auto lay = [&](const alan_tensor_t &x, int32_t *ks, int32_t *ps, int32_t *rs) {
+        int64_t reach = 0;
+        auto put = [&](const int *dims, int n, int off, int32_t *dst) {
+            for (int j = 0; j < n; ++j) {
+                const int64_t st = x.stride[dims[j]];
+                reach += (d.size[dims[j]] - 1) * (st < 0 ? -st : st);
+                if (st > lim || st < -lim) fits = false; else if (dst) dst[off + j] = (int32_t)st;
+            }
+        };
+        put(keep, nk, ko, ks);
+        put(pl, np, po, ps);
+        put(red, nr, ro, rs);
+        if (reach > lim) fits = false;
+    };
+    for (int f = 0; f < MAXF; ++f) {
+        const alan_tensor_t &src = d.factor[f < d.n_factors ? f : 0];
+        sd.f[f] = (const float *)src.data;
+        sd.fscale[f] = f < d.n_factors ? src.scale : 0.f;
+        if (f < d.n_factors) lay(src, sd.fks[f], sd.fps[f], sd.frs[f]);
+    }
+    for (int j = 0; j < np; ++j)
+        if (d.out.stride[pl[j]] != 0) return false;
+    for (int j = 0; j < nr; ++j)
+        if (d.out.stride[red[j]] != 0 || (d.lse_out.data && d.lse_out.stride[red[j]] != 0)) return false;
+    lay(d.out, sd.oks, nullptr, nullptr);
+    if (d.lse_out.data) lay(d.lse_out, sd.lks, sd.lps, nullptr);
+    if (!fits) return false;
+    sd.out = (float *)d.out.data;
+    sd.lse = (float *)d.lse_out.data;
+    sd.n_out = (uint32_t)n_out, sd.n_plate = (uint32_t)n_plate, sd.n_red = (uint32_t)n_red;
+    sd.nf = d.n_factors;
+    sd.add_const = (float)d.add_const;
+    int logG = 0;
+    while (logG < 6 && (1ll << logG) < n_red) ++logG;
+    gl.block = false;
+    gl.logG = logG;
+    const int64_t threads = n_out << logG;
+    if (threads >= (1ll << 31)) return false;
+    gl.grid = (uint32_t)((threads + 255) / 256);
+    return true;
+}
+
 static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
     uint32_t keep, red, plate;
     if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
@@ -674,6 +757,12 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         RowsPlan rp;
         if (plan_fused_plate(*d, keep, red, plate, c, rp))
             return launch_rows(c, rp, ALAN_MODE_LSE, d->add_const, workspace, workspace_bytes, stream, ev);
+    }
+    {
+        static const int sp_knob = env_knob("ALAN_SMALL_PLATE");                      // ablation knob: 0 = two launches
+        SmallPlateDesc sp;
+        GroupLaunch gl;
+        if (sp_knob != 0 && small_plate_prepare(*d, sp, gl)) return launch_small_plate(sp, gl, stream, ev);
     }
     alan_tensor_t v;
     if (d->lse_out.data) {

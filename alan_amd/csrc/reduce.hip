@@ -305,6 +305,86 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
 }
 
 // ------------------------------------------------------------------------------------------
+// Small log-sum-exp + plate sum in one launch (SmallPlateDesc): a lane group per output element; for each plate element
+// in turn the group reduces the REDUCE dims (lanes along them, shuffles), lane 0 adds the value to the plate sum.
+__global__ __launch_bounds__(256) void reduce_small_plate_kernel(const SmallPlateDesc d, const int logG) {
+    const uint32_t G = 1u << logG;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t grp = gid >> logG, gl = gid & (G - 1u);
+    const bool active = grp < d.n_out;
+    uint32_t o = active ? grp : d.n_out - 1u;
+    int32_t base[MAXF], obase = 0, lbase = 0;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) base[f] = 0;
+#pragma unroll
+    for (int k = SP_NK - 1; k >= 0; --k) {
+        const uint32_t q = fd_div(o, d.kdiv[k]);
+        const int32_t idx = (int32_t)(o - q * d.kdiv[k].d);
+        o = q;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) base[f] += idx * d.fks[f][k];
+        obase += idx * d.oks[k];
+        lbase += idx * d.lks[k];
+    }
+    float sc[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) sc[f] = d.fscale[f];
+    float total = 0.f;
+    for (uint32_t p = 0; p < d.n_plate; ++p) {
+        int32_t pb[MAXF], lp = lbase;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) pb[f] = base[f];
+        uint32_t pp = p;
+#pragma unroll
+        for (int k = SP_NP - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(pp, d.pdiv[k]);
+            const int32_t idx = (int32_t)(pp - q * d.pdiv[k].d);
+            pp = q;
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) pb[f] += idx * d.fps[f][k];
+            lp += idx * d.lps[k];
+        }
+        float m = Num<float>::ninf(), s = 0.f;
+        constexpr int UNR = 4;
+        for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
+            float val[UNR][MAXF];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const uint32_t ru = r0 + (uint32_t)u * G;
+                uint32_t rr = ru < d.n_red ? ru : r0;     // clamped: the slot is masked in accumulate()
+                int32_t off[MAXF];
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) off[f] = pb[f];
+#pragma unroll
+                for (int k = SP_NR - 1; k >= 0; --k) {
+                    const uint32_t q = fd_div(rr, d.rdiv[k]);
+                    const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+                    rr = q;
+#pragma unroll
+                    for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
+                }
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];    // (unused slots alias factor 0, stride 0)
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                accumulate<float, ALAN_MODE_LSE>(m, s, val[u], 0.f, sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
+        }
+        combine_lanes<float, ALAN_MODE_LSE, false>(m, s, G);
+        const float v = lse_finish(m, s);
+        if (active && gl == 0 && d.lse) d.lse[lp] = v;
+        total += v;
+    }
+    if (active && gl == 0) d.out[obase] = total + d.add_const;
+}
+
+int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
+    if (gl.grid == 0) return ALAN_OK;
+    hipExtLaunchKernelGGL(reduce_small_plate_kernel, dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, sd, gl.logG);
+    return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
 // ALAN_MODE_BERNOULLI_LINEAR: the Bernoulli producer with its logits computed on the fly,
 //   l = sum_t ( a_t  |  sum_e a_t[e] * b_t[e] ),     out = out_scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const
 // (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
