@@ -808,8 +808,8 @@ def _scaled_form(fn):
     """The constant c when ``fn`` is exactly ``lambda v: c * v`` / ``v * c`` with a numeric literal c, else None.
     Decided once per code object by symbolic tracing."""
     code = getattr(fn, "__code__", None)
-    if code is None or code.co_argcount != 1 or getattr(fn, "__closure__", None):
-        return None
+    if code is None or code.co_argcount != 1 or getattr(fn, "__closure__", None) or code.co_names:
+        return None                    # (co_names: a global the constant could come from -- and change under us)
     hit = _SCALED.get(id(code))
     if hit is not None and hit[0] is code:
         return hit[1]
