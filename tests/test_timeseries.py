@@ -358,7 +358,14 @@ def test_constant_multiple_lambda_is_folded_into_the_normal_producer(monkeypatch
     Normal producer multiplies the location itself (factor scale field).  Same ELBO as with the lambda evaluated."""
     from alan_amd import dist as D, engine as E
     monkeypatch.setattr(D, "LAZY_TRANSITION", False)      # (else the transition factor is not produced at all: next test)
-    prob, _ = kalman_problem(50)
+    # (a literal constant: a lambda that reads a module-level name -- kalman_problem's ``A * prev`` -- is evaluated as
+    # written, the global could change between evaluations)
+    assert D._scaled_form(lambda prev: A * prev) is None
+    y = t.randn(50, generator=t.Generator().manual_seed(0))
+    P = Plate(init=Normal(0, INIT_SCALE),
+              T=Plate(ts=Timeseries("init", Normal(lambda prev: 0.9 * prev, NOISE)), obs=Normal("ts", OBS)))
+    Q = Plate(init=Normal(0, 1), T=Plate(ts=Normal(0, 1), obs=Data()))
+    prob = Problem(BoundPlate(P, {"T": 50}), BoundPlate(Q, {"T": 50}), {"obs": y.refine_names("T")})
     prob.to("cuda")
     t.manual_seed(3)
     sample = prob.sample(10, reparam=False)
