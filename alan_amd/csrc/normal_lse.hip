@@ -60,6 +60,7 @@ constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530
 // that would be 7/8 padding.  (STAGE only: its A operand has the event index spread over the four lane quarters and is
 // read from the wave's LDS tile.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 //
 // FLAT (STAGE, NLW = 1, NK > 32 not a multiple of 32, plate elements contiguous in memory): the k rows of a wave's
@@ -304,10 +305,18 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             const float mnew = fminf(mn[u], tmin);
             const float mf = mnew == inf ? 0.f : mnew;
             float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
+            const f32x2v mf2 = {mf, mf};
+            f32x2v part = {0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc4[b][r]);
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2v a2 = {acc4[b][r], acc4[b][r + 1]};
+                    const f32x2v d2 = mf2 - a2;
+                    const f32x2v e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
+                    part += e2;
+                }
+            ssum += part[0] + part[1];
             mn[u] = mnew, sm[u] = ssum;
             }
         }
@@ -360,8 +369,17 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
             const float mnew = fminf(mn[u], tmin);
             const float mf = mnew == inf ? 0.f : mnew;
             float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
+            // (register pairs: v_pk_add_f32 takes the differences and the partial sums two at a time)
+            const f32x2v mf2 = {mf, mf};
+            f32x2v part = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ssum += __builtin_amdgcn_exp2f(mf - acc[r]);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2v a2 = {acc[r], acc[r + 1]};
+                const f32x2v d2 = mf2 - a2;
+                const f32x2v e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
+                part += e2;
+            }
+            ssum += part[0] + part[1];
             mn[u] = mnew, sm[u] = ssum;
             }
         }
