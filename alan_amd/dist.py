@@ -915,7 +915,10 @@ def _dot_pt(a, b):
     """sum over the single positional dim of a * b, broadcast over first-class dims: one launch of the library's own
     (mode DOT -- it may sit in the queue of small producer launches), or a (batched) GEMM for dtypes it does not take."""
     dims, ids = pt_order((a, b))
-    if a.x.dtype == t.float32 and b.x.dtype == t.float32:
+    n_out = math.prod(d.size for d in dims)
+    # (small ones ride in a queued multi-problem launch; a big one is a GEMM's job: 90,000 outputs take the library's
+    # generic kernel 9.4 us against rocBLAS's 4.7)
+    if a.x.dtype == t.float32 and b.x.dtype == t.float32 and n_out <= 32768:
         from . import engine as E
         from . import native as N
         with N.may_defer():
