@@ -109,7 +109,6 @@ class Sample:
         self._pt_detached = _detach_tree(pt) if reparam else pt
         self._pt_reparam = pt if reparam else None
         self._dim_views = {}
-        self._const = {}       # per-Sample memo of pure functions of the (fixed) particles: lives as long as its graphs
 
     def _view(self, which):
         if which not in self._dim_views:
@@ -165,8 +164,7 @@ class Sample:
                 extra_log_factors=extra, scope={}, active_platedims=[], all_platedims=self.all_platedims,
                 groupvarname2Kdim=self.groupvarname2Kdim,
                 varname2groupvarname=self._v2g(),
-                sampler=self.sampler, computation_strategy=computation_strategy,
-                dimcache={"__const__": self._const})
+                sampler=self.sampler, computation_strategy=computation_strategy, dimcache={})
         assert lp.dims == (), "every K and plate dim should have been eliminated"
         return lp.x
 
@@ -250,12 +248,8 @@ class Sample:
         from . import dist as D
         from . import native as N
         # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
-        # ... and on what was computed once from the particles and is read from memory by the graph (self._const): the
-        # particles' version counters are part of the key, so particles modified in place start over
-        from .model import flatten_tree
-        versions = tuple(v.x._version for v in flatten_tree(self._pt_detached).values())
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, D.LINEAR_LOGITS, D.LAZY_SCALED, D.LAZY_TRANSITION, versions)
+                N.DEFER_SMALL_LAUNCHES)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)

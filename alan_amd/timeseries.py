@@ -11,23 +11,6 @@ from .dims import PT, Dim, dims_of
 from .dist import _DistSpec
 
 
-def _previous_states(init_pos, shifted_pos, axis, store, name):
-    """cat([init, x_0 .. x_{T-2}]) along ``axis``.  ``store`` (a dict that lives as long as the Sample, or None): for a
-    fixed, gradient-free sample the result is remembered there, so that repeated evaluations of the same particles
-    (sample.elbo_nograd in a loop, and the HIP graph captured from it -- which the same Sample owns) do not redo the
-    copy.  Checked by address, layout and version counter of both tensors, which are kept alive with the entry."""
-    if store is None or (t.is_grad_enabled() and (init_pos.requires_grad or shifted_pos.requires_grad)):
-        return t.cat([init_pos.unsqueeze(axis), shifted_pos], axis)
-    key = tuple((x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version, x.dtype) for x in (init_pos, shifted_pos))
-    hit = store.get(("prev", name))
-    if hit is not None and hit[0] == key:
-        return hit[2]
-    prev = t.cat([init_pos.unsqueeze(axis), shifted_pos], axis)
-    if not (prev.is_cuda and t.cuda.is_current_stream_capturing()):     # (a graph's private memory is not for keeps)
-        store[("prev", name)] = (key, (init_pos, shifted_pos), prev)
-    return prev
-
-
 class Timeseries(nn.Module):
     is_timeseries = True
     qem_dist = False
@@ -102,8 +85,7 @@ class Timeseries(nn.Module):
         lead = [d for d in dims_of(init)]
         init_pos = init.order(*lead)
         shifted_pos = shifted.order(*lead)               # [*lead, T-1, ...]
-        store = dimcache.get("__const__") if dimcache is not None else None
-        prev = _previous_states(init_pos, shifted_pos, len(lead), store, (self.init, id(K_dim)))
+        prev = t.cat([init_pos.unsqueeze(len(lead)), shifted_pos], len(lead))
         prev = prev[(*lead, T_dim)]
         scope = dict(scope)
         scope["prev"] = PT.of(prev)

@@ -423,38 +423,3 @@ def test_transition_factor_computed_on_load_by_the_chain_equals_the_materialised
     with backend.installed():
         cpu = float(cs.elbo_nograd(alan.no_checkpoint))
     assert abs(lazy - cpu) <= 1e-4 * abs(cpu) + 1e-3, (lazy, cpu)
-
-
-@pytest.mark.gpu
-def test_previous_state_memo_follows_in_place_changes_of_the_particles():
-    """The [init, x_0 .. x_{T-2}] concatenation is remembered per Sample for gradient-free evaluations (no copy kernel in
-    repeated evaluations / the captured graph); it is keyed by the tensors' version counters, so particles modified in
-    place are seen, and an evaluation with gradients never uses it."""
-    from alan_amd.dims import PT
-    prob, _ = kalman_problem(40)
-    prob.to("cuda")
-    t.manual_seed(6)
-    sample = prob.sample(8, reparam=False)
-    a = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
-    assert any(k[0] == "prev" for k in sample._const)
-    assert float(sample.elbo_nograd(alan.no_checkpoint, graph=False)) == a
-    ts = sample._pt_detached["T"]["ts"]
-    with t.no_grad():
-        ts.x.mul_(1.01)
-    b = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
-    assert abs(b - a) > 1e-4 * abs(a)
-    fresh = alan.sample.Sample(prob, {"init": sample._pt_detached["init"], "T": {"ts": PT(ts.x.clone(), ts.dims)}},
-                               sample.groupvarname2Kdim, sample.sampler, False)
-    assert abs(float(fresh.elbo_nograd(alan.no_checkpoint, graph=False)) - b) <= 1e-6 * abs(b)
-    assert math.isfinite(float(sample.elbo_rws(alan.no_checkpoint)))
-    # replayed graphs read the remembered tensor from memory: particles changed in place start a new graph
-    g1 = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
-    assert abs(g1 - b) <= 1e-6 * abs(b)
-    with t.no_grad():
-        ts.x.mul_(0.99)
-    g2 = float(sample.elbo_nograd(alan.no_checkpoint, graph=True))
-    e2 = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
-    assert abs(g2 - e2) <= 1e-6 * abs(e2) and abs(g2 - g1) > 1e-5 * abs(g1)
-    for _ in range(4):                                                   # (and the automatic promotion likewise)
-        auto = float(sample.elbo_nograd(alan.no_checkpoint))
-    assert abs(auto - e2) <= 1e-6 * abs(e2)
