@@ -576,3 +576,29 @@ def test_reparameterised_sampling_through_one_autograd_node_gives_the_same_vi_gr
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
         t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,model,split", [("e2e_movielens_K10.pt", "movielens", ("plate_1", 38)),
+                                                 ("e2e_bus_breakdown_K3.pt", "bus_breakdown", ("plate_ID", 40))])
+def test_vi_gradients_agree_across_computation_strategies(fixture, model, split):
+    """elbo_vi parameter gradients under no_checkpoint, checkpoint (the forward is recomputed inside backward: the
+    reparameterisation nodes and the own-sample log-probs are then built a second time) and Split (sliced particles:
+    plain tensors again) on the same seeded particles (test_compstrat_elbo_vi, tests/test_problem_vs_itself.py:231-262)."""
+    fx = load_golden(fixture)
+    out = {}
+    for name, strat in (("plain", alan.no_checkpoint), ("checkpoint", alan.checkpoint), ("split", alan.Split(*split))):
+        prob = models.BUILDERS[model](fx).to("cuda").float()
+        t.manual_seed(5)
+        sample = prob.sample(int(fx["K"]), reparam=True)
+        elbo = sample.elbo_vi(strat)
+        elbo.backward()
+        out[name] = (float(elbo), {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None})
+    e0, g0 = out["plain"]
+    for name in ("checkpoint", "split"):
+        e, g = out[name]
+        assert abs(e - e0) <= 2e-6 * abs(e0), (name, e, e0)
+        assert g.keys() == g0.keys()
+        for n in g0:
+            scale = float(g0[n].abs().max()) + 1e-6
+            t.testing.assert_close(g[n], g0[n], rtol=3e-4, atol=3e-5 * scale, msg=lambda m: f"{name} {n}: {m}")
