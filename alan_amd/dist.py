@@ -443,7 +443,9 @@ class TorchDimDist:
                     x = x.permute(*range(ns, ns + nd), *range(ns), *range(ns + nd, x.ndim))
                 return ReparamPT(x, (*extra, *self.all_arg_dims), src)
         if self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"} and not sample_shape \
-                and not (reparam and t.is_grad_enabled()):
+                and not (reparam and t.is_grad_enabled()) \
+                and self.kwargs["loc"].x.dtype == self.kwargs["scale"].x.dtype \
+                and self.kwargs["loc"].x.device == self.kwargs["scale"].x.device:
             # gradient-free Normal draw, written directly in the caller's dim order (plates outermost, K innermost) from
             # noise drawn in rsample's order -- the same particles, no re-layout copy afterwards
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
