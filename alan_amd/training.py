@@ -76,11 +76,32 @@ class GraphedStep:
         self.strategy = computation_strategy
         side = t.cuda.Stream()
         side.wait_stream(t.cuda.current_stream())
-        with t.cuda.stream(side):
-            for _ in range(warmup):                    # allocator / lazy-init warm-up outside capture
-                self._iteration()
+        import warnings
+        warn_always = t.is_warn_always_enabled()
+        t.set_warn_always(True)                        # (the stream-mismatch warning below is a warn-once one)
+        try:
+            with t.cuda.stream(side), warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                for _ in range(warmup):                # allocator / lazy-init warm-up outside capture
+                    self._iteration()
+        finally:
+            t.set_warn_always(warn_always)
         t.cuda.current_stream().wait_stream(side)
         t.cuda.synchronize()
+        stale = [w for w in seen if "AccumulateGrad node's stream does not match" in str(w.message)]
+        for w in seen:
+            if w not in stale:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if stale:
+            # A parameter's gradient-accumulation node still belongs to an EARLIER backward on another stream (something
+            # keeps that autograd graph alive: typically the loss tensor of an eager elbo_vi().backward()).  Autograd
+            # would run it on that stream during the capture -- work the capture does not see; on this ROCm ending such
+            # a capture crashes the process.  Refuse here instead.
+            raise RuntimeError(
+                "GraphedStep: a parameter still carries the gradient-accumulation node of an earlier backward() made on "
+                "another stream -- some tensor of that autograd graph (e.g. the ELBO you called .backward() on) is still "
+                "alive (the ELBO, or the reparameterised Sample it came from).  Delete them or build the GraphedStep before any "
+                "eager backward on this problem, then try again.")
         self.graph = t.cuda.CUDAGraph(keep_graph=True)
         self.opt.zero_grad(set_to_none=True)
         # Capture on the SAME stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it

@@ -602,3 +602,24 @@ def test_vi_gradients_agree_across_computation_strategies(fixture, model, split)
         for n in g0:
             scale = float(g0[n].abs().max()) + 1e-6
             t.testing.assert_close(g[n], g0[n], rtol=3e-4, atol=3e-5 * scale, msg=lambda m: f"{name} {n}: {m}")
+
+
+@pytest.mark.gpu
+def test_graphed_step_refuses_to_capture_over_a_live_autograd_graph_of_an_earlier_backward():
+    """An eager elbo_vi().backward() leaves the parameters' gradient-accumulation nodes on the stream it ran on for as
+    long as anything of that autograd graph is alive (the ELBO; the reparameterised Sample).  Capturing a training step
+    then would run them outside the capture (on this ROCm: a crash when the capture ends): GraphedStep refuses with an
+    explanation, each time, and works once those tensors are gone."""
+    fx = load_golden("e2e_movielens_K10.pt")
+    prob = models.BUILDERS["movielens"](fx).to("cuda").float()
+    sample = prob.sample(10, reparam=True)
+    elbo = sample.elbo_vi(alan.no_checkpoint)
+    elbo.backward()
+    opt = t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True)
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="gradient-accumulation node"):
+            alan.GraphedStep(prob, 10, opt, method="vi")
+    del elbo, sample
+    step = alan.GraphedStep(prob, 10, opt, method="vi")
+    vals = [float(step()) for _ in range(3)]
+    assert all(v == v and abs(v) < 1e30 for v in vals)
