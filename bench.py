@@ -419,6 +419,21 @@ def main():
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
         t.cuda.empty_cache()
+        if world == 1 and not args.c4_only and "error" not in out["c4_movielens_K100"]:
+            # what ONE rank of an N-GPU C4 run computes, timed on this GPU without the collective: the same K=100 ELBO over
+            # the rank's ceil(300 / N) users (tools/rank_share.py) -- the compute side of the 1 -> 8 GPU scaling figure
+            share = {}
+            try:
+                for n in (2, 4, 8):
+                    pn = build_problem("cuda", M=-(-M_USERS // n))
+                    sn = draw(pn, 100)
+                    dn, _ = timed_evals(sn, alan.no_checkpoint, 10, 2, 1, graph=use_graph)
+                    share[f"N{n}"] = {"users": -(-M_USERS // n), "us_per_eval": dn / 10 * 1e6}
+                    del pn, sn
+                out["c4_movielens_K100"]["rank_share_no_collective"] = share
+            except Exception as e:
+                out["c4_movielens_K100"]["rank_share_no_collective"] = {"error": f"{type(e).__name__}: {e}"}
+            t.cuda.empty_cache()
         if world > 1:
             # the same plate step at a fixed 300 users PER GPU (M = 300 * N): what sharding buys when the plate grows
             # with the machine -- per-GPU work constant, still one all-reduce of [K,K] per evaluation
