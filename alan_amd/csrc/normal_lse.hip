@@ -510,6 +510,8 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     p.eh = need <= 4 ? 4 : need <= 8 ? 8 : need <= 10 ? 10 : need <= 12 ? 12 : 17;
     const int64_t nst_total = (a.NS + 31) / 32;
     p.nst = nst_total >= 4 ? 4 : nst_total >= 2 ? 2 : 1;
+    static const int nst_knob = env_knob("ALAN_NLSE_NST");                            // tuning knob: scale tiles per wave
+    if (nst_knob == 1 || nst_knob == 2 || nst_knob == 4) p.nst = std::min<int>(p.nst, nst_knob);
     const int64_t nsg = (nst_total + p.nst - 1) / p.nst;
     static const int nlw_knob = env_knob("ALAN_NLSE_NLW");                            // tuning knob
     p.nlw = (p.nst == 1 && a.NL >= 8) ? 2 : 1;
