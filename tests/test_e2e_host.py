@@ -623,3 +623,52 @@ def test_graphed_step_refuses_to_capture_over_a_live_autograd_graph_of_an_earlie
     step = alan.GraphedStep(prob, 10, opt, method="vi")
     vals = [float(step()) for _ in range(3)]
     assert all(v == v and abs(v) < 1e30 for v in vals)
+
+
+def _hier_nonmeanfield():
+    from alan_amd import Normal, Plate, BoundPlate, Problem, Data, OptParam
+    y = t.randn(6, generator=t.Generator().manual_seed(1)).refine_names("p")
+    P = Plate(mu=Normal(0., 1.), p=Plate(z=Normal("mu", 1.), obs=Normal("z", 0.5)))
+    Q = Plate(mu=Normal(OptParam(0.1), OptParam(-0.2, transformation=t.exp)),
+              p=Plate(z=Normal(lambda mu: 0.5 * mu, OptParam(0.7)), obs=Data()))
+    return Problem(BoundPlate(P, {"p": 6}), BoundPlate(Q, {"p": 6}), {"obs": y}), 9
+
+
+def _vector_events():
+    from alan_amd import Normal, Plate, BoundPlate, Problem, Data, OptParam
+    y = t.randn(5, 3, generator=t.Generator().manual_seed(2)).refine_names("p", None)
+    P = Plate(mu=Normal(t.zeros(3), t.ones(3)), p=Plate(z=Normal("mu", t.ones(3)), obs=Normal("z", t.ones(3))))
+    Q = Plate(mu=Normal(OptParam(t.zeros(3)), OptParam(t.zeros(3), transformation=t.exp)),
+              p=Plate(z=Normal(OptParam(t.zeros(3)), OptParam(t.zeros(3), transformation=t.exp)), obs=Data()))
+    return Problem(BoundPlate(P, {"p": 5}), BoundPlate(Q, {"p": 5}), {"obs": y}), 8
+
+
+def _wide_group():
+    fx = load_golden("e2e_wide_group.pt")
+    return models.BUILDERS["wide_group"](fx), int(fx["K"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("build", [_hier_nonmeanfield, _vector_events, _wide_group],
+                         ids=["parent_dependent_Q_plain_scale", "vector_events", "group_of_seven"])
+def test_reparameterisation_nodes_on_other_model_shapes(build, monkeypatch):
+    """dist.FUSE_REPARAM on / off, same seed: a Q whose location is a lambda of the sampled parent (the own-sample
+    shortcut must NOT fire: the location tensor is a new one at every evaluation) with a plain positive scale, vector
+    events with per-plate-element parameters, a Group of seven variables on one K."""
+    from alan_amd import dist as D
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(D, "FUSE_REPARAM", fuse)
+        prob, K = build()
+        prob = prob.to("cuda").float()
+        t.manual_seed(3)
+        s = prob.sample(K, reparam=True)
+        e = s.elbo_vi(alan.no_checkpoint)
+        e.backward()
+        res[fuse] = (float(e), {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None})
+        del s, e, prob
+    (e1, g1), (e0, g0) = res[True], res[False]
+    assert abs(e1 - e0) <= 1e-5 * abs(e0) and g1.keys() == g0.keys() and len(g0) >= 3
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
