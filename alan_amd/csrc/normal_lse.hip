@@ -479,6 +479,366 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same tile on the bf16 matrix instructions with 3-way split operands (the default since round 3).
+//
+// fp32 MFMA runs at the vector rate and holds the vector unit while it does (tools/mfma_f32_probe.hip: the log-sum-exp's
+// VALU work ADDS to the matrix time, 442 ns per tile per SIMD).  v_mfma_f32_32x32x16_bf16 is 16 x faster per flop and
+// leaves the vector unit free for 24 of its 32 cycles.  Each f32 operand is split exactly into three bf16 pieces
+// (x = h + m + l, round-to-nearest at every step) and the product a b is taken as the six terms of order >= 2^-16,
+//     ah bh + ah bm + am bh + ah bl + al bh + am bm        (every bf16 x bf16 product is exact in f32; f32 accumulate),
+// the terms dropped being <= 2^-23 |a b|: measured against fp64 the result is as close as the f32 fma chain
+// (tools/mfma_bf16x3_probe.hip: 2.35e-7 against 2.51e-7 of sum |a b|).  The six terms are laid out ALONG the contraction
+// dim -- 6 (E + 1) slots, 114 for E = 18 -- so a tile takes 8 matrix instructions (256 cycles) where the f32 form takes
+// 10 of 64 cycles: per event a lane holds three packed registers
+//     A: (ah, ah) (am, ah) (al, am)        B: (bh, bm) (bh, bl) (bh, bm)        [low half, high half]
+// and lane half h takes the events 2 q + h; MFMA step t consumes registers 4 t .. 4 t + 3 of both.  B is split once per
+// workgroup into an LDS table (NST tiles x NSTEP steps x 64 lanes x 16 bytes, read with one ds_read_b128 per step; in
+// registers when the wave has one scale tile); A costs 9 VALU per element and tile of 32 rows and is shared by the
+// wave's NST scale tiles.  Rows beyond NK and -inf small factors carry NL_BIG (finite: inf - inf would poison the split)
+// in the small-factor slot: 2^(min - NL_BIG log2e) = 0, and a column whose rows are ALL masked ends with a minimum
+// >= 1e29, which is reported as the NaN utils.py:219 gives.
+typedef short bf16x8v __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+constexpr float NL_BIG = 1e30f;
+
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+// (lo, hi) -> one register of two bf16, round-to-nearest-even: v_cvt_pk_bf16_f32.  A vector cast, not inline asm: the
+// compiler pads the wait states between a vector instruction's result and a matrix instruction that reads it as A or
+// B only when it knows what wrote the register -- behind an asm the MFMA read a stale operand (seen: the first tile
+// of a pipelined chain wrong, the later tiles, which reuse the same A registers, right).
+__device__ __forceinline__ unsigned nl_cvt_pk(float lo, float hi) {
+    const f32x2v v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
+}
+__device__ __forceinline__ void nl_split_a(float x, unsigned &r1, unsigned &r2, unsigned &r3) {
+    r1 = nl_cvt_pk(x, x);                                         // (h, h)
+    const float hf = __uint_as_float(r1 & 0xffff0000u);
+    const float e1 = x - hf;
+    r2 = nl_cvt_pk(e1, hf);                                       // (m, h)
+    const float mf = __uint_as_float(r2 << 16);
+    const float e2 = e1 - mf;
+    r3 = nl_cvt_pk(e2, e1);                                       // (l, m)
+}
+__device__ __forceinline__ void nl_split_b(float x, unsigned &r1, unsigned &r2, unsigned &r3) {
+    const unsigned hh = nl_cvt_pk(x, x);
+    const float hf = __uint_as_float(hh & 0xffff0000u);
+    const float e1 = x - hf;
+    const unsigned mm = nl_cvt_pk(e1, e1);
+    const float mf = __uint_as_float(mm & 0xffff0000u);
+    const unsigned ll = nl_cvt_pk(e1 - mf, e1 - mf);
+    r1 = (hh & 0xffffu) | (mm & 0xffff0000u);                     // (h, m)
+    r2 = (hh & 0xffffu) | (ll & 0xffff0000u);                     // (h, l)
+    r3 = r1;                                                      // (h, m)
+}
+
+// EQ: events per lane half incl. the small-factor slot (2 EQ >= E + 1).  Waves of a workgroup share their group of
+// scale tiles (blockIdx.x = scale group + nsg * group of four loc-row groups), so the B table is the workgroup's.
+// The value tile is staged as in the f32 kernel (STAGE): the launcher takes this kernel only for contiguous rows.
+template <int EQ, int NST, int NLW, bool FLAT>
+__global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
+    static_assert(!FLAT || NLW == 1, "flat row tiling: one loc row per wave");
+    constexpr int NSTEP = (3 * EQ + 3) / 4, NV = 4 * NSTEP;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int NK = d.NK, E = d.E, NS = d.NS;
+    const int nkt = (NK + 31) >> 5, nsg = (((NS + 31) >> 5) + NST - 1) / NST;
+    const int nlg = (d.NL + NLW - 1) / NLW;
+    const int sg = blockIdx.x % nsg, lgp = (blockIdx.x / nsg) * 4 + wave;
+    const bool wave_on = lgp < nlg;
+    const int l = min(lgp, nlg - 1) * NLW;
+    const int slot_h = E > 2 * (EQ - 1) ? 1 : 0;                   // the small-factor slot: event pair EQ - 1, this half
+    const float inf = __builtin_huge_valf();
+    // ---- LDS: B table | log-normalisers | the waves' value tiles
+    u32x4v *bt = reinterpret_cast<u32x4v *>(lds);
+    float *lgn_l = lds + NST * NSTEP * 64 * 4;
+    float *tile = lgn_l + NST * 32 + wave * (32 * 33);
+    {
+        unsigned *bw = reinterpret_cast<unsigned *>(lds);
+        for (int idx = tid; idx < NST * EQ * 64; idx += 256) {
+            const int ln = idx & 63, q = (idx >> 6) % EQ, st = (idx >> 6) / EQ;
+            const int jj = ln & 31, hh = ln >> 5, e = 2 * q + hh;
+            const int s = 32 * (sg * NST + st) + jj;
+            float b = 0.f;
+            if (s < NS && e < E) {
+                const float x = d.scl[(int64_t)s * d.s_ss + (int64_t)e * d.s_se];
+                b = (d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x)) * NL_LOG2E;
+            } else if (s < NS && q == EQ - 1 && hh == slot_h) {
+                b = NL_LOG2E;
+            }
+            unsigned r[3];
+            nl_split_b(b, r[0], r[1], r[2]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int v = 3 * q + i;
+                bw[((st * NSTEP + (v >> 2)) * 64 + ln) * 4 + (v & 3)] = r[i];
+            }
+        }
+        for (int idx = tid; idx < NST * 64 * (NV - 3 * EQ); idx += 256) {      // the registers beyond 3 EQ: zero
+            const int ln = idx & 63, rest = idx >> 6, v = 3 * EQ + rest % (NV - 3 * EQ > 0 ? NV - 3 * EQ : 1);
+            const int st = rest / (NV - 3 * EQ > 0 ? NV - 3 * EQ : 1);
+            bw[((st * NSTEP + (v >> 2)) * 64 + ln) * 4 + (v & 3)] = 0u;
+        }
+        if (tid < NST * 32) {
+            const int s = 32 * (sg * NST) + tid;
+            float lg = 0.f;
+            if (s < NS)
+                for (int e = 0; e < E; ++e) {
+                    const float x = d.scl[(int64_t)s * d.s_ss + (int64_t)e * d.s_se];
+                    lg += d.log_scale ? x : logf(x);
+                }
+            lgn_l[tid] = lg + (float)E * 0.91893853320467274178f;
+        }
+        if (FLAT || (NK & 31))                        // rows beyond NK are never written: keep them finite
+            for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;
+    }
+    __syncthreads();
+    if (!wave_on) return;                             // (no barrier below)
+    float lgn[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) lgn[st] = lgn_l[st * 32 + j];
+    u32x4v breg[NSTEP];                               // B of the unit about to be multiplied (one scale tile: for good)
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) breg[step] = bt[step * 64 + lane];
+    float mreg[NLW][EQ];
+#pragma unroll
+    for (int lw = 0; lw < NLW; ++lw)
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) {
+            const int e = 2 * q + h;
+            const float x = d.loc[(int64_t)min(l + lw, d.NL - 1) * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
+            mreg[lw][q] = e < E ? x : 0.f;
+        }
+    const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
+    const int rows_total = (m1 - m0) * NK;
+    const int n_tiles = FLAT ? (rows_total + 31) >> 5 : (m1 - m0) * nkt;
+    // the value tile: this lane's share of the contiguous run of 32 E floats (floats lane + 64 q)
+    constexpr int NX = EQ;
+    uint32_t soff[NX];
+    {
+        const int r64 = 64 / E, c64 = 64 - r64 * E;
+        int row = lane / E, col = lane - row * E;
+#pragma unroll
+        for (int qq = 0; qq < NX; ++qq) {
+            soff[qq] = row < 32 ? row * (E + 1) + col : 32 * 33 - 1;
+            row += r64, col += c64;
+            if (col >= E) col -= E, ++row;
+        }
+    }
+    auto load_tile = [&](int m, int kt_, float (&x)[NX], float (&hs)[4]) {
+        const float *vp = d.val + (int64_t)m * d.v_sm + (int64_t)(32 * kt_) * d.v_sk;      // (uniform)
+        const int rows = min(32, NK - 32 * kt_);
+        const uint32_t lim = (uint32_t)(rows * E - 1);
+#pragma unroll
+        for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        const uint32_t kk = (uint32_t)min(32 * kt_ + j, NK - 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float *sp = d.small[f] + (int64_t)m * d.small_sm[f];                       // (uniform)
+            hs[f] = sp[kk * (uint32_t)d.small_sk[f]];
+        }
+        asm volatile("" ::: "memory");
+    };
+    int pm = m0, pk = 0;
+    auto load_flat = [&](int tt, float (&x)[NX], float (&hs)[4]) {
+        const float *vp = d.val + (int64_t)m0 * d.v_sm + (int64_t)(32 * tt) * E;          // (uniform)
+        const int rows = min(32, rows_total - 32 * tt);
+        const uint32_t lim = (uint32_t)(rows * E - 1);
+#pragma unroll
+        for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        int lm = pm, lk = pk + j;
+        if (lk >= NK) lk -= NK, ++lm;
+        const bool in = lm < m1;
+        const uint32_t mm = (uint32_t)((in ? lm : m1 - 1) - m0), kk = (uint32_t)(in ? lk : NK - 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float *sp = d.small[f] + (int64_t)m0 * d.small_sm[f];                      // (uniform)
+            hs[f] = sp[mm * (uint32_t)d.small_sm[f] + kk * (uint32_t)d.small_sk[f]];
+        }
+        pk += 32;
+        if (pk >= NK) pk -= NK, ++pm;
+        asm volatile("" ::: "memory");
+    };
+    float zc[NX], zn[NX], hc[4], hn[4];
+    if (n_tiles > 0) {
+        if (FLAT)
+            load_flat(0, zc, hc);
+        else
+            load_tile(m0, 0, zc, hc);
+    }
+    constexpr int NU = NLW * NST;
+    float accm[NU], mn[NU], sm[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) accm[u] = 0.f, mn[u] = inf, sm[u] = 0.f;
+    int rem_a = NK;
+    const float n_small_mask[4] = {d.n_small > 0 ? 1.f : 0.f, d.n_small > 1 ? 1.f : 0.f, d.n_small > 2 ? 1.f : 0.f,
+                                   d.n_small > 3 ? 1.f : 0.f};
+    int kt = 0, m = m0;
+    for (int t = 0; t < n_tiles; ++t) {
+        if (FLAT) {
+            if (t + 1 < n_tiles) load_flat(t + 1, zn, hn);
+        } else {
+            int kt_n = kt + 1, m_n = m;
+            if (kt_n == nkt) kt_n = 0, ++m_n;
+            if (t + 1 < n_tiles) load_tile(m_n, kt_n, zn, hn);
+        }
+        const int valid = FLAT ? min(32, rows_total - 32 * t) : 32;
+        const int bnd = FLAT ? min(rem_a, valid) : 32;
+        const bool split = FLAT && bnd < valid;       // (wave-uniform)
+        float mnb[NU], smb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) mnb[u] = inf, smb[u] = 0.f;
+        const bool k_ok = FLAT ? j < valid : 32 * kt + j < NK;
+        float hsum = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) hsum += n_small_mask[f] != 0.f ? hc[f] : 0.f;
+        const float nh = -hsum;
+        const float slot = k_ok ? (nh > NL_BIG ? NL_BIG : nh) : NL_BIG;       // (a NaN small factor stays a NaN)
+        float zv[EQ];
+#pragma unroll
+        for (int qq = 0; qq < NX; ++qq) tile[soff[qq]] = zc[qq];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) zv[q] = tile[j * (E + 1) + min(2 * q + h, E - 1)];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // Units u = (loc row lw, scale tile st) of this value tile, software-pipelined: the matrix instructions of unit
+        // u + 1 (and the A build that precedes them when it starts a new loc row) are issued in the same basic block as
+        // the log-sum-exp of unit u, whose vector work then runs beside them; B of the unit after that is fetched from
+        // the LDS table behind them (one unit ahead: the reads land during a whole log-sum-exp).
+        unsigned areg[NV];
+        auto build_a = [&](int lw) {
+#pragma unroll
+            for (int q = 0; q < EQ; ++q) {
+                const float df = zv[q] - mreg[lw][q];
+                float a = df * df;
+                if (q == EQ - 1) a = h == slot_h ? slot : a;
+                nl_split_a(a, areg[3 * q], areg[3 * q + 1], areg[3 * q + 2]);
+            }
+#pragma unroll
+            for (int v = 3 * EQ; v < NV; ++v) areg[v] = 0u;
+        };
+        auto chain = [&]() {
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {
+                const u32x4v av = {areg[4 * step], areg[4 * step + 1], areg[4 * step + 2], areg[4 * step + 3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, av),
+                                                              __builtin_bit_cast(bf16x8v, breg[step]), acc, 0, 0, 0);
+                // The first instruction of a chain has C = 0 and a destination of its own: under -amdgpu-mfma-vgpr-form
+                // hipcc (ROCm 7.2) lets that destination overlap a dead A or B operand (seen: v_mfma v[0:15], v[68:71],
+                // v[0:3], 0), which a multi-pass MFMA does not survive.  An empty asm that takes the result and both operands keeps
+                // them alive past it.
+                if (step == 0) asm volatile("" ::"v"(acc[0]), "v"(av), "v"(breg[0]));
+            }
+            return acc;
+        };
+        auto fetch_b = [&](int st) {                  // (one scale tile: B never leaves its registers)
+            if (NST > 1) {
+#pragma unroll
+                for (int step = 0; step < NSTEP; ++step) breg[step] = bt[(st * NSTEP + step) * 64 + lane];
+            }
+        };
+        // acc[r] = -log2(e) (log-prob + small) of row (r & 3) + 8 (r >> 2) + 4 h of the tile, normaliser apart
+        auto lse_plain = [&](int u, const f32x16 &acc) {
+            float tmin = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tmin = fminf(tmin, acc[r]);
+            const float mnew = fminf(mn[u], tmin);
+            const float mf = mnew == inf ? 0.f : mnew;
+            float ssum = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u]));
+            const f32x2v mf2 = {mf, mf};
+            f32x2v part = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2v a2 = {acc[r], acc[r + 1]};
+                const f32x2v d2 = mf2 - a2;
+                const f32x2v e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};
+                part += e2;
+            }
+            ssum += part[0] + part[1];
+            mn[u] = mnew, sm[u] = ssum;
+        };
+        auto lse_split = [&](int u, const f32x16 &acc) {
+            float ta = inf, tb = inf;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool isa = 8 * g + 4 * h < bnd;
+                const float t4 = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+                ta = isa ? fminf(ta, t4) : ta;
+                tb = isa ? tb : fminf(tb, t4);
+            }
+            const float mnew = fminf(mn[u], ta);
+            const float mfa = mnew == inf ? 0.f : mnew, mfb = tb == inf ? 0.f : tb;
+            float ssa = sm[u] * __builtin_amdgcn_exp2f(mfa - (mn[u] == inf ? mfa : mn[u])), ssb = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bool isa = 8 * g + 4 * h < bnd;
+                const float mfx = isa ? mfa : mfb;
+                float part = 0.f;
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) part += __builtin_amdgcn_exp2f(mfx - acc[r]);
+                ssa += isa ? part : 0.f;
+                ssb += isa ? 0.f : part;
+            }
+            mn[u] = mnew, sm[u] = ssa, mnb[u] = tb, smb[u] = ssb;
+        };
+        auto units = [&](auto lse) {
+            build_a(0);
+            f32x16 cur = chain();                     // (breg: scale tile 0, fetched behind the previous tile's last unit)
+            fetch_b(NST > 1 ? 1 : 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                f32x16 nxt = cur;
+                if (u + 1 < NU) {
+                    const int lw1 = (u + 1) / NST, st1 = (u + 1) - lw1 * NST;
+                    if (st1 == 0) build_a(lw1);
+                    nxt = chain();
+                    fetch_b((st1 + 1) % NST);
+                }
+                lse(u, cur);
+                cur = nxt;
+            }
+        };
+        if (split)
+            units(lse_split);
+        else
+            units(lse_plain);
+        if (FLAT) rem_a -= bnd;
+        if (FLAT ? rem_a == 0 : ++kt == nkt) {        // plate element done: join the two half-waves, add to the plate sum
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int lw = u / NST, st = u - lw * NST;
+                const float mn2 = __shfl_xor(mn[u], 32), sm2 = __shfl_xor(sm[u], 32);
+                const float mm = fminf(mn[u], mn2);
+                const float mf = mm == inf ? 0.f : mm;
+                const float tot = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u])) +
+                                  sm2 * __builtin_amdgcn_exp2f(mf - (mn2 == inf ? mf : mn2));
+                float lse_m = logf(tot + Num<float>::eps) - mm * NL_LN2 - lgn[st];
+                if (mm >= 1e29f || mm == -inf) lse_m = __builtin_nanf("");      // every row masked / -inf, or a +inf term
+                accm[u] += lse_m;
+                const int s = 32 * (sg * NST + st) + j;
+                if (d.lse && h == 0 && s < NS && l + lw < d.NL) d.lse[((int64_t)m * d.NL + l + lw) * NS + s] = lse_m;
+                mn[u] = mnb[u], sm[u] = smb[u];
+            }
+            kt = 0, ++m;
+            if (FLAT) rem_a = NK - (valid - bnd);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) zc[i] = zn[i];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) hc[f] = hn[f];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int lw = u / NST, st = u - lw * NST;
+        const int s = 32 * (sg * NST + st) + j;
+        if (h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.y * d.NL + l + lw) * NS + s] = accm[u];
+    }
+}
+
 }  // namespace alan
 
 using namespace alan;
@@ -492,7 +852,7 @@ bool env_stage_ok() {
 
 struct NLPlan {
     int eh = 0, nst = 1, nlw = 1, m_chunk = 1, n_chunks = 1;
-    bool rag = false;
+    bool rag = false, x3 = false;
     size_t part_bytes = 0;
     dim3 grid;
 };
@@ -519,7 +879,13 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     // the last scale tile as a 16-wide one: a single group of tiles whose last holds at most 16 rows (NS = 100: 4)
     static const int rag_knob = env_knob("ALAN_NLSE_RAG");                            // ablation knob: 0 = off
     p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16 && rag_knob != 0;
-    const int64_t gx = (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
+    // the bf16x3 kernel (default): contiguous value rows (its staged loads), the chunks added by a second launch
+    static const int f32_knob = env_knob("ALAN_NLSE_F32");                            // ablation knob: 1 = the f32 MFMA kernel
+    p.x3 = a.v_se == 1 && a.v_sk == a.E && !a.counters && f32_knob != 1 && env_stage_ok();
+    if (p.x3 && p.eh == 17 && p.nst == 4) p.nst = 2;                                  // (its B table: 13 KB per scale tile)
+    const int64_t nsg_x = (nst_total + p.nst - 1) / p.nst;
+    const int64_t gx = p.x3 ? nsg_x * ((((a.NL + p.nlw - 1) / p.nlw) + 3) / 4)       // waves of a workgroup share their scale tiles
+                            : (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
     int64_t target = 768;                                                    // workgroups (x 4 waves)
     static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
     if (blocks_knob != ENV_UNSET) target = std::max(1, blocks_knob);
@@ -591,13 +957,43 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
-    // flat row tiling (see the kernel): the plate elements' k rows as one run
+    // flat row tiling (see the kernels): the plate elements' k rows as one run
     static const int flat_knob = env_knob("ALAN_NLSE_FLAT");                          // ablation knob: 0 = off
     bool flat = stage && p.nlw == 1 && a->NK > 32 && (a->NK & 31) != 0 && (a->NK & 3) == 0 && a->v_sm == a->NK * a->E &&
                 flat_knob != 0;                   // (NK % 4: a lane's groups of four accumulator rows never straddle two elements)
     for (int f = 0; f < a->n_small; ++f)          // (32-bit lane offsets into a small factor, inside one chunk of the plate)
         flat = flat && a->small_sm[f] >= 0 && a->small_sk[f] >= 0 &&
                (int64_t)p.m_chunk * a->small_sm[f] + a->NK * a->small_sk[f] < (1ll << 31);
+    if (p.x3) {
+        auto launch_x3 = [&](auto kern, int eq, int nst) {
+            const int nstep = (3 * eq + 3) / 4;
+            const size_t lds_x = ((size_t)nst * nstep * 64 * 4 + (size_t)nst * 32 + 4 * 32 * 33) * sizeof(float);
+            if (lds_x > 64 * 1024 &&
+                hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x) != hipSuccess)
+                return ALAN_ERR_LAUNCH;
+            hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds_x, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
+            return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+        };
+#define X3_PICK(EQV)                                                                                                   \
+    case EQV:                                                                                                          \
+        rc = p.nst == 4   ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 4, 1, true>, EQV, 4)                           \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 4, 1, false>, EQV, 4))                         \
+             : p.nst == 2 ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 2, 1, true>, EQV, 2)                           \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 2, 1, false>, EQV, 2))                         \
+             : p.nlw == 2 ? launch_x3(normal_lse_x3_kernel<EQV, 1, 2, false>, EQV, 1)                                  \
+                          : (flat ? launch_x3(normal_lse_x3_kernel<EQV, 1, 1, true>, EQV, 1)                           \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 1, 1, false>, EQV, 1));                        \
+        break;
+        switch (p.eh) {
+            X3_PICK(4)
+            X3_PICK(8)
+            X3_PICK(10)
+            X3_PICK(12)
+            default:
+                X3_PICK(17)
+        }
+#undef X3_PICK
+    } else {
 #define NL_PICK(EHV, NSTV) (rag && NSTV > 1 ? (flat ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1), true>) \
                                                     : launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, (NSTV > 1)>)) \
                             : stage ? (flat ? launch(normal_lse_mfma_kernel<EHV, NSTV, true, 1, false, true>) \
@@ -619,6 +1015,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
 #undef NL_PICK
 #undef NL_PICK2
 #undef NL_CASE
+    }
     if (rc != ALAN_OK) return rc;
     if (d.counters) return ALAN_OK;                   // (the chunks were combined by the launch itself)
 
