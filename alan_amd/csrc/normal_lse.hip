@@ -532,128 +532,109 @@ __device__ __forceinline__ void nl_split_b(float x, unsigned &r1, unsigned &r2, 
     r3 = r1;                                                      // (h, m)
 }
 
-// EQ: events per lane half incl. the small-factor slot (2 EQ >= E + 1).  Waves of a workgroup share their group of
-// scale tiles (blockIdx.x = scale group + nsg * group of four loc-row groups), so the B table is the workgroup's.
-// The value tile is staged as in the f32 kernel (STAGE): the launcher takes this kernel only for contiguous rows.
+// Diagnostic build (make TIMELINE=1 -> tools/_build/libalan_timeline.so; tools/nlse_timeline.py): every wave stamps
+// s_memtime at the phases of its life and stores them, with s_memrealtime of its start and its hardware id, into a
+// buffer of the library's own that no other code reads.  In the default build no stamp executes.
+#ifdef ALAN_TIMELINE
+constexpr int NL_TL_SLOTS = 16, NL_TL_WAVES = 8192;
+__device__ unsigned long long nl_timeline[NL_TL_WAVES * NL_TL_SLOTS];
+#define NL_STAMP(i) (tl[i] = __builtin_amdgcn_s_memtime())
+#else
+#define NL_STAMP(i) ((void)0)
+#endif
+
+// Its kernel argument: 32-bit sizes and strides only, and what every wave would otherwise derive with integer divisions
+// (the round-3 timeline: 744 instructions, half of them scalar address arithmetic on 64-bit strides, before a wave's
+// first tile -- 2.3 of the 8 us a wave lives at K = 30).  Filled by the launcher, which takes this kernel only when
+// every offset fits 31 bits and no stride is negative.
+struct X3Desc {
+    const float *val, *loc, *scl;
+    float *part, *lse;
+    const float *small[4];
+    int32_t M, NK, NL, NS, E, n_sub, n_small, log_scale;   // n_sub: the plate in this many slices, four per workgroup
+    int32_t v_sm, l_sl, l_se, s_ss, s_se;
+    int32_t small_sm[4], small_sk[4];
+    int32_t nkt, nlg;                 // k tiles per plate element; groups of NLW loc rows
+    uint32_t rcp_e;                   // ceil(2^16 / E): floor(f / E) = (f * rcp_e) >> 16 for f < 2048
+};
+
+// EQ: events per lane half incl. the small-factor slot (2 EQ >= E + 1).  Grid: x = group of NST scale tiles, y = group
+// of NLW loc rows, z = group of four slices of the plate, one per wave: the waves of a workgroup share the B table and
+// the loc rows and add up their partial sums through LDS, so a launch leaves gridDim.z partial results per output (34
+// at K = 30 where the first build left 150) for the consumer to add.  Slice c = plate elements [c M / n_sub,
+// (c + 1) M / n_sub).  The value tile is staged as in the f32 kernel (STAGE): contiguous rows only.
 template <int EQ, int NST, int NLW, bool FLAT>
-__global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
+__global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const X3Desc d) {
     static_assert(!FLAT || NLW == 1, "flat row tiling: one loc row per wave");
     constexpr int NSTEP = (3 * EQ + 3) / 4, NV = 4 * NSTEP;
     extern __shared__ __align__(16) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (scalar: what depends on it alone stays on the scalar unit)
     const int j = lane & 31, h = lane >> 5;
-    const int NK = d.NK, E = d.E, NS = d.NS;
-    const int nkt = (NK + 31) >> 5, nsg = (((NS + 31) >> 5) + NST - 1) / NST;
-    const int nlg = (d.NL + NLW - 1) / NLW;
-    const int sg = blockIdx.x % nsg, lgp = (blockIdx.x / nsg) * 4 + wave;
-    const bool wave_on = lgp < nlg;
-    const int l = min(lgp, nlg - 1) * NLW;
+    const int NK = d.NK, E = d.E, NS = d.NS, nkt = d.nkt;
+    const int ES = E | 1;                                            // row stride of the staged value tile: odd, conflict-free
+    const int sg = blockIdx.x, l = blockIdx.y * NLW, sub = blockIdx.z * 4 + wave;
     const int slot_h = E > 2 * (EQ - 1) ? 1 : 0;                   // the small-factor slot: event pair EQ - 1, this half
     const float inf = __builtin_huge_valf();
-    // ---- LDS: B table | log-normalisers | the waves' value tiles
+#ifdef ALAN_TIMELINE
+    unsigned long long tl[NL_TL_SLOTS] = {};
+    const unsigned long long tl_real = __builtin_amdgcn_s_memrealtime();
+    NL_STAMP(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(NK), "s"(E), "s"(NS) : "memory");       // (the kernel arguments have arrived)
+    NL_STAMP(13);
+#endif
+    // ---- LDS: B table | partial log-normalisers | per wave: value tile [32][ES], loc rows [NLW][32]
     u32x4v *bt = reinterpret_cast<u32x4v *>(lds);
-    float *lgn_l = lds + NST * NSTEP * 64 * 4;
-    float *tile = lgn_l + NST * 32 + wave * (32 * 33);
-    {
-        unsigned *bw = reinterpret_cast<unsigned *>(lds);
-        for (int idx = tid; idx < NST * EQ * 64; idx += 256) {
-            const int ln = idx & 63, q = (idx >> 6) % EQ, st = (idx >> 6) / EQ;
-            const int jj = ln & 31, hh = ln >> 5, e = 2 * q + hh;
-            const int s = 32 * (sg * NST + st) + jj;
-            float b = 0.f;
-            if (s < NS && e < E) {
-                const float x = d.scl[(int64_t)s * d.s_ss + (int64_t)e * d.s_se];
-                b = (d.log_scale ? 0.5f * expf(-2.f * x) : 0.5f / (x * x)) * NL_LOG2E;
-            } else if (s < NS && q == EQ - 1 && hh == slot_h) {
-                b = NL_LOG2E;
-            }
-            unsigned r[3];
-            nl_split_b(b, r[0], r[1], r[2]);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int v = 3 * q + i;
-                bw[((st * NSTEP + (v >> 2)) * 64 + ln) * 4 + (v & 3)] = r[i];
-            }
-        }
-        for (int idx = tid; idx < NST * 64 * (NV - 3 * EQ); idx += 256) {      // the registers beyond 3 EQ: zero
-            const int ln = idx & 63, rest = idx >> 6, v = 3 * EQ + rest % (NV - 3 * EQ > 0 ? NV - 3 * EQ : 1);
-            const int st = rest / (NV - 3 * EQ > 0 ? NV - 3 * EQ : 1);
-            bw[((st * NSTEP + (v >> 2)) * 64 + ln) * 4 + (v & 3)] = 0u;
-        }
-        if (tid < NST * 32) {
-            const int s = 32 * (sg * NST) + tid;
-            float lg = 0.f;
-            if (s < NS)
-                for (int e = 0; e < E; ++e) {
-                    const float x = d.scl[(int64_t)s * d.s_ss + (int64_t)e * d.s_se];
-                    lg += d.log_scale ? x : logf(x);
-                }
-            lgn_l[tid] = lg + (float)E * 0.91893853320467274178f;
-        }
-        if (FLAT || (NK & 31))                        // rows beyond NK are never written: keep them finite
-            for (int i = lane; i < 32 * 33; i += 64) tile[i] = 0.f;
-    }
-    __syncthreads();
-    if (!wave_on) return;                             // (no barrier below)
-    float lgn[NST];
-#pragma unroll
-    for (int st = 0; st < NST; ++st) lgn[st] = lgn_l[st * 32 + j];
-    u32x4v breg[NSTEP];                               // B of the unit about to be multiplied (one scale tile: for good)
-#pragma unroll
-    for (int step = 0; step < NSTEP; ++step) breg[step] = bt[step * 64 + lane];
-    float mreg[NLW][EQ];
+    float *lgp_l = lds + NST * NSTEP * 64 * 4;
+    float *tile = lgp_l + NST * 4 * 64 + wave * (32 * 33 + NLW * 36);
+    float *locl = tile + 32 * 33;                                   // [NLW][36]: events 0 .. 2 EQ - 1 <= 33
+    // ---- everything the wave needs from memory is requested before anything waits.  The loc rows: one coalesced load
+    // per row, handed to the lanes through LDS (lane (j, h) wants events 2 q + h: ten reads at immediate offsets)
+    float lrow[NLW];
 #pragma unroll
     for (int lw = 0; lw < NLW; ++lw)
-#pragma unroll
-        for (int q = 0; q < EQ; ++q) {
-            const int e = 2 * q + h;
-            const float x = d.loc[(int64_t)min(l + lw, d.NL - 1) * d.l_sl + (int64_t)min(e, E - 1) * d.l_se];
-            mreg[lw][q] = e < E ? x : 0.f;
-        }
-    const int m0 = blockIdx.y * d.m_chunk, m1 = min(d.M, m0 + d.m_chunk);
+        lrow[lw] = d.loc[(uint32_t)(min(l + lw, d.NL - 1) * d.l_sl + min(lane, E - 1) * d.l_se)];
+    const int m0 = (int)((int64_t)min(sub, d.n_sub) * d.M / d.n_sub), m1 = (int)((int64_t)min(sub + 1, d.n_sub) * d.M / d.n_sub);
     const int rows_total = (m1 - m0) * NK;
     const int n_tiles = FLAT ? (rows_total + 31) >> 5 : (m1 - m0) * nkt;
-    // the value tile: this lane's share of the contiguous run of 32 E floats (floats lane + 64 q)
+    // the value tile: 32 rows of E floats are one contiguous run; lane i takes floats i, i + 64, ... of it (buffer loads:
+    // a scalar descriptor per tile, immediate offsets, floats beyond the run read as 0) and puts float f at row f / E
     constexpr int NX = EQ;
     uint32_t soff[NX];
-    {
-        const int r64 = 64 / E, c64 = 64 - r64 * E;
-        int row = lane / E, col = lane - row * E;
 #pragma unroll
-        for (int qq = 0; qq < NX; ++qq) {
-            soff[qq] = row < 32 ? row * (E + 1) + col : 32 * 33 - 1;
-            row += r64, col += c64;
-            if (col >= E) col -= E, ++row;
-        }
+    for (int qq = 0; qq < NX; ++qq) {
+        const uint32_t f = lane + 64 * qq, row = (f * d.rcp_e) >> 16;
+        soff[qq] = row < 32 ? f + row * (uint32_t)(ES - E) : 32 * 33 - 1;             // (beyond: a slot nobody reads)
     }
-    auto load_tile = [&](int m, int kt_, float (&x)[NX], float (&hs)[4]) {
-        const float *vp = d.val + (int64_t)m * d.v_sm + (int64_t)(32 * kt_) * d.v_sk;      // (uniform)
-        const int rows = min(32, NK - 32 * kt_);
-        const uint32_t lim = (uint32_t)(rows * E - 1);
+    const uint32_t lane4 = lane * 4;
+    auto load_run = [&](const float *vp, int rows, float (&x)[NX]) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vp, 0, rows * E * 4, 0x00020000);
 #pragma unroll
-        for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        for (int qq = 0; qq < NX; ++qq)
+            x[qq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + 256 * qq, 0, 0));
+    };
+    auto load_tile = [&](int m, int kt_, float (&x)[NX], float (&hs)[4]) {
+        load_run(d.val + (int64_t)m * d.v_sm + 32 * kt_ * E, min(32, NK - 32 * kt_), x);
         const uint32_t kk = (uint32_t)min(32 * kt_ + j, NK - 1);
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const float *sp = d.small[f] + (int64_t)m * d.small_sm[f];                       // (uniform)
+        for (int f = 0; f < 4; ++f) {                 // (the launcher points unused slots at valid memory, stride 0)
+            const float *sp = d.small[f] + (int64_t)m * d.small_sm[f];                       // (scalar)
             hs[f] = sp[kk * (uint32_t)d.small_sk[f]];
         }
         asm volatile("" ::: "memory");
     };
+    // FLAT: tile tt = rows 32 tt .. of the chunk's run; (pm, pk) = the plate element and k of the FIRST row of the tile
+    // being loaded (scalar), advanced by 32 rows per tile (NK > 32: at most one wrap; a lane's row wraps once more)
     int pm = m0, pk = 0;
     auto load_flat = [&](int tt, float (&x)[NX], float (&hs)[4]) {
-        const float *vp = d.val + (int64_t)m0 * d.v_sm + (int64_t)(32 * tt) * E;          // (uniform)
-        const int rows = min(32, rows_total - 32 * tt);
-        const uint32_t lim = (uint32_t)(rows * E - 1);
-#pragma unroll
-        for (int qq = 0; qq < NX; ++qq) x[qq] = vp[min((uint32_t)(lane + 64 * qq), lim)];
+        load_run(d.val + (int64_t)m0 * d.v_sm + 32 * tt * E, min(32, rows_total - 32 * tt), x);
         int lm = pm, lk = pk + j;
         if (lk >= NK) lk -= NK, ++lm;
         const bool in = lm < m1;
         const uint32_t mm = (uint32_t)((in ? lm : m1 - 1) - m0), kk = (uint32_t)(in ? lk : NK - 1);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            const float *sp = d.small[f] + (int64_t)m0 * d.small_sm[f];                      // (uniform)
+            const float *sp = d.small[f] + (int64_t)m0 * d.small_sm[f];                      // (scalar)
             hs[f] = sp[mm * (uint32_t)d.small_sm[f] + kk * (uint32_t)d.small_sk[f]];
         }
         pk += 32;
@@ -667,6 +648,86 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
         else
             load_tile(m0, 0, zc, hc);
     }
+    // ---- the workgroup's B table: thread (wave w, lane) takes the event pairs w, w + 4, ... of its lane's (scale row,
+    // half) in every scale tile; every load of a thread is issued before the first is used.  The log-normaliser
+    // sum_e log(scale[s, e]) is collected on the way as per-(wave, lane) partial sums, added up in a fixed order behind
+    // the barrier.  Branch-free and on the fast transcendental instructions (1 ulp): this is every wave's critical path.
+    {
+        unsigned *bw = reinterpret_cast<unsigned *>(lds);
+        constexpr int NQI = (EQ + 3) / 4;
+        float xs[NST][NQI];
+        const int joff = j * d.s_ss, hoff = h ? d.s_se : 0, last_s = (NS - 1) * d.s_ss, last_e = (E - 1) * d.s_se;
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int qi = 0; qi < NQI; ++qi) {
+                const int q = wave + 4 * qi;                                                           // (scalar)
+                xs[st][qi] = d.scl[(uint32_t)(min(joff + 32 * (sg * NST + st) * d.s_ss, last_s) + min(hoff + q * 2 * d.s_se, last_e))];
+            }
+#ifdef ALAN_TIMELINE
+        NL_STAMP(14);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NL_STAMP(15);
+#endif
+        // (the loc rows on their way to the lanes, zero beyond the last event)
+#pragma unroll
+        for (int lw = 0; lw < NLW; ++lw)
+            if (lane < 36) locl[lw * 36 + lane] = lane < E ? lrow[lw] : 0.f;
+        // (the value tile's rows beyond the run are written every tile: the buffer loads read them as 0)
+        const bool lsc = d.log_scale != 0;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const bool s_ok = 32 * (sg * NST + st) + j < NS;
+            float lgp = 0.f;
+#pragma unroll
+            for (int qi = 0; qi < NQI; ++qi) {
+                const int q = wave + 4 * qi;                                                           // (scalar)
+                if (4 * qi + 3 < EQ || q < EQ) {
+                    const float x = xs[st][qi];
+                    const bool ev = s_ok && 2 * q + h < E;
+                    // log2(e) / (2 sigma^2); from log(sigma) = x: 2^(-2 log2(e) x) log2(e) / 2
+                    const float w = lsc ? __builtin_amdgcn_exp2f(-2.f * NL_LOG2E * x) * (0.5f * NL_LOG2E)
+                                        : (0.5f * NL_LOG2E) * __builtin_amdgcn_rcpf(x * x);
+                    const float bval = ev ? w : (s_ok && q == EQ - 1 && h == slot_h) ? NL_LOG2E : 0.f;
+                    lgp += ev ? (lsc ? x : __builtin_amdgcn_logf(x) * NL_LN2) : 0.f;
+                    unsigned r[3];
+                    nl_split_b(bval, r[0], r[1], r[2]);
+                    // registers 3 q .. 3 q + 2 of the lane's operand: dword (3 q + i) & 3 of step (3 q + i) >> 2
+                    const int v0 = 3 * q;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        bw[(st * NSTEP * 64 + lane) * 4 + ((v0 + i) >> 2) * 256 + ((v0 + i) & 3)] = r[i];
+                }
+            }
+            lgp_l[(st * 4 + wave) * 64 + lane] = lgp;
+        }
+        if (NV > 3 * EQ) {                            // the registers beyond 3 EQ: zero
+#pragma unroll
+            for (int st = 0; st < NST; ++st)
+#pragma unroll
+                for (int v = 3 * EQ; v < NV; ++v)
+                    if ((st * (NV - 3 * EQ) + v) % 4 == wave) bw[((st * NSTEP + (v >> 2)) * 64 + lane) * 4 + (v & 3)] = 0u;
+        }
+    }
+    NL_STAMP(1);
+    __syncthreads();
+    NL_STAMP(2);
+    float lgn[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        float lg = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) lg += lgp_l[(st * 4 + w) * 64 + j] + lgp_l[(st * 4 + w) * 64 + 32 + j];
+        lgn[st] = lg + (float)E * 0.91893853320467274178f;
+    }
+    u32x4v breg[NSTEP];                               // B of the unit about to be multiplied (one scale tile: for good)
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) breg[step] = bt[step * 64 + lane];
+    float mreg[NLW][EQ];
+#pragma unroll
+    for (int lw = 0; lw < NLW; ++lw)
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) mreg[lw][q] = locl[lw * 36 + h + 2 * q];
     constexpr int NU = NLW * NST;
     float accm[NU], mn[NU], sm[NU];
 #pragma unroll
@@ -675,6 +736,7 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
     const float n_small_mask[4] = {d.n_small > 0 ? 1.f : 0.f, d.n_small > 1 ? 1.f : 0.f, d.n_small > 2 ? 1.f : 0.f,
                                    d.n_small > 3 ? 1.f : 0.f};
     int kt = 0, m = m0;
+    NL_STAMP(3);
     for (int t = 0; t < n_tiles; ++t) {
         if (FLAT) {
             if (t + 1 < n_tiles) load_flat(t + 1, zn, hn);
@@ -693,6 +755,12 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
         float hsum = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) hsum += n_small_mask[f] != 0.f ? hc[f] : 0.f;
+#ifdef ALAN_TIMELINE
+        if (t == 0) {                                 // (the first tile's loads have landed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            NL_STAMP(4);
+        }
+#endif
         const float nh = -hsum;
         const float slot = k_ok ? (nh > NL_BIG ? NL_BIG : nh) : NL_BIG;       // (a NaN small factor stays a NaN)
         float zv[EQ];
@@ -701,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < EQ; ++q) zv[q] = tile[j * (E + 1) + min(2 * q + h, E - 1)];
+        for (int q = 0; q < EQ; ++q) zv[q] = tile[j * ES + min(2 * q + h, E - 1)];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // Units u = (loc row lw, scale tile st) of this value tile, software-pipelined: the matrix instructions of unit
@@ -806,17 +874,27 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
             units(lse_split);
         else
             units(lse_plain);
+#ifdef ALAN_TIMELINE
+        if (t == 0) NL_STAMP(5);
+        if (t == n_tiles - 1) NL_STAMP(6);
+#endif
         if (FLAT) rem_a -= bnd;
         if (FLAT ? rem_a == 0 : ++kt == nkt) {        // plate element done: join the two half-waves, add to the plate sum
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int lw = u / NST, st = u - lw * NST;
-                const float mn2 = __shfl_xor(mn[u], 32), sm2 = __shfl_xor(sm[u], 32);
-                const float mm = fminf(mn[u], mn2);
+                // (v_permlane32_swap with both operands the same register: every lane gets the lower half-wave's value
+                // and the upper half-wave's -- one vector instruction where a shuffle is an LDS round trip)
+                const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mn[u]), __float_as_uint(mn[u]), false, false);
+                const auto ps = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm[u]), __float_as_uint(sm[u]), false, false);
+                const float mn1 = __uint_as_float(pm[0]), mn2 = __uint_as_float(pm[1]);
+                const float sm1 = __uint_as_float(ps[0]), sm2 = __uint_as_float(ps[1]);
+                const float mm = fminf(mn1, mn2);
                 const float mf = mm == inf ? 0.f : mm;
-                const float tot = sm[u] * __builtin_amdgcn_exp2f(mf - (mn[u] == inf ? mf : mn[u])) +
+                const float tot = sm1 * __builtin_amdgcn_exp2f(mf - (mn1 == inf ? mf : mn1)) +
                                   sm2 * __builtin_amdgcn_exp2f(mf - (mn2 == inf ? mf : mn2));
-                float lse_m = logf(tot + Num<float>::eps) - mm * NL_LN2 - lgn[st];
+                // log(tot + eps) + max, in base 2 until the end (tot + eps >= eps: v_log_f32 needs no denormal care)
+                float lse_m = (__builtin_amdgcn_logf(tot + Num<float>::eps) - mm) * NL_LN2 - lgn[st];
                 if (mm >= 1e29f || mm == -inf) lse_m = __builtin_nanf("");      // every row masked / -inf, or a +inf term
                 accm[u] += lse_m;
                 const int s = 32 * (sg * NST + st) + j;
@@ -831,12 +909,37 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const NLDesc d) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
+    // ---- the four slices of the workgroup, added in slice order by wave 0 (both half-waves hold the sums: lanes 0-31 write)
+    float *red = lgp_l + NST * 4 * 64;                // (the waves' tile areas: every wave is past its last tile read)
+    __syncthreads();
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int lw = u / NST, st = u - lw * NST;
-        const int s = 32 * (sg * NST + st) + j;
-        if (h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.y * d.NL + l + lw) * NS + s] = accm[u];
+    for (int u = 0; u < NU; ++u)
+        if (h == 0) red[(wave * NU + u) * 32 + j] = accm[u];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int lw = u / NST, st = u - lw * NST;
+            const int s = 32 * (sg * NST + st) + j;
+            const float tot = ((red[u * 32 + j] + red[(NU + u) * 32 + j]) + red[(2 * NU + u) * 32 + j]) + red[(3 * NU + u) * 32 + j];
+            if (h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.z * d.NL + l + lw) * NS + s] = tot;
+        }
     }
+#ifdef ALAN_TIMELINE
+    NL_STAMP(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NL_STAMP(8);
+    const int wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    if (lane == 0 && wid < NL_TL_WAVES) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl[9] = tl_real, tl[10] = ((unsigned long long)xcc << 32) | hwid, tl[11] = (unsigned long long)n_tiles * NU;
+        tl[12] = __builtin_amdgcn_s_memrealtime();
+        for (int i = 0; i < NL_TL_SLOTS; ++i) nl_timeline[wid * NL_TL_SLOTS + i] = tl[i];
+    }
+#endif
 }
 
 }  // namespace alan
@@ -881,11 +984,33 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16 && rag_knob != 0;
     // the bf16x3 kernel (default): contiguous value rows (its staged loads), the chunks added by a second launch
     static const int f32_knob = env_knob("ALAN_NLSE_F32");                            // ablation knob: 1 = the f32 MFMA kernel
-    p.x3 = a.v_se == 1 && a.v_sk == a.E && !a.counters && f32_knob != 1 && env_stage_ok();
+    p.x3 = a.v_se == 1 && a.v_sk == a.E && !a.counters && f32_knob != 1 && env_stage_ok() &&
+           a.l_sl >= 0 && a.l_se >= 0 && a.s_ss >= 0 && a.s_se >= 0 &&                   // (its 32-bit lane offsets)
+           a.NL * a.l_sl + a.E * a.l_se < (1ll << 31) && a.NS * a.s_ss + a.E * a.s_se < (1ll << 31) &&
+           a.v_sm >= 0 && a.v_sm < (1ll << 31) && a.NL <= 65535;
+    for (int f = 0; f < a.n_small; ++f)
+        p.x3 = p.x3 && a.small_sm[f] >= 0 && a.small_sk[f] >= 0 && a.small_sm[f] < (1ll << 31) && a.small_sk[f] < (1ll << 31) &&
+               a.NK * a.small_sk[f] < (1ll << 31);
     if (p.x3 && p.eh == 17 && p.nst == 4) p.nst = 2;                                  // (its B table: 13 KB per scale tile)
     const int64_t nsg_x = (nst_total + p.nst - 1) / p.nst;
-    const int64_t gx = p.x3 ? nsg_x * ((((a.NL + p.nlw - 1) / p.nlw) + 3) / 4)       // waves of a workgroup share their scale tiles
-                            : (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
+    if (p.x3) {
+        // One workgroup per (scale-tile group, loc-row group, four slices of the plate).  The kernel holds two workgroups
+        // per CU (its registers: two waves per SIMD): a workgroup that has to wait for a free slot starts a whole wave
+        // lifetime late (the round-3 timeline at K = 30: 385 of 2,250 waves entered 9 us after the rest), and one wave
+        // per SIMD has nothing to hide its own latencies behind (668 ns per unit against 2 x 244) -- so as many slices
+        // as give at most 512 workgroups.
+        const int64_t per = nsg_x * ((a.NL + p.nlw - 1) / p.nlw);
+        static const int blocks_knob_x = env_knob("ALAN_NLSE_BLOCKS");                // tuning knob: target workgroups
+        const int64_t target_x = blocks_knob_x != ENV_UNSET ? std::max(1, blocks_knob_x) : 512;
+        int64_t ncg = std::max<int64_t>(1, target_x / std::max<int64_t>(1, per));
+        ncg = std::min<int64_t>(ncg, std::min<int64_t>(65535, (a.M + 3) / 4));
+        p.n_chunks = (int)ncg;
+        p.m_chunk = (int)((a.M + 4 * ncg - 1) / (4 * ncg));       // (the largest slice: what flat row tiling's offset check needs)
+        p.part_bytes = (size_t)p.n_chunks * a.NL * a.NS * sizeof(float);
+        p.grid = dim3((uint32_t)nsg_x, (uint32_t)((a.NL + p.nlw - 1) / p.nlw), (uint32_t)ncg);
+        return ALAN_OK;
+    }
+    const int64_t gx = (((a.NL + p.nlw - 1) / p.nlw) * nsg + 3) / 4;
     int64_t target = 768;                                                    // workgroups (x 4 waves)
     static const int blocks_knob = env_knob("ALAN_NLSE_BLOCKS");                      // tuning knob
     if (blocks_knob != ENV_UNSET) target = std::max(1, blocks_knob);
@@ -897,10 +1022,11 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
         // them -- ceil(workgroups / 256) x (plate elements per workgroup).  Among the chunkings that keep the chip
         // between ~2 and ~4 waves per SIMD take the cheapest, fewer workgroups on a tie (K=100, M=75: 475 workgroups of
         // 4 users instead of 625 of 3 -- 98 against 112 us; M=300 and the K=30 launch keep their measured optimum).
+        const int64_t lo = 450, hi = 1100;
         int64_t best = -1, best_cost = 0;
         for (int64_t mc = a.M; mc >= 1; --mc) {
             const int64_t chunks = (a.M + mc - 1) / mc, wgs = gx * chunks;
-            if (chunks > 65535 || wgs < 450 || wgs > 1100) continue;
+            if (chunks > 65535 || wgs < lo || wgs > hi) continue;
             const int64_t cost = ((wgs + 255) / 256) * mc;
             if (best < 0 || cost < best_cost) best = mc, best_cost = cost;
         }
@@ -913,6 +1039,15 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
 }
 
 }  // namespace
+
+#ifdef ALAN_TIMELINE
+extern "C" int alan_nlse_timeline_read(unsigned long long *host_out, int n_waves) {
+    if (n_waves > NL_TL_WAVES) n_waves = NL_TL_WAVES;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nl_timeline), sizeof(unsigned long long) * n_waves * NL_TL_SLOTS) == hipSuccess
+               ? NL_TL_SLOTS : -1;
+}
+#endif
 
 extern "C" size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *a) {
     if (!a) return 0;
@@ -965,24 +1100,34 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         flat = flat && a->small_sm[f] >= 0 && a->small_sk[f] >= 0 &&
                (int64_t)p.m_chunk * a->small_sm[f] + a->NK * a->small_sk[f] < (1ll << 31);
     if (p.x3) {
-        auto launch_x3 = [&](auto kern, int eq, int nst) {
+        X3Desc x;
+        std::memset(&x, 0, sizeof(x));
+        x.val = d.val, x.loc = d.loc, x.scl = d.scl, x.part = d.part, x.lse = d.lse;
+        x.M = d.M, x.NK = d.NK, x.NL = d.NL, x.NS = d.NS, x.E = d.E, x.n_sub = 4 * p.n_chunks, x.n_small = d.n_small;
+        x.log_scale = d.log_scale;
+        x.v_sm = (int32_t)d.v_sm, x.l_sl = (int32_t)d.l_sl, x.l_se = (int32_t)d.l_se, x.s_ss = (int32_t)d.s_ss, x.s_se = (int32_t)d.s_se;
+        for (int f = 0; f < 4; ++f) x.small[f] = d.small[f], x.small_sm[f] = (int32_t)d.small_sm[f], x.small_sk[f] = (int32_t)d.small_sk[f];
+        x.nkt = (d.NK + 31) / 32, x.nlg = (d.NL + p.nlw - 1) / p.nlw;
+        x.rcp_e = (65536u + (uint32_t)d.E - 1) / (uint32_t)d.E;
+        const dim3 grid3 = p.grid;
+        auto launch_x3 = [&](auto kern, int eq, int nst, int nlw) {
             const int nstep = (3 * eq + 3) / 4;
-            const size_t lds_x = ((size_t)nst * nstep * 64 * 4 + (size_t)nst * 32 + 4 * 32 * 33) * sizeof(float);
+            const size_t lds_x = ((size_t)nst * nstep * 64 * 4 + (size_t)nst * 4 * 64 + 4 * (32 * 33 + nlw * 36)) * sizeof(float);
             if (lds_x > 64 * 1024 &&
                 hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x) != hipSuccess)
                 return ALAN_ERR_LAUNCH;
-            hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds_x, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
+            hipExtLaunchKernelGGL(kern, grid3, dim3(256), lds_x, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, x);
             return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
         };
 #define X3_PICK(EQV)                                                                                                   \
     case EQV:                                                                                                          \
-        rc = p.nst == 4   ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 4, 1, true>, EQV, 4)                           \
-                                  : launch_x3(normal_lse_x3_kernel<EQV, 4, 1, false>, EQV, 4))                         \
-             : p.nst == 2 ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 2, 1, true>, EQV, 2)                           \
-                                  : launch_x3(normal_lse_x3_kernel<EQV, 2, 1, false>, EQV, 2))                         \
-             : p.nlw == 2 ? launch_x3(normal_lse_x3_kernel<EQV, 1, 2, false>, EQV, 1)                                  \
-                          : (flat ? launch_x3(normal_lse_x3_kernel<EQV, 1, 1, true>, EQV, 1)                           \
-                                  : launch_x3(normal_lse_x3_kernel<EQV, 1, 1, false>, EQV, 1));                        \
+        rc = p.nst == 4   ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 4, 1, true>, EQV, 4, 1)                        \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 4, 1, false>, EQV, 4, 1))                      \
+             : p.nst == 2 ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 2, 1, true>, EQV, 2, 1)                        \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 2, 1, false>, EQV, 2, 1))                      \
+             : p.nlw == 2 ? launch_x3(normal_lse_x3_kernel<EQV, 1, 2, false>, EQV, 1, 2)                               \
+                          : (flat ? launch_x3(normal_lse_x3_kernel<EQV, 1, 1, true>, EQV, 1, 1)                        \
+                                  : launch_x3(normal_lse_x3_kernel<EQV, 1, 1, false>, EQV, 1, 1));                     \
         break;
         switch (p.eh) {
             X3_PICK(4)

@@ -30,7 +30,8 @@ _STATUS = {
     -4: "kernel launch failed",
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libalan_mi355.so")
+# (ALAN_AMD_LIB: another build of the same library, e.g. the diagnostic one of `make TIMELINE=1`)
+LIB_PATH = os.environ.get("ALAN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libalan_mi355.so")
 
 
 class NativeError(RuntimeError):
