@@ -853,6 +853,7 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const X3Desc d) {
             }
             mn[u] = mnew, sm[u] = ssa, mnb[u] = tb, smb[u] = ssb;
         };
+        constexpr int VPG = (64 + NSTEP - 1) / NSTEP;    // vector instructions per matrix instruction (a log-sum-exp has ~64)
         auto units = [&](auto lse) {
             build_a(0);
             f32x16 cur = chain();                     // (breg: scale tile 0, fetched behind the previous tile's last unit)
@@ -867,6 +868,17 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const X3Desc d) {
                     fetch_b((st1 + 1) % NST);
                 }
                 lse(u, cur);
+                // the order the scheduler is asked for: one matrix instruction, the B read that refills its operand, then a
+                // share of the log-sum-exp's vector work -- left alone it emits the eight dependent MFMAs back to back
+                // (the wave then stalls through all of them) and the vector instructions behind
+                if (u + 1 < NU) {
+#pragma unroll
+                    for (int i = 0; i < NSTEP; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (NST > 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+                    }
+                }
                 cur = nxt;
             }
         };
@@ -1056,6 +1068,13 @@ extern "C" size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *
     return (p.part_bytes + 255) & ~(size_t)255;
 }
 
+extern "C" int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *a) {
+    if (!a || a->counters) return 0;
+    NLPlan p;
+    if (plan_nl(*a, p) != ALAN_OK) return 0;
+    return p.n_chunks;
+}
+
 extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace, size_t workspace_bytes,
                                void *stream_) {
     if (!a) return ALAN_ERR_BAD_DESC;
@@ -1063,13 +1082,15 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     NLPlan p;
     int rc = plan_nl(*a, p);
     if (rc != ALAN_OK) return rc;
-    if (!workspace || workspace_bytes < p.part_bytes) return ALAN_ERR_WORKSPACE;
+    const bool keep = a->keep_partials != 0;
+    if (keep && a->counters) return ALAN_ERR_BAD_DESC;
+    if (!keep && (!workspace || workspace_bytes < p.part_bytes)) return ALAN_ERR_WORKSPACE;
     NLDesc d;
     std::memset(&d, 0, sizeof(d));
     d.val = (const float *)a->value;
     d.loc = (const float *)a->loc;
     d.scl = (const float *)a->scale;
-    d.part = (float *)workspace;
+    d.part = keep ? (float *)a->out : (float *)workspace;
     d.lse = (float *)a->lse_out;
     d.M = (int)a->M, d.NK = (int)a->NK, d.NL = (int)a->NL, d.NS = (int)a->NS, d.E = (int)a->E;
     d.m_chunk = p.m_chunk, d.n_small = a->n_small, d.log_scale = a->log_scale;
@@ -1162,7 +1183,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
 #undef NL_CASE
     }
     if (rc != ALAN_OK) return rc;
-    if (d.counters) return ALAN_OK;                   // (the chunks were combined by the launch itself)
+    if (d.counters || keep) return ALAN_OK;           // (the chunks were combined by the launch itself / are the caller's to add)
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
     Canon s2;

@@ -47,6 +47,7 @@ struct SmallDesc {
     float *const *ring_slots;      // result ring (alan_reduce_desc_t.ring_*); ring_n = 0: off
     int32_t *ring_counter;
     int32_t ring_n;
+    int32_t presum_n, presum_stride;   // role ALAN_PRESUM: factor 0 is the sum of presum_n slices presum_stride apart (0: off)
 };
 
 // Kernel argument of the linear-logits Bernoulli producer (ALAN_MODE_BERNOULLI_LINEAR): fp32, 32-bit offsets, at
@@ -128,8 +129,9 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
 int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype, hipStream_t stream,
                  const EvPair &ev = EvPair());
 // Small-problem variant of the group kernel; ALAN_ERR_UNSUPPORTED when the problem does not fit SmallDesc.
+// (presum_n > 1: factor 0 is a sum of slices, role ALAN_PRESUM; dry: build and check only, launch nothing)
 int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
-                     hipStream_t stream, const EvPair &ev);
+                     hipStream_t stream, const EvPair &ev, int64_t presum_n = 0, int64_t presum_stride = 0, bool dry = false);
 // The two halves of it, for alan_reduce_batch: fill a SmallDesc; launch up to SMALL_MULTI of them as one kernel.
 int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype, SmallDesc &sd);
 // `lin`: the LinDesc of the (at most one) problem whose mode[] entry is ALAN_MODE_BERNOULLI_LINEAR; its sd[] slot is unused

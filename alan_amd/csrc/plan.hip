@@ -643,8 +643,70 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     return ALAN_OK;
 }
 
+// Role ALAN_PRESUM: the descriptor with that dim taken out (size 1) and the factor that carries it moved to slot 0,
+// which the small kernel then reads as the sum of `n` slices `stride` apart.  -1: no such dim; -2: malformed.
+static int strip_presum(const alan_reduce_desc_t &d, alan_reduce_desc_t &d2, int64_t &n, int64_t &stride) {
+    int p = -1;
+    for (int i = 0; i < d.ndim && i < MAXD; ++i)
+        if (d.role[i] == ALAN_PRESUM) {
+            if (p >= 0) return -2;
+            p = i;
+        }
+    if (p < 0) return -1;
+    if (d.mode != ALAN_MODE_LSE && d.mode != ALAN_MODE_SUM) return -2;
+    if (d.n_factors < 1 || d.n_factors > MAXF) return -2;
+    int f = -1;
+    for (int i = 0; i < d.n_factors; ++i)
+        if (d.factor[i].stride[p] != 0) {
+            if (f >= 0) return -2;
+            f = i;
+        }
+    if (d.out.stride[p] != 0 || d.weight.data || d.lse_out.data) return -2;
+    for (int i = 0; i < d.ndim; ++i)
+        if (d.role[i] == ALAN_PLATE) return -2;
+    d2 = d;
+    n = d.size[p];
+    stride = f >= 0 ? d.factor[f].stride[p] : 0;
+    d2.size[p] = 1;
+    d2.role[p] = ALAN_KEEP;
+    if (f > 0) std::swap(d2.factor[0], d2.factor[f]);
+    if (f < 0 || n < 1) return -2;          // (a dim nobody carries cannot be summed: its size would multiply the result)
+    return p;
+}
+
+// The single small-kernel launch a PRESUM problem is (or ALAN_ERR_UNSUPPORTED); dry: check only.
+static int run_presum(const alan_reduce_desc_t &d2, int64_t n, int64_t stride, hipStream_t stream, bool dry) {
+    uint32_t keep, red, plate;
+    int rc = classify(d2, keep, red, plate);
+    if (rc != ALAN_OK) return rc;
+    if (d2.out.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    EvPair ev;
+    ev.start = (hipEvent_t)d2.ev_start;
+    ev.stop = (hipEvent_t)d2.ev_stop;
+    if (d2.ring_n) {
+        if (d2.ring_n < 0 || !d2.ring_slots || !d2.ring_counter) return ALAN_ERR_BAD_DESC;
+        ev.ring_slots = d2.ring_slots, ev.ring_counter = d2.ring_counter, ev.ring_n = d2.ring_n;
+    }
+    const int mode = (d2.mode == ALAN_MODE_LSE && red == 0) ? ALAN_MODE_SUM : d2.mode;     // (log-sum-exp over no dims)
+    Canon c;
+    rc = canonicalise(d2, keep, red, d2.out, c);
+    if (rc != ALAN_OK) return rc;
+    GroupDesc gd;
+    GroupLaunch gl;
+    rc = plan_group(c, d2.out.dtype, d2.add_const, gd, gl, 1.f);
+    if (rc != ALAN_OK) return rc;
+    return try_launch_small(c, gd, gl, mode, d2.out.dtype, stream, ev, n, stride, dry);
+}
+
 extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
     if (!d) return ALAN_ERR_BAD_DESC;
+    {
+        alan_reduce_desc_t d2;
+        int64_t n, stride;
+        const int p = strip_presum(*d, d2, n, stride);
+        if (p == -2) return ALAN_ERR_BAD_DESC;
+        if (p >= 0) return run_presum(d2, n, stride, nullptr, true);
+    }
     if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
         LinDesc ld;
         GroupLaunch gl;
@@ -688,6 +750,13 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
 extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t workspace_bytes, void *stream_) {
     if (!d) return ALAN_ERR_BAD_DESC;
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        alan_reduce_desc_t d2;
+        int64_t n, stride;
+        const int p = strip_presum(*d, d2, n, stride);
+        if (p == -2) return ALAN_ERR_BAD_DESC;
+        if (p >= 0) return run_presum(d2, n, stride, stream, false);
+    }
     if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
         LinDesc ld;
         GroupLaunch gl;
@@ -793,5 +862,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 6; }
+extern "C" int alan_abi_version(void) { return 7; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

@@ -257,6 +257,7 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
     for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
         T val[UNR][MAXF];
         T wv[UNR];
+        int32_t off0[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const uint32_t ru = r0 + (uint32_t)u * G;
@@ -277,6 +278,26 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
 #pragma unroll
             for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];
             wv[u] = MODE == ALAN_MODE_WEXPSUM ? d.w[woff] : 0.f;
+            off0[u] = off[0];
+        }
+        if ((MODE == ALAN_MODE_LSE || MODE == ALAN_MODE_SUM) && d.presum_n > 1) {
+            // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, sixteen loads per element in
+            // flight, added in slice order
+            constexpr int PF = 16;                    // (a lone workgroup: its time is rounds of load latency)
+            for (int32_t c0 = 1; c0 < d.presum_n; c0 += PF) {
+                T part[UNR][PF];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) {
+                        const int32_t c = c0 + i < d.presum_n ? c0 + i : 0;
+                        part[u][i] = d.f[0][off0[u] + c * d.presum_stride];
+                    }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) val[u][0] += c0 + i < d.presum_n ? part[u][i] : T(0);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
@@ -389,7 +410,7 @@ int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStrea
 //   l = sum_t ( a_t  |  sum_e a_t[e] * b_t[e] ),     out = out_scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const
 // (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
 // TorchDimDist.py:127-162).  A lane group per output element, lanes along the summed dims; each lane walks the dot
-// products of its element serially, four products in flight.
+// products of its element serially, all loads of up to 32 events in flight.
 template <bool BLOCK>
 __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const uint32_t block_id) {
     const uint32_t G = BLOCK ? 256u : (1u << logG);
@@ -452,17 +473,24 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             }
             const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
             const int len = d.len[tm], as = d.ads[tm], bs = d.bds[tm];
+            // (every load of up to 32 events issued before the first product: the kernel is a chain of load latencies --
+            // four products in flight made movielens' 18-event dot five round trips; clamped loads, masked products)
             float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            int e = 0;
-            for (; e + 4 <= len; e += 4) {
-                const float a0 = pa[(e + 0) * as], a1 = pa[(e + 1) * as], a2 = pa[(e + 2) * as], a3 = pa[(e + 3) * as];
-                const float b0 = pb[(e + 0) * bs], b1 = pb[(e + 1) * bs], b2 = pb[(e + 2) * bs], b3 = pb[(e + 3) * bs];
-                acc0 = fmaf(a0, b0, acc0);
-                acc1 = fmaf(a1, b1, acc1);
-                acc2 = fmaf(a2, b2, acc2);
-                acc3 = fmaf(a3, b3, acc3);
+            for (int e0 = 0; e0 < len; e0 += 32) {
+                float av[32], bv[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const int e = min(e0 + i, len - 1);
+                    av[i] = pa[e * as], bv[i] = pb[e * bs];
+                }
+#pragma unroll
+                for (int i = 0; i < 32; i += 4) {
+                    acc0 = fmaf(e0 + i + 0 < len ? av[i + 0] : 0.f, bv[i + 0], acc0);
+                    acc1 = fmaf(e0 + i + 1 < len ? av[i + 1] : 0.f, bv[i + 1], acc1);
+                    acc2 = fmaf(e0 + i + 2 < len ? av[i + 2] : 0.f, bv[i + 2], acc2);
+                    acc3 = fmaf(e0 + i + 3 < len ? av[i + 3] : 0.f, bv[i + 3], acc3);
+                }
             }
-            for (; e < len; ++e) acc0 = fmaf(pa[e * as], pb[e * bs], acc0);
             xl += (acc0 + acc1) + (acc2 + acc3);
         }
         const float ls = (xl < 0.f ? xl : 0.f) - log1pf(expf(xl < 0.f ? xl : -xl));
@@ -647,10 +675,17 @@ int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype
 }
 
 int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl, int mode, int compute_dtype,
-                     hipStream_t stream, const EvPair &ev) {
+                     hipStream_t stream, const EvPair &ev, int64_t presum_n, int64_t presum_stride, bool dry) {
     SmallDesc sd;
     const int rc = build_small(c, gd, mode, compute_dtype, sd);
     if (rc != ALAN_OK) return rc;
+    if (presum_n > 1) {
+        if (mode != ALAN_MODE_LSE && mode != ALAN_MODE_SUM) return ALAN_ERR_UNSUPPORTED;
+        const int64_t st = presum_stride < 0 ? -presum_stride : presum_stride;
+        if (presum_n > (1 << 16) || st * presum_n >= (1ll << 30)) return ALAN_ERR_UNSUPPORTED;      // (int32 offsets)
+        sd.presum_n = (int32_t)presum_n, sd.presum_stride = (int32_t)presum_stride;
+    }
+    if (dry) return (ev.ring_n && (gd.n_out != 1 || gl.grid != 1)) ? ALAN_ERR_UNSUPPORTED : ALAN_OK;
     if (ev.ring_n) {
         if (gd.n_out != 1 || gl.grid != 1) return ALAN_ERR_UNSUPPORTED;
         sd.ring_slots = (float *const *)ev.ring_slots;

@@ -273,6 +273,41 @@ class LazyNormalPT(PT):
         return self
 
 
+class PartialSumPT(PT):
+    """A plate step's result left as the per-slice partial sums of its launch, ``parts`` = [slices, *dims] (the fused
+    plate step with keep_partials): ``.x`` adds them up the first time anyone asks (one SUM launch, what the library's
+    own second stage would have been), but the contraction that consumes the factor can take ``parts`` itself and add
+    the slices on load (engine.contract, role PRESUM) -- one launch fewer per evaluation.  Gradient-free only."""
+    __slots__ = ("parts", "_val")
+
+    def __init__(self, parts, dims):
+        self.parts = parts
+        self._val = None
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+
+    @property
+    def x(self):
+        if self._val is None:
+            from . import engine as E
+            self._val = E.sum_slices(self.parts)
+        return self._val
+
+    @property
+    def materialised(self):
+        return self._val is not None
+
+    @property
+    def n_pos(self):
+        return 0
+
+    def size_of(self, dim_id):
+        return self.parts.shape[1 + self.ids.index(dim_id)]
+
+    def detach(self):
+        return self
+
+
 class LinearPT(PT):
     """The value of a model lambda that is a sum of arguments and dot products of arguments (movielens' logits
     ``lambda z, x: z @ x``; bus_breakdown's ``alpha + phi @ bus_company_name + psi @ run_type``), not evaluated yet:

@@ -15,6 +15,7 @@ import math
 import torch as t
 
 from . import native as N
+from .dims import Dim
 
 
 # --------------------------------------------------------------------------- descriptor building
@@ -151,10 +152,33 @@ def _result_dtype(tensors):
 
 
 # --------------------------------------------------------------------------- autograd function
-def _reduce_forward(spec, tensors, need_grad, ring=None):
+def sum_slices(parts):
+    """[slices, ...] -> the sum over the leading dim, as one SUM launch (dims.PartialSumPT.x)."""
+    N.flush()
+    toks = tuple(range(parts.ndim))
+    out, _ = _reduce_factors([(parts, toks)], plate=(0,))
+    return out
+
+
+def _reduce_forward(spec, tensors, need_grad, ring=None, presum=()):
     """The launch behind _Reduce.forward.  Returns (out, out_dims, lse or None, sizes).  ``ring``: a ResultRing the
-    value may be delivered through (then ``out`` is the ring's placeholder)."""
+    value may be delivered through (then ``out`` is the ring's placeholder).  ``presum``: dims carried by one factor
+    each -- the slices of a dims.PartialSumPT -- that are summed as that factor is loaded (role PRESUM); where the
+    library declines, the factor is summed by a launch of its own first."""
     dimlists, reduce, plate, add_const = spec
+    if presum:
+        assert not need_grad and len(presum) == 1
+        mode = N.MODE_LSE if reduce else N.MODE_SUM
+        res = None if plate else _reduce_presum(mode, tensors, dimlists, reduce, add_const, ring, presum[0])
+        if res is not None:
+            return res
+        tensors, dimlists = list(tensors), list(dimlists)
+        for i, d in enumerate(dimlists):
+            if presum[0] in d:
+                k = d.index(presum[0])
+                x = tensors[i].movedim(k, 0) if k else tensors[i]
+                tensors[i], dimlists[i] = sum_slices(x), tuple(dd for dd in d if dd != presum[0])
+        spec = (tuple(dimlists), reduce, plate, add_const)
     factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
     sizes = _space(factors)
     for d in (*reduce, *plate):
@@ -186,6 +210,28 @@ def _reduce_forward(spec, tensors, need_grad, ring=None):
         roles = {d: (N.REDUCE if d in plate else N.KEEP) for d in sizes}
         _launch(N.MODE_SUM, factors, sizes, roles, out, out_dims, add_const=add_const)
     return out, out_dims, lse, sizes
+
+
+def _reduce_presum(mode, tensors, dimlists, reduce, add_const, ring, pdim):
+    """One launch that adds the slices of the factor carrying ``pdim`` as it loads it.  None: the library declines."""
+    factors = [(x.detach(), d) for x, d in zip(tensors, dimlists)]
+    sizes = _space(factors)
+    keep = [d for d in sizes if d not in reduce and d != pdim]
+    dtype = _result_dtype(list(tensors))
+    device = tensors[0].device
+    if dtype != t.float32:
+        return None
+    out_dims = _out_order(factors, keep, sizes)
+    roles = {d: (N.PRESUM if d == pdim else N.REDUCE if d in reduce else N.KEEP) for d in sizes}
+    if ring is not None and not ring.declined and reduce and not out_dims and ring.device == device:
+        if _launch(mode, factors, sizes, roles, ring.placeholder, out_dims, add_const=add_const, ring=ring):
+            ring.taken += 1
+            return ring.placeholder, out_dims, None, sizes
+        ring.declined = True
+    out = t.empty([sizes[d] for d in out_dims], dtype=dtype, device=device)
+    if not _launch(mode, factors, sizes, roles, out, out_dims, add_const=add_const):
+        return None
+    return out, out_dims, None, sizes
 
 
 class _Reduce(t.autograd.Function):
@@ -316,9 +362,14 @@ def reduce_factors(factors, reduce=(), plate=(), add_const=0.0):
     return out, tok.keys(dims)
 
 
-def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0, ring=None):
+def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0, ring=None, presum=()):
     factors = [(x, tuple(d)) for x, d in factors]
     reduce, plate = tuple(reduce), tuple(plate)
+    if presum:
+        assert not (t.is_grad_enabled() and any(x.requires_grad for x, _ in factors)), "partial sums: gradient-free only"
+        spec = (tuple(d for _, d in factors), reduce, plate, float(add_const))
+        out, out_dims, _, _ = _reduce_forward(spec, [x for x, _ in factors], False, ring, tuple(presum))
+        return out, tuple(out_dims)
     if add_const != 0.0 and any(x.requires_grad for x, _ in factors) and reduce and not plate:
         # keep the saved log-sum-exp free of the constant: apply it outside
         out, dims = _reduce_factors(factors, reduce, plate, 0.0)
@@ -428,12 +479,22 @@ def _normal_lse_desc(a, log_scale, d=None):
     return d
 
 
-def _normal_lse_forward(a, log_scale, want_lse):
-    """One alan_normal_lse launch.  -> (out [NL, NS], lse [M, NL, NS] or None), or None when the library declines."""
+def _normal_lse_forward(a, log_scale, want_lse, partials=False):
+    """One alan_normal_lse launch.  -> (out [NL, NS], lse [M, NL, NS] or None), or None when the library declines.
+    ``partials``: out is [slices, NL, NS], the launch's partial sums left for the consumer to add (keep_partials)."""
     d = _normal_lse_desc(a, log_scale)
     device = a["xv"].device
-    out = t.empty(d.NL, d.NS, dtype=t.float32, device=device)
-    d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
+    n_parts = 0
+    if partials and not N.COMBINE_IN_LAUNCH:
+        import ctypes as C
+        d.out = d.value                                  # (planning only: any non-null pointer)
+        n_parts = int(N.lib().alan_normal_lse_n_partials(C.byref(d)))
+    if n_parts > 1:
+        out = t.empty(n_parts, d.NL, d.NS, dtype=t.float32, device=device)
+        d.out, d.o_sl, d.o_ss, d.add_const, d.keep_partials = out.data_ptr(), d.NS, 1, 0.0, 1
+    else:
+        out = t.empty(d.NL, d.NS, dtype=t.float32, device=device)
+        d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
     lse = t.empty(d.M, d.NL, d.NS, dtype=t.float32, device=device) if want_lse else None
     d.lse_out = lse.data_ptr() if want_lse else None
     if not N.run_normal_lse(d, device):
@@ -511,12 +572,13 @@ class _NormalLse(t.autograd.Function):
         return (None, *grads, *out_small)
 
 
-def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
+def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False, partials=False):
     """out[l, s] = sum_plate LSE_K( log N(value[plate,K,:]; loc[l,:], scale[s,:]) + sum small[plate,K] ) in one
     launch, the [plate, l, s, K] factor never materialised (alan_normal_lse).  value = (tensor, (two dims: the plate
     and K, any order)); loc / scale = (tensor, (one dim,)); smalls = [(tensor, dims within {plate, K})].
     Differentiable in every argument (alan_normal_lse_backward).  Returns (out, (loc dim, scale dim)) or None when
-    the library declines."""
+    the library declines.  ``partials`` (gradient-free calls only): out may be [slices, l, s] -- the launch's per-slice
+    partial sums, for a consumer that adds them on load (dims.PartialSumPT)."""
     N.flush()          # consumers read what queued producer launches write (native.deferring)
     a = _normal_lse_args(value, loc, scale, smalls, plate, K)
     if a is None:
@@ -537,7 +599,7 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False):
                 bool(log_scale))
         out = _NormalLse.apply(spec, value[0], loc[0], scale[0], *[x for x, _ in smalls])
         return out, (a["dl"], a["ds"])
-    res = _normal_lse_forward(a, log_scale, False)
+    res = _normal_lse_forward(a, log_scale, False, partials)       # (partials: out may come back [slices, l, s])
     if res is None:
         return None
     return res[0], (a["dl"], a["ds"])
@@ -624,6 +686,16 @@ def bernoulli_linear_logprob(value, terms, out_dims, affine=(1.0, 0.0)):
     ok = _launch(N.MODE_BERNOULLI_LINEAR, factors, sizes, roles, out, odims, out_scale=float(affine[0]),
                  add_const=float(affine[1]), scales=scales)
     return out if ok else None
+
+
+PRESUM_DIMS = {}         # slices -> the Dim that stands for "slice of a partial sum" (kept alive: contract() knows them by identity)
+
+
+def presum_dim(n):
+    d = PRESUM_DIMS.get(n)
+    if d is None:
+        d = PRESUM_DIMS[n] = Dim("partial_sum_slices", n)
+    return d
 
 
 # --------------------------------------------------------------------------- elimination planner
@@ -713,7 +785,9 @@ def contract(factors, Ks, plate=(), final=False):
             raise Exception(f"dim {k} to sum is not on any factor")
     Ks = tok.many(Ks)
     plate = tok.many(plate)
-    steps = plan_elimination([d for _, d in factors], sizes, Ks)
+    # (the slice dim of a partial-sum factor, dims.PartialSumPT: invisible to the planner, summed as its step loads it)
+    presum = {tok(d) for d in PRESUM_DIMS.values() if d in tok}
+    steps = plan_elimination([tuple(dd for dd in d if dd not in presum) for _, d in factors], sizes, Ks)
     if not steps:
         steps = [(tuple(range(len(factors))), ())] if (plate or len(factors) > 1) else []
     pool = list(factors)
@@ -723,7 +797,8 @@ def contract(factors, Ks, plate=(), final=False):
         group = [pool[i] for i in ids]
         record.append(([(x, tok.keys(d)) for x, d in group], tok.keys(now)))
         out, dims = _reduce_factors(group, reduce=now, plate=plate if last else (),
-                                    ring=_RING[0] if (final and last) else None)
+                                    ring=_RING[0] if (final and last) else None,
+                                    presum=tuple(p for p in presum if any(p in d for _, d in group)))
         pool.append((out, dims))
     if not steps:
         return factors[0][0], tok.keys(factors[0][1]), record

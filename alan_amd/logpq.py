@@ -20,7 +20,7 @@ import torch as t
 import torch.utils.checkpoint
 
 from . import engine as E
-from .dims import PT, ExpPT, LazyNormalPT, pt_add, pt_align
+from .dims import PT, ExpPT, LazyNormalPT, PartialSumPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
 from .dist import TorchDimDist
@@ -98,8 +98,11 @@ def _fused_plate_step(lps, Ks, plate):
             return None
         smalls.append((lp.x, lp.dims))
     res = E.normal_lse((z.value.x, z.value.dims), (z.loc.x, z.loc.dims), (z.scale.x, z.scale.dims), smalls, pl, K,
-                       log_scale=z.log_scale)
-    return None if res is None else PT(*res)
+                       log_scale=z.log_scale, partials=PARTIAL_PLATE_SUMS)
+    if res is None:
+        return None
+    out, dims = res
+    return PartialSumPT(out, dims) if out.ndim == len(dims) + 1 else PT(out, dims)
 
 
 def _chain_of_terms(lps, Ks, core):
@@ -152,6 +155,11 @@ def _chain_of_terms(lps, Ks, core):
     return PT(vec if batch else vec[0], (*batch, core[1]))
 
 
+PARTIAL_PLATE_SUMS = True
+"""The fused plate step of a gradient-free evaluation leaves its per-slice partial sums for the parent's contraction to
+add as it loads them (engine.contract, role PRESUM) instead of adding them in a launch of its own."""
+
+
 def _contract(lps, Ks, plate=(), final=False):
     fused = _fused_plate_step(lps, Ks, plate)
     if fused is not None:
@@ -159,7 +167,14 @@ def _contract(lps, Ks, plate=(), final=False):
     for lp in lps:
         # "There shouldn't be any non-torchdim dimensions" (reduce_Ks.py:13-14)
         assert lp.n_pos == 0, "log-prob factors must have no positional dims"
-    out, dims, _ = E.contract([(lp.x, lp.dims) for lp in lps], tuple(Ks), plate=tuple(plate), final=final)
+    facs, part = [], None
+    for lp in lps:
+        if isinstance(lp, PartialSumPT) and not lp.materialised and part is None:
+            part = lp                                  # (one per contraction; a second one is summed the usual way)
+            facs.append((lp.parts, (E.presum_dim(lp.parts.shape[0]), *lp.dims)))
+        else:
+            facs.append((lp.x, lp.dims))
+    out, dims, _ = E.contract(facs, tuple(Ks), plate=tuple(plate), final=final)
     return PT(out, dims)
 
 

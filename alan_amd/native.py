@@ -15,7 +15,7 @@ MAX_DIMS = 8
 MAX_FACTORS = 6
 
 F32, F64 = 0, 1
-KEEP, REDUCE, PLATE, DOT = 0, 1, 2, 3
+KEEP, REDUCE, PLATE, DOT, PRESUM = 0, 1, 2, 3, 4
 MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSCALE = 0, 1, 2, 3, 4, 5
 MODE_PRODUCER_GRAD = 6
 MODE_BERNOULLI_LINEAR = 7
@@ -86,7 +86,7 @@ class NormalLseDesc(C.Structure):
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
                 ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64),
                 ("lse_out", C.c_void_p), ("add_const", C.c_double), ("counters", C.c_void_p), ("n_counters", C.c_int64),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("keep_partials", C.c_int32)]
 
 
 class NormalLseBackwardDesc(C.Structure):
@@ -125,6 +125,8 @@ def lib():
         L.alan_normal_lse.argtypes = [C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_workspace_bytes.restype = C.c_size_t
         L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
+        L.alan_normal_lse_n_partials.restype = C.c_int64
+        L.alan_normal_lse_n_partials.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_normal_lse_backward.restype = C.c_int
         L.alan_normal_lse_backward.argtypes = [C.POINTER(NormalLseBackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_backward_workspace_bytes.restype = C.c_size_t
@@ -172,6 +174,7 @@ def lib():
 
 EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
+           "alan_normal_lse_n_partials",
            "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
@@ -287,11 +290,13 @@ def flush():
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     """Enqueue one alan_reduce call.  False only for a call the library may decline -- one with a result ring
-    (desc.ring_n), or of mode BERNOULLI_LINEAR -- when it does: nothing was enqueued, the caller takes its other route."""
+    (desc.ring_n), of mode BERNOULLI_LINEAR, or with a PRESUM dim -- when it does: nothing was enqueued, the caller takes
+    its other route."""
     L = lib()
-    if desc.mode == MODE_BERNOULLI_LINEAR and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
+    presum = any(desc.role[i] == PRESUM for i in range(desc.ndim))
+    if (desc.mode == MODE_BERNOULLI_LINEAR or presum) and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
         return False
-    if (DEFER_SMALL_LAUNCHES and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
+    if (DEFER_SMALL_LAUNCHES and not presum and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and not desc.ring_n
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
             and (not _Q.pending or _Q.pending[0][1] == device)):
@@ -356,7 +361,7 @@ def run_normal_lse(desc, device):
     """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
     L = lib()
     flush()
-    if COMBINE_IN_LAUNCH and desc.NL * ((desc.NS + 31) // 32) <= N_COUNTERS:
+    if COMBINE_IN_LAUNCH and not desc.keep_partials and desc.NL * ((desc.NS + 31) // 32) <= N_COUNTERS:
         c = arrival_counters(device)
         if c is not None:
             desc.counters, desc.n_counters = c.data_ptr(), N_COUNTERS
@@ -365,8 +370,8 @@ def run_normal_lse(desc, device):
         return False
     if _TIMER[0] is not None:
         _TIMER[0].attach(desc, 0, mode=MODE_FUSED_FWD, flops=2.0 * desc.M * desc.NK * desc.NL * desc.NS * (desc.E + 1))
-    ws = t.empty(nbytes, dtype=t.uint8, device=device)
-    rc = L.alan_normal_lse(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
+    ws = None if desc.keep_partials else t.empty(nbytes, dtype=t.uint8, device=device)     # (the partials ARE the output)
+    rc = L.alan_normal_lse(C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, current_stream(device))
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse")

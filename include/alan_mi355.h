@@ -54,7 +54,13 @@ typedef enum {
     ALAN_KEEP = 0,    /* survives into the output */
     ALAN_REDUCE = 1,  /* reduced by the mode's operator (log-sum-exp / sum / weighted exp-sum) */
     ALAN_PLATE = 2,   /* ALAN_MODE_LSE only: summed AFTER the log-sum-exp (logpq.py:149) */
-    ALAN_DOT = 3      /* ALAN_MODE_BERNOULLI_LINEAR only: an event dim the logits are contracted over */
+    ALAN_DOT = 3,     /* ALAN_MODE_BERNOULLI_LINEAR only: an event dim the logits are contracted over */
+    ALAN_PRESUM = 4   /* ALAN_MODE_LSE / ALAN_MODE_SUM only: a dim carried by exactly ONE factor (zero stride in every
+                         other tensor), summed BEFORE that factor enters the sum of factors -- the per-slice partial
+                         results alan_normal_lse leaves with keep_partials (logpq.py:149: the plate sum, finished by the
+                         launch that consumes it instead of by a launch of its own).  At most one such dim; no
+                         ALAN_PLATE dim beside it.  ALAN_ERR_UNSUPPORTED (alan_reduce_check says so beforehand) unless
+                         the problem takes the small single-launch kernel: the caller then sums the factor first */
 } alan_role_t;
 
 typedef enum {
@@ -189,8 +195,15 @@ typedef struct {
     void *ev_start, *ev_stop;                          /* optional hipEvent_t pair (NULL = off) recorded immediately
                                                           before / after the MFMA kernel of the call (forward, or the
                                                           backward when the descriptor sits in a backward desc) */
+    int32_t keep_partials;                             /* != 0: no second launch -- out receives the launch's partial
+                                                          sums, [alan_normal_lse_n_partials(desc), NL, NS] fp32
+                                                          contiguous (o_sl, o_ss, add_const not used), for a consumer
+                                                          that adds them itself (alan_reduce, role ALAN_PRESUM) */
 } alan_normal_lse_desc_t;
 size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
+/* How many partial results per output a keep_partials call leaves (0: the library declines the shape, or would add
+ * them up inside the launch: then keep_partials must not be set). */
+int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of alan_normal_lse with respect to EVERY input, in one pass that recomputes the log-prob tiles on the matrix

@@ -23,6 +23,15 @@ def oracle_launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_o
     if len(factors) > N.MAX_FACTORS:
         raise N.NativeError(f"alan_amd: {len(factors)} factors in one contraction step (max {N.MAX_FACTORS})")
     dtype = out.dtype
+    # role PRESUM (the slices of a partial plate sum, logpq.py:149 finished by the consumer): summed within the one
+    # factor that carries the dim, before the factors are added
+    presum = [d for d in space if roles[d] == getattr(N, "PRESUM", 4)]
+    if presum:
+        assert len(presum) == 1 and sum(presum[0] in dims for _, dims in factors) == 1
+        factors = [(f.sum(list(dims).index(presum[0])), tuple(d for d in dims if d != presum[0])) if presum[0] in dims
+                   else (f, dims) for f, dims in factors]
+        sizes = {d: n for d, n in sizes.items() if d != presum[0]}
+        space = tuple(sizes)
     x = 0
     for i, (f, dims) in enumerate(factors):
         s = 1.0 if scales is None else scales[i]

@@ -672,3 +672,21 @@ def test_reparameterisation_nodes_on_other_model_shapes(build, monkeypatch):
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
         t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
+
+
+def test_partial_sum_factor_is_added_by_the_contraction_that_consumes_it(oracle_backend):
+    """engine.contract with a factor left as per-slice partial sums (dims.PartialSumPT -> role PRESUM): the slices are
+    summed inside that one factor before the factors are added -- equal to contracting the summed factor."""
+    from alan_amd import engine as E
+    from alan_amd.dims import Dim
+    g = t.Generator().manual_seed(3)
+    ka, kb = Dim("Ka", 4), Dim("Kb", 5)
+    parts = t.randn(7, 4, 5, generator=g)
+    a, b = t.randn(4, generator=g), t.randn(5, generator=g)
+    want, _, _ = E.contract([(parts.sum(0), (ka, kb)), (a, (ka,)), (b, (kb,))], (ka, kb))
+    got, dims, _ = E.contract([(parts, (E.presum_dim(7), ka, kb)), (a, (ka,)), (b, (kb,))], (ka, kb))
+    assert dims == () and t.allclose(got, want, rtol=1e-6, atol=1e-6)
+    # one K only: the other survives, the slice dim does not
+    want1, d1, _ = E.contract([(parts.sum(0), (ka, kb)), (a, (ka,))], (ka,))
+    got1, d2, _ = E.contract([(parts, (E.presum_dim(7), ka, kb)), (a, (ka,))], (ka,))
+    assert len(d2) == 1 and d2[0] is kb and t.allclose(got1, want1, rtol=1e-6, atol=1e-6)

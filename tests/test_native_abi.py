@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 6
+    assert L.alan_abi_version() == 7
     assert L.alan_build_target() == b"gfx950"
 
 
@@ -48,7 +48,7 @@ def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
 def test_fused_plate_step_struct_layout_and_rejections():
     """alan_normal_lse_desc_t / alan_normal_lse_backward_desc_t as the header lays them out (natural alignment), and
     malformed descriptors refused before any GPU work."""
-    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 2 * 8
+    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 2 * 8 + 8   # (keep_partials + padding)
     assert ctypes.sizeof(N.NormalLseDesc) == fwd
     assert ctypes.sizeof(N.NormalLseBackwardDesc) == fwd + 8 + 8 + 2 * 8 + 4 * 8
     L = N.lib()
