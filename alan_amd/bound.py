@@ -253,18 +253,12 @@ class Problem(nn.Module):
         return self._device_tensor.device
 
     # ---- what a captured evaluation reads (Sample.elbo_nograd's automatic HIP-graph replay) -------------------------
-    def _apply(self, fn, *args, **kwargs):
-        # .to() / .double() / .cuda() re-create the buffers: forget the cached tensor list
-        self.__dict__.pop("_tensor_list", None)
-        return super()._apply(fn, *args, **kwargs)
-
     def memory_fingerprint(self):
-        """Addresses (and sizes) of every parameter and buffer of the problem: a captured evaluation stays valid for
-        as long as these do not change (in-place updates -- optimiser steps, load_state_dict -- keep them)."""
-        ts = self.__dict__.get("_tensor_list")
-        if ts is None:
-            ts = self.__dict__["_tensor_list"] = [*self.parameters(), *self.buffers()]
-        return tuple((x.data_ptr(), x.numel()) for x in ts)
+        """Addresses (and sizes) of every parameter and buffer of the problem, walked afresh on every call: a captured
+        evaluation stays valid for as long as these do not change (in-place updates -- optimiser steps, load_state_dict
+        -- keep them; a sub-module's .to() / .double(), load_state_dict(assign=True) or a replaced Parameter do not, and
+        a cached tensor list would have kept the old tensors alive and their addresses unchanged)."""
+        return tuple((x.data_ptr(), x.numel()) for x in (*self.parameters(), *self.buffers()))
 
     def check_device(self):
         if not (self.device == self.P.device and self.device == self.Q.device):

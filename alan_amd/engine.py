@@ -107,6 +107,24 @@ class ResultRing:
 _RING = [None]          # set by sample._GraphedELBO around warm-up + capture of one evaluation
 
 
+class TooLargeForMergedSplit(Exception):
+    """A tensor the engine was about to allocate exceeds split.MERGE_MAX_BYTES while a Split plate is being evaluated
+    as one merged slice: the plate falls back to the reference's per-chunk loop (logpq.logPQ_plate)."""
+
+
+_ALLOC_LIMIT = [None]   # bytes; set by logpq.logPQ_plate around a merged Split evaluation
+
+
+def _empty(shape, dtype, device):
+    """torch.empty for the engine's factor-sized outputs, under the merged-Split memory bound."""
+    lim = _ALLOC_LIMIT[0]
+    if lim is not None:
+        n = math.prod(shape) * (8 if dtype == t.float64 else 4)
+        if n > lim:
+            raise TooLargeForMergedSplit(f"{n} bytes")
+    return t.empty(shape, dtype=dtype, device=device)
+
+
 def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=None, add_const=0.0,
             scales=None, out_scale=1.0, ring=None):
     space = list(sizes)
@@ -196,13 +214,13 @@ def _reduce_forward(spec, tensors, need_grad, ring=None, presum=()):
             ring.taken += 1
             return ring.placeholder, out_dims, None, sizes
         ring.declined = True
-    out = t.empty([sizes[d] for d in out_dims], dtype=dtype, device=device)
+    out = _empty([sizes[d] for d in out_dims], dtype, device)
     lse = None
     if reduce:
         roles = {d: (N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP) for d in sizes}
         if plate and need_grad:
             lse_dims = _out_order(factors, keep + list(plate), sizes)
-            lse = (t.empty([sizes[d] for d in lse_dims], dtype=dtype, device=device), lse_dims)
+            lse = (_empty([sizes[d] for d in lse_dims], dtype, device), lse_dims)
         _launch(N.MODE_LSE, factors, sizes, roles, out, out_dims, lse_out=lse, add_const=add_const)
         if lse is None:
             lse = (out, out_dims)   # add_const is 0 whenever a backward is needed through here
@@ -400,7 +418,7 @@ def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None):
     odims = tok.many(out_dims)
     roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
     dtype = _result_dtype([x for x, _ in factors])
-    out = t.empty([sizes[d] for d in odims], dtype=dtype, device=args[0][0].device)
+    out = _empty([sizes[d] for d in odims], dtype, args[0][0].device)
     _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]),
             scales=scales)
     return out
@@ -495,7 +513,7 @@ def _normal_lse_forward(a, log_scale, want_lse, partials=False):
     else:
         out = t.empty(d.NL, d.NS, dtype=t.float32, device=device)
         d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
-    lse = t.empty(d.M, d.NL, d.NS, dtype=t.float32, device=device) if want_lse else None
+    lse = _empty([d.M, d.NL, d.NS], t.float32, device) if want_lse else None
     d.lse_out = lse.data_ptr() if want_lse else None
     if not N.run_normal_lse(d, device):
         return None
@@ -682,7 +700,7 @@ def bernoulli_linear_logprob(value, terms, out_dims, affine=(1.0, 0.0)):
         return None
     odims = tok.many(out_dims)
     roles = {d: (N.DOT if d in dots else N.KEEP if d in odims else N.REDUCE) for d in sizes}
-    out = t.empty([sizes[d] for d in odims], dtype=t.float32, device=value[0].device)
+    out = _empty([sizes[d] for d in odims], t.float32, value[0].device)
     ok = _launch(N.MODE_BERNOULLI_LINEAR, factors, sizes, roles, out, odims, out_scale=float(affine[0]),
                  add_const=float(affine[1]), scales=scales)
     return out if ok else None

@@ -30,10 +30,25 @@ from .timeseries import Timeseries
 
 def logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
                 all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
-                dimcache=None):
+                dimcache=None, merge=None):
+    split_here = name is not None and name == getattr(computation_strategy, "platename", None)
+    if split_here and merge is None and computation_strategy.merging():
+        # the merged slice under Split's memory bound: any engine allocation beyond split.MERGE_MAX_BYTES sends the plate
+        # back to the reference's per-chunk loop
+        from . import split as S
+        saved, E._ALLOC_LIMIT[0] = E._ALLOC_LIMIT[0], S.MERGE_MAX_BYTES
+        try:
+            return logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scope, active_platedims,
+                               all_platedims, groupvarname2Kdim, varname2groupvarname, sampler, computation_strategy,
+                               dimcache, merge=True)
+        except E.TooLargeForMergedSplit:
+            merge = False
+        finally:
+            E._ALLOC_LIMIT[0] = saved
+    kw = {"merge": merge} if split_here else {}
     chunks = computation_strategy.split_args(
         name=name, sample=sample, inputs_params=inputs_params, extra_log_factors=extra_log_factors,
-        data=data, all_platedims=all_platedims)
+        data=data, all_platedims=all_platedims, **kw)
     run = _logPQ_plate if computation_strategy is no_checkpoint else _logPQ_plate_checkpointed
 
     sharded = len(chunks) > 1 and getattr(computation_strategy, "sharded", lambda: False)()

@@ -388,7 +388,8 @@ def run_normal_lse_backward(desc, device):
         return False
     if _TIMER[0] is not None:
         f = desc.fwd
-        _TIMER[0].attach(f, 0, mode=MODE_FUSED_BWD, flops=2.0 * f.M * f.NK * f.NL * f.NS * (f.E + 1))
+        # per 32 x 32 tile: D recomputed over the E + 1 event slots, then the V and U products (32 rows summed each)
+        _TIMER[0].attach(f, 0, mode=MODE_FUSED_BWD, flops=2.0 * f.M * f.NK * f.NL * f.NS * ((f.E + 1) + 32 + 32))
     ws = t.empty(nbytes, dtype=t.uint8, device=device)
     rc = L.alan_normal_lse_backward(C.byref(desc), ws.data_ptr(), nbytes, current_stream(device))
     if rc == ERR_UNSUPPORTED:

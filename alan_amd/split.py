@@ -62,6 +62,13 @@ of the union, so the result is the same up to fp re-association, and on 288 GB o
 plate (a 1.2 GB factor, when it is materialised at all) fits many times over.  ``Split(..., merge=False)`` -- or this
 switch -- restores the reference's per-chunk loop."""
 
+MERGE_MAX_BYTES = 16 << 30
+"""Split's memory-bounding contract (Split.py, computation_strategy.rst) under merging: where the merged slice would make
+the engine allocate any single tensor larger than this -- a materialised [plate, K, K, K] factor that the fused plate
+step did not take, its saved log-sum-exp for a backward -- the plate is evaluated chunk by chunk as the reference does
+(logpq.logPQ_plate catches engine.TooLargeForMergedSplit and starts the plate over).  The fused route never
+materialises the factor, so the BASELINE configurations all merge."""
+
 
 def rank_block(n_chunks, world, rank):
     """Contiguous block of chunk indices for ``rank`` (balanced to within one chunk)."""
@@ -85,19 +92,23 @@ class Split:
     def merging(self):
         return MERGE_CHUNKS if self.merge is None else bool(self.merge)
 
-    def split_args(self, name, sample, inputs_params, extra_log_factors, data, all_platedims):
+    def split_args(self, name, sample, inputs_params, extra_log_factors, data, all_platedims, merge=None):
+        """``merge``: override of ``merging()`` for this call (False: the plate did not fit as one merged slice)."""
         whole = dict(sample=sample, inputs_params=inputs_params, extra_log_factors=extra_log_factors,
                      data=data, all_platedims=all_platedims)
         if name != self.platename:
             return [whole]
         orig = all_platedims[self.platename]
         sizes = chunk_sizes(orig.size, self.split_size)
-        if self.merging():
+        self.last_sizes = list(sizes)
+        if self.merging() if merge is None else merge:
             if not self.sharded():
+                self.last_sizes = [orig.size]
                 return [whole]                       # one rank: its block is the whole plate
             world = dist.get_world_size(self.group)
             self._check_ranks(len(sizes), world)
             sizes = [sum(sizes[i] for i in rank_block(len(sizes), world, r)) for r in range(world)]
+            self.last_sizes = list(sizes)
         new_dims = [Dim(f"{self.platename}_split_{i}", s) for i, s in enumerate(sizes)]
 
         def split_tree(tree):
@@ -144,6 +155,9 @@ class Split:
                             "split_size so that every rank gets at least one chunk")
 
 
+ALL_REDUCES = [0]        # [how many so far, then (group, numel, dtype) of the latest ones, newest last]
+
+
 class _AllReduceSum(t.autograd.Function):
     """Sum of per-rank partial log-marginals.
 
@@ -158,6 +172,9 @@ class _AllReduceSum(t.autograd.Function):
         ctx.world = dist.get_world_size(group)
         x = x.contiguous().clone()
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+        ALL_REDUCES.append((group, x.numel(), x.dtype))      # (what a captured sharded evaluation's graph may hold)
+        ALL_REDUCES[0] += 1
+        del ALL_REDUCES[1:-64]
         return x
 
     @staticmethod

@@ -211,15 +211,16 @@ def pmc_traffic(name, key):
 
 
 def fused_pmc_traffic(K, backward=False):
-    """The same for the fused plate step at the S-ML sizes profiles/r2_fused_kernel_pmc.json covers (M=300, K=30 / 100)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r2_fused_kernel_pmc.json")))["kernels"]
-        want = 4 * M_USERS * K ** 3
-        for name, rec in d.items():
-            if ("bwd" in name) == backward and rec["factor_bytes_never_materialised"] == want:
-                return rec["traffic_bytes"]
-    except Exception:
-        pass
+    """The same for the fused plate step at the S-ML sizes profiles/r3_fused_kernel_pmc.json covers (M=300, K=30 / 100)."""
+    for name in ("r3_fused_kernel_pmc.json", "r2_fused_kernel_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            want = 4 * M_USERS * K ** 3
+            for kname, rec in d.items():
+                if ("bwd" in kname) == backward and rec["factor_bytes_never_materialised"] == want:
+                    return rec["traffic_bytes"]
+        except Exception:
+            pass
     return None
 
 
@@ -239,9 +240,23 @@ def fused_roofline(records, tag, what, traffic=None):
     return {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
             "traffic": traffic, "kernel": what, "us_per_launch": ms * 1e3, "algorithmic_flops": flops,
             "launches_timed": len(ts),
-            "note": "fp32 MFMA results are consumed by the vector unit (one exp per element) and on gfx950 the two do not "
-                    "overlap: tools/mfma_f32_probe.hip measures 0.60 of peak for a bare chain-of-10-MFMAs + "
-                    "log-sum-exp tile loop -- the practical ceiling of this kernel"}
+            "note": "algorithmic fp32 flops of the tile GEMM against the chip's fp32 matrix peak (what an fp32 "
+                    "implementation has).  The forward executes each fp32 product as six exact bf16 x bf16 products of 3-way "
+                    "split operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error against fp64 equal to the fp32 "
+                    "fma chain's, tools/mfma_bf16x3_probe.hip); it is bound by the vector unit (A-operand split, one exp "
+                    "per element), not by the matrix cores.  The backward still runs on fp32 MFMA, whose results the vector "
+                    "unit consumes without overlap (tools/mfma_f32_probe.hip: 0.60 of peak is that kernel's ceiling)"}
+
+
+def literal_hbm_reading(us_per_launch, K, M=None):
+    """SURVEY 8(d) read literally: the S-ML algorithmic bytes -- the factor a materialising implementation streams,
+    4 (M K^3 + M K + 2 K) -- over the fused launch's duration, against 8 TB/s."""
+    M = M_USERS if M is None else M
+    b = 4 * (M * K ** 3 + M * K + 2 * K)
+    gbs = b / (us_per_launch * 1e-6) / 1e9
+    return {"bound": "hbm", "algorithmic_bytes": b, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "note": "the fused kernel never reads these bytes (the factor is not materialised): the figure is the rate at "
+                    "which it replaces a stream of them"}
 
 
 def rows_roofline(K, M, iters=20, traffic_key=None):
@@ -379,11 +394,12 @@ def main():
     }
     # ---- roofline of the DOMINANT kernel of the evaluation, timed live with HIP events handed to its launch
     rf = fused_roofline(res, native.MODE_FUSED_FWD,
-                        "alan::normal_lse_mfma_kernel (plate_1 step, the factor F[M,K,K,K] never materialised: per "
-                        "(m, K_mu) a 32x32 tile of log-probs on v_mfma_f32_32x32x2_f32, log-sum-exp over K_z down the "
-                        "accumulator registers, plate sum in a register)",
+                        "alan::normal_lse_x3_kernel (plate_1 step, the factor F[M,K,K,K] never materialised: per "
+                        "(m, K_mu) a 32x32 tile of log-probs on v_mfma_f32_32x32x16_bf16 with 3-way split fp32 operands, "
+                        "log-sum-exp over K_z down the accumulator registers, plate sum in a register)",
                         traffic=fused_pmc_traffic(K) if world == 1 else None)
     if rf is not None:
+        rf["literal_hbm"] = literal_hbm_reading(rf["us_per_launch"], K)
         out["roofline"] = rf
     else:                                                # FUSE_PLATE_STEP off: the HBM-bound rows kernel dominates
         res_lse = [(b, m) for mode, b, m in res if mode == native.MODE_LSE]
@@ -406,15 +422,27 @@ def main():
             out["c4_movielens_K100"] = {"evals_per_s": 10 / d100, "ms_per_eval": d100 / 10 * 1e3, "elbo": v100,
                                         "n_gpus": world,
                                         "strategy": f"Split('plate_1', {st100.split_size}" +
-                                                    (", shard=True)" if world > 1 else ")")}
+                                                    (", shard=True)" if world > 1 else ")"),
+                                        # (what this rank actually evaluated: split.MERGE_CHUNKS makes a rank's block of
+                                        # chunks one slice unless that would break Split's memory bound)
+                                        "merged": st100.merging() and len(getattr(st100, "last_sizes", [])) == max(1, world),
+                                        "effective_chunk_sizes": getattr(st100, "last_sizes", None)}
             with KernelTimer() as kt100:
                 for _ in range(5):
                     s100.elbo_nograd(st100)
                 t.cuda.synchronize()
-            rf100 = fused_roofline(kt100.results(), native.MODE_FUSED_FWD, "alan::normal_lse_mfma_kernel at K=100",
+            rf100 = fused_roofline(kt100.results(), native.MODE_FUSED_FWD, "alan::normal_lse_x3_kernel at K=100",
                                    traffic=fused_pmc_traffic(100) if world == 1 else None)
             if rf100 is not None:
+                rf100["literal_hbm"] = literal_hbm_reading(rf100["us_per_launch"], 100)
                 out["c4_movielens_K100"]["roofline"] = rf100
+            if world > 1:
+                # the same evaluation unsharded, on this very GPU, in this very run (every rank does it: no collective
+                # inside): the N = 1 figure the sharded one is to be read against
+                st1 = alan.Split("plate_1", st100.split_size)
+                d1, v1 = timed_evals(s100, st1, 10, 2, 1, graph=use_graph)
+                out["c4_movielens_K100"]["n1_same_run"] = {"evals_per_s": 10 / d1, "ms_per_eval": d1 / 10 * 1e3, "elbo": v1}
+                out["c4_movielens_K100"]["speedup_vs_n1_same_run"] = d1 / d100
         except Exception as e:
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
@@ -428,7 +456,11 @@ def main():
                     pn = build_problem("cuda", M=-(-M_USERS // n))
                     sn = draw(pn, 100)
                     dn, _ = timed_evals(sn, alan.no_checkpoint, 10, 2, 1, graph=use_graph)
-                    share[f"N{n}"] = {"users": -(-M_USERS // n), "us_per_eval": dn / 10 * 1e6}
+                    share[f"N{n}"] = {"users": -(-M_USERS // n), "us_per_eval": dn / 10 * 1e6,
+                                      # (what the rank's compute alone allows from 1 to N GPUs: the all-reduce of the
+                                      # [K, K] partial, 40 KB, comes on top)
+                                      "projected_speedup_before_collective":
+                                          out["c4_movielens_K100"]["ms_per_eval"] * 1e3 / (dn / 10 * 1e6)}
                     del pn, sn
                 out["c4_movielens_K100"]["rank_share_no_collective"] = share
             except Exception as e:
@@ -526,10 +558,7 @@ def main():
             rfb = fused_roofline(ktb.results(), native.MODE_FUSED_BWD, "alan::normal_lse_bwd_kernel (every gradient of the "
                                  "plate step in one pass: D recomputed, V and U products on the matrix cores)",
                                  traffic=fused_pmc_traffic(K, backward=True))
-            if rfb is not None:
-                rfb["algorithmic_flops"] *= 4.2          # D (E + 1 steps) + V and U (32 steps each) per tile
-                rfb["achieved"] *= 4.2
-                rfb["frac"] *= 4.2
+            if rfb is not None:                          # (flops from the shape: native.run_normal_lse_backward)
                 tr["fused_backward_kernel"] = rfb
             del p_tr
             out["training_iteration"] = tr
@@ -563,8 +592,8 @@ def main():
                 rec = {"evals_per_s": n_g / d_g, "us_per_eval": us, "elbo": v_g, "algorithmic_bytes": algo(k2),
                        "hbm_floor_us": algo(k2) / HBM_PEAK_GBS / 1e3}
                 if k2 == 30:
-                    d_e, _ = timed_evals(s2, alan.no_checkpoint, 20, 3, world)
-                    rec["evals_per_s_plain_call"] = 20 / d_e
+                    d_e, _ = timed_evals(s2, alan.no_checkpoint, 20, 3, world)          # graph=False: kernel by kernel
+                    rec["evals_per_s_eager"] = 20 / d_e
                     try:
                         v_cpu = cpu_elbo_of(builder, s2)
                         rec["elbo_cpu_oracle"] = v_cpu

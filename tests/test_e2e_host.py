@@ -690,3 +690,22 @@ def test_partial_sum_factor_is_added_by_the_contraction_that_consumes_it(oracle_
     want1, d1, _ = E.contract([(parts.sum(0), (ka, kb)), (a, (ka,))], (ka,))
     got1, d2, _ = E.contract([(parts, (E.presum_dim(7), ka, kb)), (a, (ka,))], (ka,))
     assert len(d2) == 1 and d2[0] is kb and t.allclose(got1, want1, rtol=1e-6, atol=1e-6)
+
+
+def test_merged_split_keeps_the_memory_bound(oracle_backend, monkeypatch):
+    """Split's memory-bounding contract under chunk merging: when the merged slice would make the engine allocate a
+    tensor beyond split.MERGE_MAX_BYTES the plate is evaluated chunk by chunk (the reference's loop, its chunk sizes),
+    with the same result; below the bound it is one slice."""
+    from alan_amd import split as S
+    fx = load_golden("e2e_movielens_K3.pt")
+    prob = models.BUILDERS["movielens"](fx)
+    sample = models.sample_from_fixture(prob, fx, "cpu")
+    strat = alan.Split("plate_1", 38)
+    merged = float(sample.elbo_nograd(strat))
+    assert strat.last_sizes == [300]
+    monkeypatch.setattr(S, "MERGE_MAX_BYTES", 64)            # every factor of the merged slice is "too large"
+    strat2 = alan.Split("plate_1", 38)
+    chunked = float(sample.elbo_nograd(strat2))
+    assert strat2.last_sizes == [38] * 7 + [34]
+    ref = float(fx["elbo"]["split"])
+    assert abs(chunked - ref) <= 1e-4 * abs(ref) and abs(merged - ref) <= 1e-4 * abs(ref)
