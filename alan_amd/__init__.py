@@ -6,6 +6,14 @@ own Plate / BoundPlate / Problem / Sample API (src/alan/__init__.py:1-16 of the 
 Host code (model definition, sampling, per-factor log-probs) is Python on PyTorch-ROCm; the
 contraction itself is hand-written HIP for gfx950 in libalan_mi355.so (include/alan_mi355.h).
 There is no CPU fallback: evaluating an ELBO needs the library and a GPU.
+
+Where a drop-in user sees something other than the reference (each with a switch that restores the reference's way):
+  * ``importance_sample`` on a Timeseries draws exact JOINT trajectories by default; the reference draws every timestep
+    independently from a filtering marginal (reduce_Ks.py:85-232).  ``posterior.TIMESERIES_POSTERIOR = "reference"``.
+  * fp64 observations enter the fused fp32 plate step converted (result returned as fp64, within 1e-6 of the reference's
+    fp64 log-sum-exp on the BASELINE configurations).  ``engine.FP64_SMALL_FACTORS = "exact"``.
+  * ``Split(plate, size)`` evaluates a rank's chunks as one slice while every tensor that needs stays under
+    ``split.MERGE_MAX_BYTES``; ``Split(..., merge=False)`` is the reference's per-chunk loop.
 """
 from .model import Plate, Group, Data
 from .timeseries import Timeseries

@@ -461,8 +461,14 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     ld.n_red = (uint32_t)n_red;
     ld.out_scale = d.out.scale;
     ld.add_const = (float)d.add_const;
+    // lanes per output element: as few as fill the chip (~160 k threads) -- a lane's prologue, the index decomposition
+    // of its output, is ~100 instructions, and at 64 lanes per output a lane of bus_breakdown's 150-observation plate paid
+    // it for 2 or 3 elements (K = 100, 60 k outputs: 57 us at 64 lanes, 32 us at 4; K = 30, 5.4 k outputs: 8.6 us at 32
+    // lanes, 13.6 at 8)
     int logG = 0;
-    while (logG < 6 && (1ll << logG) < n_red) ++logG;
+    while (logG < 6 && (n_out << logG) < 160000 && (1ll << logG) < n_red) ++logG;
+    static const int logg_knob = env_knob("ALAN_LIN_LOGG");                           // tuning knob (unset: the rule above)
+    if (logg_knob != ENV_UNSET && logg_knob >= 0 && logg_knob <= 6) logG = logg_knob;
     gl.block = logG == 6 && n_red >= 512 && n_out * 64 < 256ll * 256 * 4;
     gl.logG = logG;
     if (gl.block) {

@@ -281,9 +281,9 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
             off0[u] = off[0];
         }
         if ((MODE == ALAN_MODE_LSE || MODE == ALAN_MODE_SUM) && d.presum_n > 1) {
-            // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, sixteen loads per element in
+            // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, eight loads per element in
             // flight, added in slice order
-            constexpr int PF = 16;                    // (a lone workgroup: its time is rounds of load latency)
+            constexpr int PF = 8;                     // (more costs every small kernel registers: 16 took them to 5 waves per SIMD)
             for (int32_t c0 = 1; c0 < d.presum_n; c0 += PF) {
                 T part[UNR][PF];
 #pragma unroll
@@ -411,6 +411,27 @@ int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStrea
 // (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
 // TorchDimDist.py:127-162).  A lane group per output element, lanes along the summed dims; each lane walks the dot
 // products of its element serially, all loads of up to 32 events in flight.
+template <int N>
+__device__ __forceinline__ float lin_dot(const float *pa, const float *pb, int len, int as, int bs) {
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int e0 = 0; e0 < len; e0 += N) {
+        float av[N], bv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int e = min(e0 + i, len - 1);
+            av[i] = pa[e * as], bv[i] = pb[e * bs];
+        }
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            acc0 = fmaf(e0 + i + 0 < len ? av[i + 0] : 0.f, bv[i + 0], acc0);
+            acc1 = fmaf(e0 + i + 1 < len ? av[i + 1] : 0.f, bv[i + 1], acc1);
+            acc2 = fmaf(e0 + i + 2 < len ? av[i + 2] : 0.f, bv[i + 2], acc2);
+            acc3 = fmaf(e0 + i + 3 < len ? av[i + 3] : 0.f, bv[i + 3], acc3);
+        }
+    }
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+
 template <bool BLOCK>
 __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const uint32_t block_id) {
     const uint32_t G = BLOCK ? 256u : (1u << logG);
@@ -442,6 +463,9 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
         obase += idx * d.oks[k];
     }
     float s = 0.f, m = 0.f;
+    // one summed dim (bus_breakdown's plate of 150 observations): offsets are linear in r -- no index decomposition per
+    // element (it was a third of the instructions of an element at K = 100: 9 M elements)
+    const bool one_dim = d.rdiv[0].d == 1;
     for (uint32_t r = gl; r < d.n_red; r += G) {
         int32_t aoff[LIN_T], boff[LIN_T], voff = vbase;
 #pragma unroll
@@ -449,18 +473,27 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             aoff[tm] = abase[tm];
             boff[tm] = bbase[tm];
         }
-        uint32_t rr = r;
-#pragma unroll
-        for (int k = LIN_NR - 1; k >= 0; --k) {
-            const uint32_t q = fd_div(rr, d.rdiv[k]);
-            const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
-            rr = q;
+        if (one_dim) {
 #pragma unroll
             for (int tm = 0; tm < LIN_T; ++tm) {
-                aoff[tm] += idx * d.ars[tm][k];
-                boff[tm] += idx * d.brs[tm][k];
+                aoff[tm] += (int32_t)r * d.ars[tm][LIN_NR - 1];
+                boff[tm] += (int32_t)r * d.brs[tm][LIN_NR - 1];
             }
-            voff += idx * d.vrs[k];
+            voff += (int32_t)r * d.vrs[LIN_NR - 1];
+        } else {
+            uint32_t rr = r;
+#pragma unroll
+            for (int k = LIN_NR - 1; k >= 0; --k) {
+                const uint32_t q = fd_div(rr, d.rdiv[k]);
+                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+                rr = q;
+#pragma unroll
+                for (int tm = 0; tm < LIN_T; ++tm) {
+                    aoff[tm] += idx * d.ars[tm][k];
+                    boff[tm] += idx * d.brs[tm][k];
+                }
+                voff += idx * d.vrs[k];
+            }
         }
         const float y = d.val[voff];
         float xl = 0.f;
@@ -473,27 +506,17 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             }
             const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
             const int len = d.len[tm], as = d.ads[tm], bs = d.bds[tm];
-            // (every load of up to 32 events issued before the first product: the kernel is a chain of load latencies --
-            // four products in flight made movielens' 18-event dot five round trips; clamped loads, masked products)
-            float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-            for (int e0 = 0; e0 < len; e0 += 32) {
-                float av[32], bv[32];
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int e = min(e0 + i, len - 1);
-                    av[i] = pa[e * as], bv[i] = pb[e * bs];
-                }
-#pragma unroll
-                for (int i = 0; i < 32; i += 4) {
-                    acc0 = fmaf(e0 + i + 0 < len ? av[i + 0] : 0.f, bv[i + 0], acc0);
-                    acc1 = fmaf(e0 + i + 1 < len ? av[i + 1] : 0.f, bv[i + 1], acc1);
-                    acc2 = fmaf(e0 + i + 2 < len ? av[i + 2] : 0.f, bv[i + 2], acc2);
-                    acc3 = fmaf(e0 + i + 3 < len ? av[i + 3] : 0.f, bv[i + 3], acc3);
-                }
-            }
-            xl += (acc0 + acc1) + (acc2 + acc3);
+            // (every load of a chunk issued before the first product: the kernel is a chain of load latencies -- four
+            // products in flight made movielens' 18-event dot five round trips.  The chunk is the smallest of 4 / 8 / 16
+            // that holds the dot (16 at a time beyond): clamped loads past its length are wasted issue, and a chunk of 32
+            // cost the kernel half its waves per SIMD in registers -- bus_breakdown K = 100 ran twice as long)
+            xl += len <= 4 ? lin_dot<4>(pa, pb, len, as, bs) : len <= 8 ? lin_dot<8>(pa, pb, len, as, bs)
+                                                             : lin_dot<16>(pa, pb, len, as, bs);
         }
-        const float ls = (xl < 0.f ? xl : 0.f) - log1pf(expf(xl < 0.f ? xl : -xl));
+        // logsigmoid(x) = min(x, 0) - log(1 + exp(-|x|)) on the fast transcendental instructions (1 ulp each; 1 + e in
+        // (1, 2] is rounded as the reference's log1p argument is): the accurate expf / log1pf were two thirds of an element
+        const float e = __builtin_amdgcn_exp2f(-fabsf(xl) * 1.44269504088896340736f);
+        const float ls = fminf(xl, 0.f) - __builtin_amdgcn_logf(1.f + e) * 0.69314718055994530942f;
         s += ls - (1.f - y) * xl;
     }
     combine_lanes<float, ALAN_MODE_SUM, BLOCK>(m, s, G);

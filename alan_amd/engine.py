@@ -104,6 +104,15 @@ class ResultRing:
         return s
 
 
+FP64_SMALL_FACTORS = "fused"
+"""What the fused plate step does with an fp64 small factor (the likelihood of fp64 observations, which the reference's
+sum of factors promotes to fp64 before its log-sum-exp, utils.py:218-220).  "fused" (default): the factor enters the fp32
+kernel converted and the result is returned as fp64 -- inside 1e-6 of the reference's value on the BASELINE
+configurations, three launches per evaluation.  "exact": the plate step declines such a problem and the materialised
+route runs it -- fp32 factor produced as the reference produces it, factors added and reduced in fp64 by the generic
+kernel -- at roughly twice the time."""
+
+
 _RING = [None]          # set by sample._GraphedELBO around warm-up + capture of one evaluation
 
 
@@ -132,6 +141,11 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
         raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
     if len(factors) > N.MAX_FACTORS:
         raise N.NativeError(f"alan_amd: {len(factors)} factors in one contraction step (max {N.MAX_FACTORS})")
+    if FP64_SMALL_FACTORS == "exact" and out.dtype == t.float64 and mode in (N.MODE_LSE, N.MODE_SUM, N.MODE_WEXPSUM) \
+            and any(x.dtype == t.float32 for x, _ in factors):
+        # mixed fp32 / fp64 factors, exactly as the reference's promotion computes them: every factor in fp64 (the
+        # library's streaming kernel would otherwise run such a problem at the big fp32 factor's precision, rows.hip)
+        factors = [(x.double() if x.dtype == t.float32 else x, d) for x, d in factors]
     desc = N.ReduceDesc()
     desc.mode = mode
     desc.ndim = len(space)
@@ -456,6 +470,8 @@ def _normal_lse_args(value, loc, scale, smalls, plate, K):
             not all(x.dtype in (t.float32, t.float64) for x, _ in smalls):
         return None
     wide = any(x.dtype == t.float64 for x, _ in smalls)
+    if wide and FP64_SMALL_FACTORS == "exact":
+        return None                                   # (the materialised route adds the factors and takes the log-sum-exp in fp64)
     # (an fp64 small factor -- the likelihood of fp64 observations -- enters the fp32 kernel converted; the result is
     # returned as fp64, the dtype torch's promotion gives the reference's sum of factors)
     smalls = [(x.float() if x.dtype == t.float64 else x, d) for x, d in smalls]

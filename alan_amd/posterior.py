@@ -156,9 +156,19 @@ def sample_Ks_timeseries(lps, Ks, K_currs, K_inits, T_dim, indices, N_dim, N):
     if ms.dtype != t.float32 or K > N_.POSTERIOR_MAX_K or not ms.is_cuda:
         # (not on the GPU: only under the test-only CPU backend, whose seam is alan_reduce)
         draws = _sample_chain_by_steps(flat, init, N, B, has_N)
+    elif TIMESERIES_POSTERIOR == "reference" and has_N:
+        # chains that depend on the sample (a drawn K of another group plugged in): the same table, the forward recursion
+        # of sample n run on chain n from its own initial state, mixed over n
+        fl = flat.reshape(N, B, T, K, K)
+        tabs = []
+        for b in range(B):
+            alpha = t.stack([N_.chain_filter(fl[n, b:b + 1], init[n:n + 1, b].contiguous())[0, :, 0] for n in range(N)], 1)
+            mix = t.logsumexp(alpha, 1)                                                  # [T, K]
+            tabs.append(mix - t.logsumexp(mix, -1, keepdim=True))
+        logp = t.stack(tabs)
+        d = t.multinomial(logp.exp().reshape(B * T, K), N, replacement=True)
+        draws = d.reshape(B, T, N).permute(2, 0, 1).contiguous()
     elif TIMESERIES_POSTERIOR == "reference":
-        if has_N:
-            raise NotImplementedError("TIMESERIES_POSTERIOR = 'reference' with chains that depend on the sample")
         if B == 1 or bool((init == init[:, :1]).all()):
             logp = filtering_marginals(flat, init[:, 0].contiguous())                  # [B, T, K]
         else:                                                                           # initial states differ by plate

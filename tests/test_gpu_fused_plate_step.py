@@ -294,3 +294,25 @@ def test_in_launch_combine_of_the_chunk_partials_gives_the_same_result(monkeypat
         t.testing.assert_close(outs[0], two, rtol=2e-6, atol=1e-4)
         assert all(t.equal(o, outs[0]) for o in outs), (M, NK, NL, NS)
         assert int(N.arrival_counters(z.device).abs().sum()) == 0
+
+
+def test_fp64_small_factor_exact_switch_routes_around_the_fp32_kernel(monkeypatch):
+    """engine.FP64_SMALL_FACTORS = "exact": with an fp64 small factor (the likelihood of fp64 observations) the fused fp32
+    plate step declines and the caller's materialised route adds and reduces in fp64, as the reference's promotion does
+    (utils.py:218-220); the default converts the factor and stays inside 1e-6 of that."""
+    g = t.Generator().manual_seed(11)
+    M, K, Ev = 20, 10, 6
+    pl, Kz, dl, ds = Dim("plate", M), Dim("K", K), Dim("Kl", K), Dim("Ks", K)
+    z, mu, raw = t.randn(M, K, Ev, generator=g).to(DEV), t.randn(K, Ev, generator=g).to(DEV), (0.3 * t.randn(K, Ev, generator=g)).to(DEV)
+    small = (t.randn(M, K, generator=g, dtype=t.float64).to(DEV), (pl, Kz))
+    fused, _ = E.normal_lse((z, (pl, Kz)), (mu, (dl,)), (raw, (ds,)), [small], pl, Kz, log_scale=True)
+    assert fused.dtype == t.float64
+    monkeypatch.setattr(E, "FP64_SMALL_FACTORS", "exact")
+    assert E.normal_lse((z, (pl, Kz)), (mu, (dl,)), (raw, (ds,)), [small], pl, Kz, log_scale=True) is None
+    F = E.normal_logprob((z, (pl, Kz)), (mu, (dl,)), (raw, (ds,)), (pl, dl, ds, Kz), log_scale=True)       # fp32, as the reference's
+    exact, dims = E.reduce_factors([(F, (pl, dl, ds, Kz)), small], reduce=(Kz,), plate=(pl,))
+    assert exact.dtype == t.float64
+    exact = exact if dims[0] is dl else exact.t()
+    want = t.logsumexp(F.double() + small[0][:, None, None, :], -1).sum(0)
+    t.testing.assert_close(exact, want, rtol=1e-12, atol=1e-10)
+    t.testing.assert_close(fused, want, rtol=1e-6, atol=1e-5)

@@ -353,6 +353,21 @@ def test_timeseries_posterior_reference_mode_runs_end_to_end(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["nested", "with_group"])
+def test_timeseries_posterior_reference_mode_with_chains_that_depend_on_the_sample(which, monkeypatch):
+    """The same mode where a drawn K of another group is plugged into the chain (a chain per posterior sample): the
+    forward recursion of sample n runs on chain n (round 2 raised NotImplementedError here)."""
+    from alan_amd import posterior as PS
+    monkeypatch.setattr(PS, "TIMESERIES_POSTERIOR", "reference")
+    prob = nested_problem(5)[0] if which == "nested" else with_group_problem(5)
+    prob.to("cuda")
+    t.manual_seed(2)
+    isamp = prob.sample(20, reparam=False).importance_sample(64)
+    d = isamp.dump()["ts"]
+    assert "N" in d.names and "T" in d.names and bool(t.isfinite(d.rename(None)).all())
+
+
+@pytest.mark.gpu
 def test_constant_multiple_lambda_is_folded_into_the_normal_producer(monkeypatch):
     """``lambda prev: 0.9 * prev`` (the Kalman model's transition mean) stays lazy on gradient-free evaluations: the
     Normal producer multiplies the location itself (factor scale field).  Same ELBO as with the lambda evaluated."""

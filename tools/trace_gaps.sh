@@ -8,7 +8,7 @@ rm -rf $O && mkdir -p $O
 timeout -k 10 200 rocprofv3 --kernel-trace -d $O/t --output-format csv -- python3 tools/prof_case.py $1 $2 $3 > $O/log 2>&1 || { echo failed; tail -5 $O/log; exit 1; }
 python3 - "$(find $O/t -name '*kernel_trace.csv' | head -1)" $3 <<'PY' | tee $O/summary.txt
 import sys, csv, statistics as st
-rows = sorted(({"name": r["Kernel_Name"].split("(")[0][-48:], "s": int(r["Start_Timestamp"]), "e": int(r["End_Timestamp"])}
+rows = sorted(({"name": r["Kernel_Name"][:90], "s": int(r["Start_Timestamp"]), "e": int(r["End_Timestamp"])}
                for r in csv.DictReader(open(sys.argv[1]))), key=lambda r: r["s"])
 n = int(sys.argv[2])
 # the last n replays: find the period (kernels per replay) from the tail
