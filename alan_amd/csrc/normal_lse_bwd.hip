@@ -63,7 +63,12 @@ __host__ __device__ inline NLBLds nlb_lds(int EH, int NS, int NL, int E) {
 }
 
 // SMALL_ONLY: only d small is wanted (elbo_rws: the sample is detached, log Q carries the gradient) -- no V, no U.
-template <int EH, bool SMALL_ONLY>
+// FLAT (as the forward's flat row tiling; NK > 32, NK % 4 == 0, plate elements contiguous): the k rows of all plate
+// elements are ONE run of M NK rows cut into tiles of 32, so only the run's last tile is padded (K = 100: 938 tiles
+// where a tile grid per plate element has 1,200).  A tile then ends one plate element (rows below `bnd`) and begins the
+// next: the forward's log-sum-exp of either is held per lane and chosen per group of four accumulator rows; everything
+// else -- V, U, d value, d small -- is indifferent to which plate element a row belongs to.
+template <int EH, bool SMALL_ONLY, bool FLAT = false>
 __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,31 +77,47 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
     const NLBLds L = nlb_lds(EH, NS, NL, E);
     float *wt = lds, *lgt = lds + L.o_lgt, *wtT = lds + L.o_wtT, *mu = lds + L.o_mu, *scr = lds + L.o_scr;
     const int nkt = (NK + 31) >> 5, nst = L.nsp >> 5;
-    const int m = blockIdx.x / nkt, kt = blockIdx.x - m * nkt;
+    // the tile's rows: (m, 32 kt ..) of one plate element, or rows 32 blockIdx.x .. of the flat run
+    const int64_t rows_total = (int64_t)d.M * NK, row0 = FLAT ? 32ll * blockIdx.x : 0;
+    const int m = FLAT ? (int)(row0 / NK) : blockIdx.x / nkt, kt = FLAT ? 0 : blockIdx.x - m * nkt;
+    const int bnd = FLAT ? (int)std::min<int64_t>(32, (int64_t)(m + 1) * NK - row0) : 32;   // rows of the tile in element m
     const int ys = blockIdx.y, gy = gridDim.y;
     const int sE = E >> 1;                                  // step / half of event slot E (the small factors; ones)
     const bool slotE = (E & 1) == h;
 
-    // ---- this lane's share of the plate element, requested before the tables are built
+    // ---- this lane's share of the tile, requested before the tables are built
     const int kA = 32 * kt + j;
-    const bool k_ok = kA < NK;
-    const float *vrow = d.val + (int64_t)m * d.v_sm + (int64_t)min(kA, NK - 1) * d.v_sk;
+    const bool k_ok = FLAT ? row0 + j < rows_total : kA < NK;
+    int mj = m, kj = min(kA, NK - 1);                       // this lane's row: (plate element, k)
+    if (FLAT) {
+        const int64_t rj = std::min<int64_t>(row0 + j, rows_total - 1);
+        mj = (int)(rj / NK), kj = (int)(rj - (int64_t)mj * NK);
+    }
+    const float *vrow = d.val + (int64_t)mj * d.v_sm + (int64_t)kj * d.v_sk;
     float vA[EH];
 #pragma unroll
     for (int step = 0; step < EH; ++step) vA[step] = vrow[(int64_t)min(2 * step + h, E - 1) * d.v_se];
     float hsum = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-        const float x = d.small[f][(int64_t)m * d.small_sm[f] + (int64_t)min(kA, NK - 1) * d.small_sk[f]];
+        const float x = d.small[f][(int64_t)mj * d.small_sm[f] + (int64_t)kj * d.small_sk[f]];
         hsum += f < d.n_small ? x : 0.f;
     }
-    // the same rows with the event index on the lanes: vT[r] = value[m, k_r(h), e = j], 1 in column E, 0 beyond
+    // the same rows with the event index on the lanes: vT[r] = value[row r(h) of the tile, e = j], 1 in column E, 0 beyond
     float vT[16];
     if (!SMALL_ONLY) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kr = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float x = d.val[(int64_t)m * d.v_sm + (int64_t)min(kr, NK - 1) * d.v_sk + (int64_t)min(j, E - 1) * d.v_se];
+            const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+            int64_t roff;
+            if (FLAT) {
+                const int64_t rf = std::min<int64_t>(row0 + rr, rows_total - 1);
+                const int mr = (int)(rf / NK);
+                roff = (int64_t)mr * d.v_sm + (rf - (int64_t)mr * NK) * d.v_sk;
+            } else {
+                roff = (int64_t)m * d.v_sm + (int64_t)min(32 * kt + rr, NK - 1) * d.v_sk;
+            }
+            const float x = d.val[roff + (int64_t)min(j, E - 1) * d.v_se];
             vT[r] = j < E ? x : (j == E ? 1.f : 0.f);
         }
     }
@@ -161,6 +182,8 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
             // per-lane scalars of this tile: upstream gradient and the forward's log-sum-exp at (m, l, s)
             const float Gs = s_ok ? d.gout[(int64_t)l * d.g_sl + (int64_t)s * d.g_ss] : 0.f;
             const float nls = s_ok ? -d.lse[((int64_t)m * NL + l) * NS + s] : 0.f;
+            // (FLAT: the rows from `bnd` on belong to the next plate element)
+            const float nls2 = (FLAT && bnd < 32 && s_ok && m + 1 < d.M) ? -d.lse[((int64_t)(m + 1) * NL + l) * NS + s] : 0.f;
             float a[EH];
 #pragma unroll
             for (int step = 0; step < EH; ++step) {
@@ -177,7 +200,10 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
             // acc[r] = -(log-prob + small) of row k_r(h), column s: X = G * exp(-lse - acc)
             // (lanes beyond the last scale row hold 0, not inf * 0: their columns enter U's sum over s)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = s_ok ? Gs * __expf(nls - acc[r]) : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const float nl = (FLAT && 8 * (r >> 2) + 4 * h >= bnd) ? nls2 : nls;     // (NK % 4 == 0: four rows of a register group go together)
+                acc[r] = s_ok ? Gs * __expf(nl - acc[r]) : 0.f;
+            }
             if (SMALL_ONLY) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dvacc[r] += acc[r];
@@ -263,8 +289,12 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
             if (j == 0) scr[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = x;
         }
         __syncthreads();
-        if (tid < 32 && 32 * kt + tid < NK)
+        if (FLAT) {
+            if (tid < 32 && row0 + tid < rows_total)
+                d.dsm[(int64_t)ys * rows_total + row0 + tid] = scr[tid] + scr[32 + tid] + scr[64 + tid] + scr[96 + tid];
+        } else if (tid < 32 && 32 * kt + tid < NK) {
             d.dsm[((int64_t)ys * d.M + m) * NK + 32 * kt + tid] = scr[tid] + scr[32 + tid] + scr[64 + tid] + scr[96 + tid];
+        }
         return;
     }
 #pragma unroll
@@ -276,8 +306,8 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
         const float tot = scr[(0 * 16 + r) * 64 + lane] + scr[(1 * 16 + r) * 64 + lane] +
                           scr[(2 * 16 + r) * 64 + lane] + scr[(3 * 16 + r) * 64 + lane];
         const int k = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (k < NK) {
-            const int64_t row = ((int64_t)ys * d.M + m) * NK + k;
+        if (FLAT ? row0 + k < rows_total : k < NK) {
+            const int64_t row = FLAT ? (int64_t)ys * rows_total + row0 + k : ((int64_t)ys * d.M + m) * NK + k;
             if (j < E && d.dval) d.dval[row * E + j] = -2.f * tot;
             if (j == E && d.dsm) d.dsm[row] = tot;
         }
@@ -336,7 +366,8 @@ namespace {
 
 struct NLBPlan {
     int eh = 0, nkt = 1, nst = 1, gy = 1;
-    bool small_only = false;
+    int64_t tiles = 0;           // workgroups along x: M * nkt, or ceil(M NK / 32) with flat row tiling
+    bool small_only = false, flat = false;
     size_t lds = 0;
     size_t o_ploc = 0, o_pscl = 0, o_dvp = 0, o_dsp = 0, bytes = 0;   // workspace offsets (bytes)
     int64_t rows_loc = 0, rows_scl = 0;
@@ -358,8 +389,15 @@ int plan_nlb(const alan_normal_lse_backward_desc_t &b, NLBPlan &p) {
     const NLBLds L = nlb_lds(p.eh, (int)a.NS, (int)a.NL, (int)a.E);
     p.lds = (size_t)L.total * sizeof(float);
     if (p.lds > 150 * 1024) return ALAN_ERR_UNSUPPORTED;
+    // flat row tiling (see the kernel): the plate elements' k rows as one run
+    static const int flat_knob = env_knob("ALAN_NLB_FLAT");                   // ablation knob: 0 = off
+    // (not for SMALL_ONLY: with no V and no U a tile is short, and the second log-sum-exp value per lane and the
+    // selects cost more than the saved tiles -- K = 100: 334 against 315 us)
+    p.flat = a.NK > 32 && (a.NK & 31) != 0 && (a.NK & 3) == 0 && a.v_sm == a.NK * a.v_sk && flat_knob != 0 &&
+             (b.grad_value || b.grad_loc || b.grad_scale);
     // workgroups: one per (plate element, k tile), times gy shares of the loc rows so that the chip is covered
-    const int64_t base = a.M * p.nkt;
+    const int64_t base = p.flat ? (a.M * a.NK + 31) / 32 : a.M * p.nkt;
+    p.tiles = base;
     if (base * 64 >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
     // (one share unless the plate is short: every share adds a row of partials to the column sums and the loc-share
     // add launch -- at K=30, M=300 one share is 39 + 4 us, three are 37 + 10 + 4)
@@ -429,7 +467,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     d.ploc = (!p.small_only && b->grad_loc) ? (float *)(ws + p.o_ploc) : nullptr;
     d.pscl = (!p.small_only && b->grad_scale) ? (float *)(ws + p.o_pscl) : nullptr;
 
-    const dim3 grid((uint32_t)(a.M * p.nkt), (uint32_t)p.gy);
+    const dim3 grid((uint32_t)p.tiles, (uint32_t)p.gy);
     auto launch = [&](auto kern) {
         if (p.lds > 64 * 1024)
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
@@ -440,7 +478,8 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     };
 #define NLB_CASE(EHV)                                                                        \
     case EHV:                                                                                \
-        rc = p.small_only ? launch(normal_lse_bwd_kernel<EHV, true>) : launch(normal_lse_bwd_kernel<EHV, false>); \
+        rc = p.flat ? (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true, true>) : launch(normal_lse_bwd_kernel<EHV, false, true>)) \
+                    : (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true>) : launch(normal_lse_bwd_kernel<EHV, false>)); \
         break;
     switch (p.eh) {
         NLB_CASE(4)
@@ -448,7 +487,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
         NLB_CASE(10)
         NLB_CASE(12)
         default:
-            rc = p.small_only ? launch(normal_lse_bwd_kernel<16, true>) : launch(normal_lse_bwd_kernel<16, false>);
+            NLB_CASE(16)
     }
 #undef NLB_CASE
     if (rc != ALAN_OK) return rc;

@@ -172,6 +172,8 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
         // small launches are latency chains: widen the group until a lane sees one element
         while (logG < 6 && (c.n_out << logG) < want_threads && (1ll << logG) < c.n_red) ++logG;
     }
+    static const int glogg_knob = env_knob("ALAN_GROUP_LOGG");                        // tuning knob
+    if (glogg_knob != ENV_UNSET && glogg_knob >= 0 && glogg_knob <= 6 && c.n_red > 1) logG = glogg_knob;
     gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 512);
     gl.logG = logG;
     if (gl.block) {

@@ -561,6 +561,33 @@ def main():
             if rfb is not None:                          # (flops from the shape: native.run_normal_lse_backward)
                 tr["fused_backward_kernel"] = rfb
             del p_tr
+            # the same at K = 100 under C4's strategy (Split('plate_1', 38): the rank's chunks as one slice)
+            try:
+                p_tr = build_problem("cuda")
+                opt = t.optim.Adam(list(p_tr.parameters()), lr=1e-2, capturable=True, fused=True)
+                step = alan.GraphedStep(p_tr, 100, opt, method="vi", computation_strategy=alan.Split("plate_1", 38))
+                for _ in range(3):
+                    step()
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    v_tr = step()
+                t.cuda.synchronize()
+                tr["vi_K100_split38"] = {"ms_per_iter": (time.perf_counter() - t0) / 10 * 1e3, "last_elbo": float(v_tr)}
+                del step, opt
+                with KernelTimer() as ktb100:
+                    for _ in range(3):
+                        for q in p_tr.parameters():
+                            q.grad = None
+                        p_tr.sample(100, reparam=True).elbo_vi(alan.Split("plate_1", 38)).backward()
+                    t.cuda.synchronize()
+                rfb100 = fused_roofline(ktb100.results(), native.MODE_FUSED_BWD, "alan::normal_lse_bwd_kernel at K=100 "
+                                        "(flat row tiling)", traffic=fused_pmc_traffic(100, backward=True))
+                if rfb100 is not None:
+                    tr["vi_K100_split38"]["fused_backward_kernel"] = rfb100
+                del p_tr
+            except Exception as e:
+                tr["vi_K100_split38"] = {"error": f"{type(e).__name__}: {e}"}
             out["training_iteration"] = tr
         except Exception as e:
             out["training_iteration"] = {"error": f"{type(e).__name__}: {e}"}

@@ -169,7 +169,8 @@ def _torch_reference(z, mu, raw, smalls, log_scale, G, dtype=t.float64):
 SHAPES = [(300, 30, 30, 30, 18, 2, True), (38, 100, 100, 100, 18, 2, True), (7, 5, 4, 3, 3, 0, False),
           (11, 33, 9, 70, 20, 1, True), (5, 8, 40, 31, 1, 3, True), (3, 64, 2, 32, 31, 4, False),
           (4, 16, 5, 128, 9, 1, False), (6, 10, 7, 50, 18, 2, True), (9, 97, 3, 33, 17, 2, False),
-          (2, 130, 2, 5, 30, 0, True), (1, 1, 1, 1, 1, 1, False), (40, 30, 30, 30, 18, 2, True)]
+          (2, 130, 2, 5, 30, 0, True), (1, 1, 1, 1, 1, 1, False), (40, 30, 30, 30, 18, 2, True),
+          (5, 36, 3, 40, 7, 2, True), (3, 72, 2, 64, 5, 1, False), (1, 44, 2, 33, 18, 0, True)]   # (flat row tiling: tiles that span two plate elements, a padded last tile, one element)
 
 
 @pytest.mark.parametrize("M,NK,NL,NS,Ev,n_small,log_scale", SHAPES)
