@@ -65,6 +65,9 @@ struct LinDesc {
     int32_t vks[LIN_NK], vrs[LIN_NR], oks[LIN_NK];
     int32_t aks[LIN_T][LIN_NK], ars[LIN_T][LIN_NR], bks[LIN_T][LIN_NK], brs[LIN_T][LIN_NR];
     int32_t len[LIN_T], ads[LIN_T], bds[LIN_T];
+    // ALAN_MODE_BERNOULLI_LINEAR_GRAD: upstream gradient (strides over the keep dims), the gradient's dot stride
+    const float *g;
+    int32_t gks[LIN_NK], ods;
 };
 
 // Kernel argument of the small log-sum-exp + plate-sum kernel: out[keep] = sum_plate LSE_red(sum_f factor_f) + add_const
@@ -138,6 +141,7 @@ int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
                        const LinDesc *lin = nullptr);
 int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);
+int launch_lin_grad(const LinDesc &ld, hipStream_t stream, const EvPair &ev);
 
 // rows.hip: LDS-staged fast path.  Returns ALAN_ERR_UNSUPPORTED when the canonical problem does not
 // fit it (caller then falls back to the group kernel).  With PLATE dims in the canonical problem the

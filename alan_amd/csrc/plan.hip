@@ -356,8 +356,10 @@ static bool split_long_dim(const alan_reduce_desc_t &d, uint32_t keep, uint32_t 
 // ALAN_MODE_BERNOULLI_LINEAR -> the kernel's argument and launch geometry.  ALAN_ERR_UNSUPPORTED: a well-formed problem
 // outside what the kernel takes (the caller evaluates the logits itself and uses ALAN_MODE_BERNOULLI).
 static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl) {
+    const bool grad = d.mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD;
     if (d.ndim < 0 || d.ndim > MAXD || d.n_factors < 2 || d.n_factors > MAXF) return ALAN_ERR_BAD_DESC;
-    if (d.lse_out.data || d.weight.data || d.ring_n || !d.out.data) return ALAN_ERR_BAD_DESC;
+    if (d.lse_out.data || (d.weight.data != nullptr) != grad || d.ring_n || !d.out.data) return ALAN_ERR_BAD_DESC;
+    if (grad && d.weight.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
     for (int f = 0; f < d.n_factors; ++f) {
         if (!d.factor[f].data) return ALAN_ERR_BAD_DESC;
         if (d.factor[f].dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
@@ -385,6 +387,7 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     }
     if (nk > LIN_NK || nr > LIN_NR) return ALAN_ERR_UNSUPPORTED;
     // threads run along the output's innermost dim; lanes of a group along the value's
+    // (the gradient's layout is that of `a`: its innermost keep dim sits above the dot dim)
     std::sort(keep, keep + nk, [&](int a, int b) { return d.out.stride[a] > d.out.stride[b]; });
     std::sort(red, red + nr, [&](int a, int b) { return d.factor[0].stride[a] > d.factor[0].stride[b]; });
     const int ko = LIN_NK - nk, ro = LIN_NR - nr;
@@ -422,7 +425,23 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     lay(d.factor[0], ld.vks, ld.vrs, -1);
     for (int j = 0; j < nr; ++j)
         if (d.out.stride[red[j]] != 0) return ALAN_ERR_BAD_DESC;
-    lay(d.out, ld.oks, nullptr, -1);
+    if (grad) {
+        // the upstream gradient over the keep dims; the gradient's own dot stride (out is laid out like `a`)
+        for (int j = 0; j < nr; ++j)
+            if (d.weight.stride[red[j]] != 0) return ALAN_ERR_BAD_DESC;
+        if (dot_strides(d.weight)) return ALAN_ERR_BAD_DESC;
+        lay(d.weight, ld.gks, nullptr, -1);
+        ld.g = (const float *)d.weight.data;
+        if (dot == 0 || (dot & (dot - 1))) return ALAN_ERR_UNSUPPORTED;        // (exactly one DOT dim: the first term's)
+        int dd = -1;
+        for (int i = 0; i < d.ndim; ++i)
+            if ((dot >> i) & 1) dd = i;
+        lay(d.out, ld.oks, nullptr, dd);
+        if (d.out.stride[dd] > lim || d.out.stride[dd] < -lim) return ALAN_ERR_UNSUPPORTED;
+        ld.ods = (int32_t)d.out.stride[dd];
+    } else {
+        lay(d.out, ld.oks, nullptr, -1);
+    }
     ld.val = (const float *)d.factor[0].data;
     ld.out = (float *)d.out.data;
     // terms
@@ -463,6 +482,19 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     ld.n_red = (uint32_t)n_red;
     ld.out_scale = d.out.scale;
     ld.add_const = (float)d.add_const;
+    if (grad) {
+        // the gradient kernel: a thread per row of `a` -- term 0 must be a dot product of at most 32 events whose first
+        // operand carries every keep dim and no summed dim
+        if (nt < 1 || !ld.b[0] || ld.len[0] > 32 || ld.len[0] < 1) return ALAN_ERR_UNSUPPORTED;
+        for (int k = 0; k < LIN_NR; ++k)
+            if (ld.ars[0][k] != 0) return ALAN_ERR_UNSUPPORTED;
+        for (int j = 0; j < nk; ++j)
+            if (ld.aks[0][ko + j] == 0) return ALAN_ERR_UNSUPPORTED;
+        for (int tm = 1; tm < nt; ++tm)
+            if (ld.b[tm] && ld.len[tm] > 8 * 64) return ALAN_ERR_UNSUPPORTED;
+        gl.logG = 0, gl.block = false, gl.grid = (uint32_t)((n_out + 255) / 256);
+        return ALAN_OK;
+    }
     // lanes per output element: as few as fill the chip (~160 k threads) -- a lane's prologue, the index decomposition
     // of its output, is ~100 instructions, and at 64 lanes per output a lane of bus_breakdown's 150-observation plate paid
     // it for 2 or 3 elements (K = 100, 60 k outputs: 57 us at 64 lanes, 32 us at 4; K = 30, 5.4 k outputs: 8.6 us at 32
@@ -715,7 +747,7 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
         if (p == -2) return ALAN_ERR_BAD_DESC;
         if (p >= 0) return run_presum(d2, n, stride, nullptr, true);
     }
-    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) {
         LinDesc ld;
         GroupLaunch gl;
         return lin_prepare(*d, ld, gl);
@@ -726,7 +758,7 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
 
 extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;
-    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) return 0;
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) return 0;
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
     {
@@ -765,7 +797,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         if (p == -2) return ALAN_ERR_BAD_DESC;
         if (p >= 0) return run_presum(d2, n, stride, stream, false);
     }
-    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) {
         LinDesc ld;
         GroupLaunch gl;
         const int rc = lin_prepare(*d, ld, gl);
@@ -773,7 +805,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         EvPair ev;
         ev.start = (hipEvent_t)d->ev_start;
         ev.stop = (hipEvent_t)d->ev_stop;
-        return launch_lin(ld, gl, stream, ev);
+        return d->mode == ALAN_MODE_BERNOULLI_LINEAR ? launch_lin(ld, gl, stream, ev) : launch_lin_grad(ld, stream, ev);
     }
     uint32_t keep, red, plate;
     int rc = classify(*d, keep, red, plate);

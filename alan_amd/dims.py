@@ -315,10 +315,14 @@ class LinearPT(PT):
     terms to the producer kernel that computes the logits itself (alan_reduce mode BERNOULLI_LINEAR) -- no batched
     GEMM, no adds, no logits tensor.  ``terms``: tuples of one PT (a plain summand, no positional dims) or two PTs
     (contracted over their single positional dim).  Only built where no gradient is wanted."""
-    __slots__ = ("terms", "make", "_val")
+    __slots__ = ("terms", "make", "_val", "grad")
 
-    def __init__(self, terms, dims, make):
+    def __init__(self, terms, dims, make, grad=None):
+        """``grad``: None, or the index of the ONE term whose first operand is attached to the autograd graph (a dot
+        term: movielens' z under elbo_vi) -- the Bernoulli log-prob then goes through dist._BernoulliLinear, whose
+        backward is the library's own launch; ``.x`` still evaluates the lambda through torch's autograd."""
         self.terms, self.make = tuple(terms), make
+        self.grad = grad
         self._val = None
         self.dims = tuple(dims)
         self.ids = tuple(id(d) for d in self.dims)

@@ -205,6 +205,67 @@ def _sum_leading(x, blk=64):
     return _sum_leading(part, blk)
 
 
+class _BernoulliLinear(t.autograd.Function):
+    """sum log Bernoulli(value; logits = a . b + further terms) with the logits computed by the producer launch itself
+    (alan_reduce mode BERNOULLI_LINEAR) and the gradient with respect to ``a`` -- the only differentiable input -- by
+    the library's gradient launch (mode BERNOULLI_LINEAR_GRAD): no batched GEMM, no logits tensor, in either direction
+    (TorchDimDist.py:127-162 + the model lambda under autograd)."""
+
+    @staticmethod
+    def forward(ctx, spec, value, a, *rest):
+        from . import engine as E
+        vd, term_dims, od, affine = spec
+        flat = [a.detach(), *[r.detach() for r in rest]]
+        terms, i = [], 0
+        for td_ in term_dims:
+            terms.append(tuple((flat[i + j], d) for j, d in enumerate(td_)))
+            i += len(td_)
+        out = E.bernoulli_linear_logprob((value.detach(), vd), terms, od, affine)
+        ctx.spec, ctx.terms, ctx.value = spec, terms, value.detach()
+        if out is None:
+            # (a shape the producer does not take: the same value through torch, laid out like od)
+            l, ids = _BernoulliLinear._logits(terms, (value.detach(), vd))
+            lp = t.nn.functional.logsigmoid(l) - (1.0 - pt_align(PT(value.detach(), vd), ids)) * l
+            keep = {id(d) for d in od}
+            red = [k for k, i in enumerate(ids) if i not in keep]
+            lp = lp.sum(red) if red else lp
+            left = [i for i in ids if i in keep]
+            lp = lp.permute(*[left.index(id(d)) for d in od]) if od else lp
+            out = t.add(affine[1], lp, alpha=affine[0]) if affine != (1.0, 0.0) else lp
+        return out
+
+    @staticmethod
+    def _logits(terms, value):
+        dims, ids = pt_order([PT(*value), *[PT(x, d) for tm in terms for x, d in tm]])
+        l = 0
+        for tm in terms:
+            if len(tm) == 1:
+                l = l + pt_align(PT(tm[0][0], tm[0][1]), ids)
+            else:
+                l = l + (pt_align(PT(tm[0][0], tm[0][1]), ids) * pt_align(PT(tm[1][0], tm[1][1]), ids)).sum(-1)
+        return l, ids
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, G):
+        from . import engine as E
+        vd, term_dims, od, affine = ctx.spec
+        g = E.bernoulli_linear_grad(G, (ctx.value, vd), ctx.terms, od, scale=affine[0])
+        if g is None:
+            # (shapes the gradient kernel does not take: the same formula through torch)
+            (a, ad), (b, bd) = ctx.terms[0]
+            l, ids = _BernoulliLinear._logits(ctx.terms, (ctx.value, vd))
+            c = pt_align(PT(G, od), ids) * affine[0] * (pt_align(PT(ctx.value, vd), ids) - t.sigmoid(l))
+            full = c.unsqueeze(-1) * pt_align(PT(b, bd), ids)
+            a_ids = {id(d) for d in ad}
+            red = [k for k, i in enumerate(ids) if i not in a_ids]
+            full = full.sum(red) if red else full
+            keep = [i for i in ids if i in a_ids]
+            perm = [keep.index(id(d)) for d in ad]
+            g = full.permute(*perm, len(perm)).expand(a.shape).contiguous()
+        return (None, None, g, *([None] * (len(ctx.needs_input_grad) - 3)))
+
+
 class _FusedBernoulliLogProb(t.autograd.Function):
     """sum log Bernoulli(value; logits) over the event dims and every first-class dim missing from the
     output (ONE HIP launch, alan_reduce mode BERNOULLI).  backward: d logits = G * (value - sigmoid(logits))
@@ -547,9 +608,21 @@ class TorchDimDist:
                     and not (t.is_grad_enabled() and x.x.requires_grad):
                 # logits = a sum of arguments and dot products of arguments: the producer computes them itself
                 from . import engine as E
-                out = E.bernoulli_linear_logprob((x.x, x.dims), _producer_terms(x, logits.terms), out_dims, ab)
-                if out is not None:
-                    return PT(out, out_dims)
+                if logits.grad is None:
+                    out = E.bernoulli_linear_logprob((x.x, x.dims), _producer_terms(x, logits.terms), out_dims, ab)
+                    if out is not None:
+                        return PT(out, out_dims)
+                else:
+                    # one operand carries a gradient: its term first, forward and backward both library launches
+                    terms = [logits.terms[logits.grad], *[tm for i, tm in enumerate(logits.terms) if i != logits.grad]]
+                    prod = _producer_terms(x, terms)
+                    target = terms[0][0]
+                    if len(prod[0]) == 2 and set(target.ids) == {id(d) for d in out_dims}:
+                        spec = (x.dims, tuple(tuple(d for _, d in tm) for tm in prod), out_dims, ab)
+                        flat = [tensor for tm in prod for tensor, _ in tm]
+                        out = _BernoulliLinear.apply(spec, x.x, target.x, *flat[1:])
+                        if out is not None:
+                            return PT(out, out_dims)
             spec = (x.dims, logits.dims, out_dims, ab)
             if not (t.is_grad_enabled() and (x.x.requires_grad or logits.x.requires_grad)):
                 from . import engine as E
@@ -834,6 +907,10 @@ def _scaled_form(fn):
     return c
 
 
+LINEAR_LOGITS_GRAD = True
+"""The same where ONE operand of the lambda carries a gradient (elbo_vi): the forward is the producer launch, the backward
+the library's gradient launch (dist._BernoulliLinear) instead of torch's batched GEMMs and elementwise kernels."""
+
 LINEAR_LOGITS = True
 """A model lambda that is a sum of its arguments and of dot products of them (``z @ x``,
 ``alpha + phi @ bus_company_name + psi @ run_type``) stays unevaluated where no gradient is wanted (dims.LinearPT): a
@@ -901,16 +978,25 @@ def _linear_pt(fn, named_args, form, dimcache):
     used = {i for k in form for i in k[1:]}
     if used != set(range(len(vals))):
         return None                               # (an unused argument still contributes its dims: leave that to torch)
-    for v in vals:
-        if not (v.x.is_cuda and v.x.dtype == t.float32) or (t.is_grad_enabled() and v.x.requires_grad):
+    grad = None
+    for i, v in enumerate(vals):
+        if not (v.x.is_cuda and v.x.dtype == t.float32):
             return None
+        if t.is_grad_enabled() and v.x.requires_grad:
+            # one operand may be attached to the autograd graph: the first operand of a dot term, used once (movielens'
+            # z in `z @ x` under elbo_vi) -- its gradient is the library's own launch (mode BERNOULLI_LINEAR_GRAD)
+            where = [ti for ti, k in enumerate(form) if k[0] == "dot" and k[1] == i]
+            uses = sum(k[1:].count(i) for k in form)
+            if not LINEAR_LOGITS_GRAD or grad is not None or len(where) != 1 or uses != 1:
+                return None
+            grad = where[0]
     seen, count = {}, {}
     for p in vals:
         for d, i in zip(p.dims, p.ids):
             seen.setdefault(i, d)
             count[i] = count.get(i, 0) + 1
     order = sorted(seen, key=lambda i: -count[i])                  # as _call_lambda_vmap lays its result out
-    return LinearPT(terms, [seen[i] for i in order], lambda: _call_lambda_vmap(fn, named_args, dimcache).x)
+    return LinearPT(terms, [seen[i] for i in order], lambda: _call_lambda_vmap(fn, named_args, dimcache).x, grad=grad)
 
 
 def _dot_pt(a, b):
@@ -968,7 +1054,7 @@ def call_model_lambda(fn, named_args, dimcache=None):
             # a constant multiple of one variable: lazy (dims.ScaledPT) -- a fused Normal producer takes it as the
             # location's scale field and the multiply launch never happens; anyone else reading .x gets c * v
             return ScaledPT(vals[0].x, c, vals[0].dims)
-    if LINEAR_LOGITS and LAMBDA_BACKEND == "vmap" and len(vals) >= 2 and all(type(v) is PT for v in vals):
+    if LINEAR_LOGITS and LAMBDA_BACKEND == "vmap" and len(vals) >= 2 and all(type(v) in (PT, ReparamPT) for v in vals):
         form = _linear_form(fn)
         if form is not None:
             lin = _linear_pt(fn, named_args, form, dimcache)

@@ -722,6 +722,51 @@ def bernoulli_linear_logprob(value, terms, out_dims, affine=(1.0, 0.0)):
     return out if ok else None
 
 
+def _linear_factors(value, terms):
+    """(factors, scales, dot tokens, tok) of a linear-logits launch: the value, then every term's operands tagged with
+    their term number (factor.scale), a dot term's two operands sharing one extra DOT dim."""
+    tok = _Tokens()
+    factors, scales, dots = [(value[0].detach(), tok.many(value[1]))], [1.0], []
+    for ti, term in enumerate(terms):
+        if len(term) == 1:
+            (x, d), = term
+            factors.append((x.detach(), tok.many(d)))
+        else:
+            e = tok(("_dot", ti))
+            dots.append(e)
+            for x, d in term:
+                factors.append((x.detach(), tok.many(d) + (e,)))
+        scales += [float(ti + 1)] * len(term)
+    return factors, scales, dots, tok
+
+
+def bernoulli_linear_grad(G, value, terms, out_dims, scale=1.0):
+    """Gradient of ``bernoulli_linear_logprob`` with respect to the FIRST operand of its FIRST term, which must be a dot
+    product (movielens' z in ``z @ x``): sum over the summed dims of G * (value - sigmoid(logits)) * b, one launch that
+    recomputes the logits (alan_reduce mode BERNOULLI_LINEAR_GRAD) -- what autograd derives from the lambda's batched
+    matmul and Bernoulli.log_prob.  Returns the gradient shaped like that operand, or None when the library declines."""
+    if len(terms[0]) != 2:
+        return None
+    factors, scales, dots, tok = _linear_factors(value, terms)
+    a, a_keys = factors[1]
+    if len(factors) > N.MAX_FACTORS or any(x.dtype != t.float32 for x, _ in factors) or G.dtype != t.float32:
+        return None
+    try:
+        sizes = _space(factors)
+    except Exception:
+        return None
+    if len(sizes) > N.MAX_DIMS:
+        return None
+    odims = tok.many(out_dims)
+    if set(a_keys[:-1]) != set(odims):
+        return None                                   # the operand must carry exactly the kept dims
+    roles = {d: (N.DOT if d in dots else N.KEEP if d in odims else N.REDUCE) for d in sizes}
+    out = t.empty(a.shape, dtype=t.float32, device=a.device)             # contiguous, dims ordered like the operand
+    ok = _launch(N.MODE_BERNOULLI_LINEAR_GRAD, factors, sizes, roles, out, a_keys, weight=(G.detach().contiguous(), odims),
+                 out_scale=float(scale), scales=scales)
+    return out if ok else None
+
+
 PRESUM_DIMS = {}         # slices -> the Dim that stands for "slice of a partial sum" (kept alive: contract() knows them by identity)
 
 

@@ -20,6 +20,7 @@ MODE_LSE, MODE_SUM, MODE_WEXPSUM, MODE_NORMAL, MODE_BERNOULLI, MODE_NORMAL_LOGSC
 MODE_PRODUCER_GRAD = 6
 MODE_BERNOULLI_LINEAR = 7
 MODE_DOT = 8
+MODE_BERNOULLI_LINEAR_GRAD = 9
 MODE_FUSED_FWD, MODE_FUSED_BWD = 100, 101      # (KernelTimer record tags of alan_normal_lse / _backward; not library modes)
 GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
 
@@ -294,9 +295,10 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     its other route."""
     L = lib()
     presum = any(desc.role[i] == PRESUM for i in range(desc.ndim))
-    if (desc.mode == MODE_BERNOULLI_LINEAR or presum) and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
+    lin_grad = desc.mode == MODE_BERNOULLI_LINEAR_GRAD
+    if (desc.mode == MODE_BERNOULLI_LINEAR or presum or lin_grad) and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
         return False
-    if (DEFER_SMALL_LAUNCHES and not presum and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
+    if (DEFER_SMALL_LAUNCHES and not presum and not lin_grad and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and not desc.ring_n
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
             and (not _Q.pending or _Q.pending[0][1] == device)):

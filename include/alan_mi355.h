@@ -95,9 +95,17 @@ typedef enum {
                               is sum over ONE ALAN_DOT dim of their product.  At most 3 terms; fp32 only
                               (ALAN_ERR_UNSUPPORTED otherwise: evaluate the logits and use ALAN_MODE_BERNOULLI).
                               out = out.scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const */
-    ALAN_MODE_DOT = 8      /* out = sum_R factor_0 * factor_1 (+ add_const): exactly 2 factors.  A term of such logits whose
+    ALAN_MODE_DOT = 8,     /* out = sum_R factor_0 * factor_1 (+ add_const): exactly 2 factors.  A term of such logits whose
                               operands lack some dim of the likelihood's index space, evaluated once (what the lambda's
                               `phi @ bus_company_name` is); small ones join alan_reduce_batch launches */
+    ALAN_MODE_BERNOULLI_LINEAR_GRAD = 9  /* backward of ALAN_MODE_BERNOULLI_LINEAR with respect to the FIRST operand `a`
+                              of its FIRST dot term (movielens: z of `z @ x`) -- what autograd derives from the lambda's
+                              batched matmul and TorchDimDist.py:127-162.  The forward's factors and roles unchanged;
+                              weight = the upstream gradient over the KEEP dims; out = the gradient, laid out over the
+                              KEEP dims and the DOT dim like `a` (out.scale = the forward's out.scale):
+                                  out[keep, e] = out.scale * sum_R weight[keep] * (value - sigmoid(l)) * b[..., e]
+                              `a` must carry every KEEP dim and no REDUCE dim, the dot at most 32 events
+                              (ALAN_ERR_UNSUPPORTED otherwise: the caller differentiates the lambda itself) */
 } alan_mode_t;
 /* Producer modes (NORMAL, NORMAL_LOGSCALE, BERNOULLI) write  out = out.scale * sum_R(log-prob) + add_const, so the
  * "-(log Q + log K)" of logpq.py:234-235 costs no extra pass; out.scale must be 1 in the other modes. */

@@ -277,3 +277,60 @@ def test_chain_terms_normal_rejects_malformed_descriptors():
                                               nbytes, None) == -1
     assert L.alan_chain_logmmexp_terms_normal(ptrs, strides, 1, None, 0, 1, 4, 3, None, None, ws.data_ptr(), nbytes,
                                               None) == -1
+
+
+@pytest.mark.parametrize("M,K,Nf,Ev,extra", [(300, 30, 5, 18, False), (300, 100, 5, 18, False), (7, 3, 5, 18, True), (33, 10, 1, 1, False),
+                                             (5, 4, 40, 3, True), (2, 2, 9, 32, False)])
+def test_linear_logits_gradient_launch_matches_autograd(M, K, Nf, Ev, extra):
+    """alan_reduce mode BERNOULLI_LINEAR_GRAD (engine.bernoulli_linear_grad): d / d z of sum_n log Bernoulli(obs; z . x
+    [+ a plain term]) weighted by a random upstream gradient, against fp64 autograd through the lambda's matmul and
+    torch.distributions; z stored [K, plate, event] (the sample's layout) or the other way round."""
+    g = t.Generator().manual_seed(M + K + Nf)
+    for z_dims in (("k", "m"), ("m", "k")):
+        shape = (K, M, Ev) if z_dims == ("k", "m") else (M, K, Ev)
+        z = t.randn(*shape, generator=g).to(DEV)
+        x = t.randn(M, Nf, Ev, generator=g).to(DEV)
+        obs = (t.rand(M, Nf, generator=g) < 0.4).float().to(DEV)
+        terms = [((z, z_dims), (x, ("m", "n")))]
+        if extra:
+            terms.append(((t.randn(M, generator=g).to(DEV), ("m",)),))
+        out_dims = z_dims
+        G = t.randn(*shape[:2], generator=g).to(DEV)
+        got = E.bernoulli_linear_grad(G, (obs, ("m", "n")), terms, out_dims, scale=-0.5)
+        assert got is not None and got.shape == z.shape
+        zr = z.double().requires_grad_(True)
+        rterms = [((zr, z_dims), (x, ("m", "n"))), *terms[1:]]
+        ref = _ref(obs, ("m", "n"), rterms, out_dims)
+        (want,) = t.autograd.grad((ref * G.double() * -0.5).sum(), [zr])
+        t.testing.assert_close(got.double(), want, rtol=2e-5, atol=2e-6 * float(want.abs().max()) + 1e-7)
+
+
+@pytest.mark.parametrize("fixture", ["e2e_movielens_K3.pt", "e2e_movielens_K10.pt"])
+def test_movielens_vi_gradients_with_the_logits_gradient_launch(fixture, monkeypatch):
+    """elbo_vi on movielens: the likelihood lambda `z @ x` and its gradient as library launches (dist.LINEAR_LOGITS_GRAD)
+    against the same through torch's batched GEMMs and autograd -- ELBO and every parameter gradient."""
+    from alan_amd import dist as D
+    fx = load_golden(fixture)
+    if fx["data"]["obs"][0].dtype != t.float32:
+        fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})
+
+    def run(flag):
+        monkeypatch.setattr(D, "LINEAR_LOGITS_GRAD", flag)
+        prob = models.BUILDERS["movielens"](fx).to(DEV)
+        t.manual_seed(5)
+        t.cuda.manual_seed_all(5)
+        calls = []
+        real = E.bernoulli_linear_grad
+        monkeypatch.setattr(E, "bernoulli_linear_grad", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        elbo = prob.sample(int(fixture.split("_K")[1].split(".")[0]), reparam=True).elbo_vi(alan.no_checkpoint)
+        elbo.backward()
+        monkeypatch.setattr(E, "bernoulli_linear_grad", real)
+        return float(elbo), {n: p.grad.detach().double().cpu().clone() for n, p in prob.named_parameters() if p.grad is not None}, len(calls)
+
+    e1, g1, n1 = run(True)
+    e0, g0, n0 = run(False)
+    assert n1 == 1 and n0 == 0
+    assert abs(e1 - e0) <= 1e-5 * abs(e0)
+    assert set(g1) == set(g0) and g1
+    for n in g0:
+        t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * float(g0[n].abs().max()) + 1e-7, msg=lambda m: f"{n}: {m}")
