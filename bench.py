@@ -631,6 +631,42 @@ def main():
                 del s2
             others[name] = per_k
         out["other_configs"] = others
+        # ---- the timeseries chain with its backward (row a10 for C5's shape): forward alone and forward + backward of
+        # logsumexp(chain_logmmexp(ms), -1) on a [T=1000, K, K] factor, each as a replayed graph
+        chain = {}
+        try:
+            from alan_amd.contract import chain_logmmexp_lse
+            for k2 in (30, 100):
+                ms = (-0.5 * t.randn(1000, k2, k2, device="cuda") ** 2 - 0.92 - math.log(k2)).requires_grad_(True)
+                gv = t.rand(k2, device="cuda")
+                rec = {}
+                for what, fn in (("forward_us", lambda: chain_logmmexp_lse(ms.detach())),
+                                 ("forward_backward_us", lambda: t.autograd.grad(chain_logmmexp_lse(ms), ms, gv))):
+                    side = t.cuda.Stream()
+                    side.wait_stream(t.cuda.current_stream())
+                    with t.cuda.stream(side):
+                        for _ in range(3):
+                            fn()
+                    t.cuda.current_stream().wait_stream(side)
+                    t.cuda.synchronize()
+                    gr = t.cuda.CUDAGraph()
+                    with t.cuda.graph(gr, stream=side):
+                        keep_ = fn()
+                    for _ in range(3):
+                        gr.replay()
+                    t.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        gr.replay()
+                    t.cuda.synchronize()
+                    rec[what] = (time.perf_counter() - t0) / 20 * 1e6
+                    del gr, keep_
+                rec["backward_us"] = rec["forward_backward_us"] - rec["forward_us"]
+                chain[f"K{k2}"] = rec
+                del ms
+        except Exception as e:
+            chain["error"] = f"{type(e).__name__}: {e}"
+        out["timeseries_chain_T1000"] = chain
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
