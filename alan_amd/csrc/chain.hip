@@ -42,12 +42,15 @@ struct ChainAdd {
     const T *nv, *nl, *ns;
     int64_t nvs[4], nls[4], nss[4];         // (sB, sT, sRow, sCol) of value / loc / scale
     T lmul;
+    const T *nl0;                           // optional location of step 0 (then step t >= 1 reads nl at t - 1)
+    int64_t nl0s[4];
 };
 
 template <typename T>
 __device__ __forceinline__ T chain_normal_term(const ChainAdd<T> &ad, int64_t b, int64_t t, int i, int j) {
     const T v = ad.nv[b * ad.nvs[0] + t * ad.nvs[1] + i * ad.nvs[2] + j * ad.nvs[3]];
-    const T l = ad.nl[b * ad.nls[0] + t * ad.nls[1] + i * ad.nls[2] + j * ad.nls[3]];
+    const T l = (ad.nl0 && t == 0) ? ad.nl0[b * ad.nl0s[0] + i * ad.nl0s[2] + j * ad.nl0s[3]]
+                                   : ad.nl[b * ad.nls[0] + (t - (ad.nl0 ? 1 : 0)) * ad.nls[1] + i * ad.nls[2] + j * ad.nls[3]];
     const T sc = ad.ns[b * ad.nss[0] + t * ad.nss[1] + i * ad.nss[2] + j * ad.nss[3]];
     const T z = v - ad.lmul * l;
     // torch.distributions.Normal.log_prob, as the producer kernels evaluate it (reduce.hip accumulate<NORMAL>)
@@ -732,11 +735,12 @@ __global__ __launch_bounds__(MAXT) void chain_wave_kernel(const float *ms, int64
                               c2 = (int)ad.sC[1];
                     // the Normal term's operands, likewise: uniform bases, 32-bit offsets
                     const float *qv = NORM ? ad.nv + b * ad.nvs[0] + tn * ad.nvs[1] : p0;
-                    const float *ql = NORM ? ad.nl + b * ad.nls[0] + tn * ad.nls[1] : p0;
+                    const bool first = NORM && ad.nl0 && tn == 0;                 // (the previous state of step 0: its own source)
+                    const float *ql = !NORM ? p0 : first ? ad.nl0 + b * ad.nl0s[0] : ad.nl + b * ad.nls[0] + (tn - (ad.nl0 ? 1 : 0)) * ad.nls[1];
                     const float *qs = NORM ? ad.ns + b * ad.nss[0] + tn * ad.nss[1] : p0;
                     // (host-checked: the value varies along the columns only, the location along the rows only -- a
                     // transition's x[t, k] and prev[t, k_init] -- so one of the two is fixed per lane)
-                    const int vc = (int)ad.nvs[3], lr = (int)ad.nls[2];
+                    const int vc = (int)ad.nvs[3], lr = first ? (int)ad.nl0s[2] : (int)ad.nls[2];
                     const int jc = j < K ? j : 0;
                     const float fixed = !NORM ? 0.f : rowwise ? ad.lmul * ql[jc * lr] : qv[jc * vc];
                     // (the scale does not vary inside a matrix -- the host checked: the usual scalar -- so its weight
@@ -889,6 +893,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         for (int q = 0; q < 4; ++q)
             ad0.nvs[q] = normal->v_stride[q], ad0.nls[q] = normal->l_stride[q], ad0.nss[q] = normal->s_stride[q];
         ad0.lmul = (T)normal->loc_mul;
+        ad0.nl0 = (const T *)normal->loc0;
+        for (int q = 0; q < 4; ++q) ad0.nl0s[q] = normal->loc0 ? normal->l0_stride[q] : 0;
     }
     for (int q = 0; q < n_more; ++q) {
         if (!more || !more[q] || !more_strides) return ALAN_ERR_BAD_DESC;
@@ -920,7 +926,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         // and its value along the columns only, its location along the rows only (one of them is then fixed per lane)
         if (normal)
             fits32 = fits32 && span(0, ad0.nvs[3]) && span(ad0.nls[2], 0) && ad0.nss[2] == 0 && ad0.nss[3] == 0 &&
-                     ad0.nvs[2] == 0 && ad0.nls[3] == 0;
+                     ad0.nvs[2] == 0 && ad0.nls[3] == 0 && (!ad0.nl0 || (span(ad0.nl0s[2], 0) && ad0.nl0s[3] == 0));
     }
     // (below K ~ 12 the vector-unit tree kernel is as fast or faster: a 32 x 32 MFMA tile is mostly padding there)
     if (K > 12 && K <= 32 && !per_round && !no_wave && fits32 && std::is_same<T, float>::value) {

@@ -411,15 +411,25 @@ int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStrea
 // (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
 // TorchDimDist.py:127-162).  A lane group per output element, lanes along the summed dims; each lane walks the dot
 // products of its element serially, all loads of up to 32 events in flight.
+// sum_e a[e] b[e] over `len` events: loads issued N at a time, in groups of four that are skipped (a scalar branch) when
+// they lie wholly beyond `len` -- an 18-event dot is 20 loads per operand in two round trips.
 template <int N>
 __device__ __forceinline__ float lin_dot(const float *pa, const float *pb, int len, int as, int bs) {
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int e0 = 0; e0 < len; e0 += N) {
         float av[N], bv[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int e = min(e0 + i, len - 1);
-            av[i] = pa[e * as], bv[i] = pb[e * bs];
+        for (int g = 0; g < N / 4; ++g) {
+            if (e0 + 4 * g < len) {
+#pragma unroll
+                for (int i = 4 * g; i < 4 * g + 4; ++i) {
+                    const int e = min(e0 + i, len - 1);
+                    av[i] = pa[e * as], bv[i] = pb[e * bs];
+                }
+            } else {
+#pragma unroll
+                for (int i = 4 * g; i < 4 * g + 4; ++i) av[i] = 0.f, bv[i] = 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < N; i += 4) {
@@ -507,11 +517,9 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
             const int len = d.len[tm], as = d.ads[tm], bs = d.bds[tm];
             // (every load of a chunk issued before the first product: the kernel is a chain of load latencies -- four
-            // products in flight made movielens' 18-event dot five round trips.  The chunk is the smallest of 4 / 8 / 16
-            // that holds the dot (16 at a time beyond): clamped loads past its length are wasted issue, and a chunk of 32
-            // cost the kernel half its waves per SIMD in registers -- bus_breakdown K = 100 ran twice as long)
-            xl += len <= 4 ? lin_dot<4>(pa, pb, len, as, bs) : len <= 8 ? lin_dot<8>(pa, pb, len, as, bs)
-                                                             : lin_dot<16>(pa, pb, len, as, bs);
+            // products in flight made movielens' 18-event dot five round trips.  16 at a time (groups of four beyond the
+            // length skipped): a chunk of 32 cost the kernel half its waves per SIMD in registers)
+            xl += lin_dot<16>(pa, pb, len, as, bs);
         }
         // logsigmoid(x) = min(x, 0) - log(1 + exp(-|x|)) on the fast transcendental instructions (1 ulp each; 1 + e in
         // (1, 2] is rounded as the reference's log1p argument is): the accurate expf / log1pf were two thirds of an element
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(256) void bernoulli_linear_grad_kernel(const LinDes
                 continue;
             }
             const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
-            xl += lin_dot<8>(pa, pb, d.len[tm], d.ads[tm], d.bds[tm]);
+            xl += lin_dot<16>(pa, pb, d.len[tm], d.ads[tm], d.bds[tm]);
         }
         // y - sigmoid(x), sigmoid on the fast transcendental instructions (rcp of 1 + 2^(-x log2 e))
         const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-xl * 1.44269504088896340736f));

@@ -15,7 +15,7 @@ import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ReparamPT, ScaledPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ReparamPT, ScaledPT, ShiftPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -434,6 +434,28 @@ class _OwnSampleLogProb(t.autograd.Function):
         return None, None, None, g * (-a) / scale
 
 
+def _peek(p):
+    """A tensor with the device, dtype, autograd state and shape of ``p.x`` that does not make a lazy PT evaluate."""
+    if isinstance(p, ShiftPT) and not p.materialised:
+        return p.rest
+    if isinstance(p, ScaledPT) and not p.materialised:
+        return _peek(p.src) if p._raw is None else p._raw
+    if isinstance(p, ExpPT) and not p.materialised:
+        return p.raw
+    return p.x
+
+
+def _lazy_shift(loc):
+    """The un-concatenated previous state behind a transition's location (a ShiftPT, or a constant multiple of one), or
+    None.  -> (ShiftPT, multiplier)"""
+    if isinstance(loc, ShiftPT) and not loc.materialised:
+        return loc, 1.0
+    if isinstance(loc, ScaledPT) and not loc.materialised and loc._raw is None and isinstance(loc.src, ShiftPT) \
+            and not loc.src.materialised:
+        return loc.src, loc.mul
+    return None
+
+
 class TorchDimDist:
     """A torch.distributions distribution whose parameters are torchdim tensors (or PTs)."""
 
@@ -570,6 +592,14 @@ class TorchDimDist:
             lazy = isinstance(scale, ExpPT) and not scale.materialised
             spec = (x.dims, loc.dims, scale.dims, out_dims, lazy, ab)
             sx = scale.raw if lazy else scale.x
+            shift = _lazy_shift(loc)
+            if shift is not None and unevaluated_ok and LAZY_TRANSITION and ab == (1.0, 0.0) and not drop \
+                    and not (t.is_grad_enabled() and (x.x.requires_grad or sx.requires_grad)) \
+                    and x.x.dtype == shift[0].rest.dtype == sx.dtype == t.float32:
+                # a timeseries transition whose previous state is still in its two pieces: the factor stays unevaluated,
+                # the pieces go to the chain's first round as they are (logpq._chain_of_terms)
+                return LazyNormalPT(PT(x.x.detach(), x.dims), shift[0], PT(sx.detach(), scale.dims), lazy, out_dims,
+                                    loc_mul=shift[1])
             lx = loc.raw if isinstance(loc, ScaledPT) and not loc.materialised else loc.x
             nograd = not (t.is_grad_enabled() and (x.x.requires_grad or lx.requires_grad or sx.requires_grad))
             vi, li, si = set(x.ids), set(loc.ids), set(scale.ids)
@@ -681,7 +711,9 @@ class TorchDimDist:
             sc = args[2]
             if isinstance(sc, ExpPT) and not sc.materialised:        # look at the raw parameter instead
                 args = (x, args[1], PT(sc.raw, sc.dims))
-            if isinstance(args[1], ScaledPT) and not args[1].materialised:
+            if _lazy_shift(args[1]) is not None:                     # (an un-concatenated previous state: look at its series)
+                args = (x, PT(_peek(args[1]), args[1].dims), args[2])
+            elif isinstance(args[1], ScaledPT) and not args[1].materialised:
                 args = (x, PT(args[1].raw, args[1].dims), args[2])
         elif self.dist is td.Bernoulli and set(self.kwargs) == {"logits"}:
             kind, args = "bernoulli", (x, self.kwargs["logits"])
@@ -1047,6 +1079,11 @@ def call_model_lambda(fn, named_args, dimcache=None):
         # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
         # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
         return ExpPT(vals[0].x, vals[0].dims)
+    if LAZY_SCALED and len(vals) == 1 and isinstance(vals[0], ShiftPT) and not vals[0].materialised \
+            and vals[0].rest.dtype == t.float32:
+        c = _scaled_form(fn)
+        if c is not None:                         # c * (the un-concatenated previous state): both stay as they are
+            return ScaledPT(None, c, vals[0].dims, src=vals[0])
     if LAZY_SCALED and len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_cuda and vals[0].x.dtype == t.float32 \
             and not (t.is_grad_enabled() and vals[0].x.requires_grad):
         c = _scaled_form(fn)

@@ -20,7 +20,7 @@ import torch as t
 import torch.utils.checkpoint
 
 from . import engine as E
-from .dims import PT, ExpPT, LazyNormalPT, PartialSumPT, pt_add, pt_align
+from .dims import PT, ExpPT, LazyNormalPT, PartialSumPT, ShiftPT, pt_add, pt_align
 from .model import Plate, tree_tensors, update_scope
 from .split import all_reduce_sum, no_checkpoint
 from .dist import TorchDimDist
@@ -141,8 +141,11 @@ def _chain_of_terms(lps, Ks, core):
     if any(lp.n_pos for lp in lps):
         return None
     xs = [lp.x for lp in lps]
-    if trans is not None and not all(p.x.is_cuda and p.x.dtype == xs[0].dtype for p in (trans.value, trans.loc, trans.scale)):
-        lps, xs, trans = [*lps, trans], [*xs, trans.x], None
+    # (the transition's location may be the un-concatenated previous state, dims.ShiftPT: looked at through its series)
+    shift = trans.loc if trans is not None and isinstance(trans.loc, ShiftPT) and not trans.loc.materialised else None
+    peek = lambda p: p.rest if p is shift else p.x
+    if trans is not None and not all(peek(p).is_cuda and peek(p).dtype == xs[0].dtype for p in (trans.value, trans.loc, trans.scale)):
+        lps, xs, trans, shift = [*lps, trans], [*xs, trans.x], None, None
     if not all(x.is_cuda and x.dtype == xs[0].dtype for x in xs) or xs[0].dtype not in (t.float32, t.float64):
         return None
     K = core[1].size
@@ -168,7 +171,14 @@ def _chain_of_terms(lps, Ks, core):
         return x if batch else x.unsqueeze(0)
 
     normal = None
-    if trans is not None:
+    if trans is not None and shift is not None:
+        # location = init at step 0, the series one step behind after it: two views, no concatenation
+        rest = view(PT(shift.rest, shift.dims))
+        lead = tuple(d for d in shift.dims if d is not core[0])
+        first = pt_align(PT(shift.first, lead), ids).expand([1 if i == id(core[0]) else n for i, n in zip(ids, shape)])
+        normal = (view(trans.value), rest, view(trans.scale), trans.loc_mul, trans.log_scale,
+                  first if batch else first.unsqueeze(0))
+    elif trans is not None:
         normal = (view(trans.value), view(trans.loc), view(trans.scale), trans.loc_mul, trans.log_scale)
     vec = N.chain_logmmexp_terms([view(lp) for lp in lps], normal)
     return PT(vec if batch else vec[0], (*batch, core[1]))

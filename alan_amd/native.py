@@ -71,7 +71,7 @@ class ReduceDesc(C.Structure):
 class ChainNormal(C.Structure):
     _fields_ = [("value", C.c_void_p), ("loc", C.c_void_p), ("scale", C.c_void_p),
                 ("v_stride", C.c_int64 * 4), ("l_stride", C.c_int64 * 4), ("s_stride", C.c_int64 * 4),
-                ("loc_mul", C.c_double), ("log_scale", C.c_int32)]
+                ("loc_mul", C.c_double), ("log_scale", C.c_int32), ("loc0", C.c_void_p), ("l0_stride", C.c_int64 * 4)]
 
 
 class BackwardDesc(C.Structure):
@@ -452,13 +452,22 @@ def chain_logmmexp_terms(terms, normal=None):
     strides = (C.c_int64 * (4 * len(terms)))(*[s for x in terms for s in x.stride()])
     nd = None
     if normal is not None:
-        v, l, sc, mul, log_scale = normal
-        assert all(x.shape == terms[0].shape and x.dtype == terms[0].dtype for x in (v, l, sc))
+        v, l, sc, mul, log_scale, *rest = normal
+        l0 = rest[0] if rest else None             # (the location of step 0: then `l` is read one step behind)
+        assert all(x.shape == terms[0].shape and x.dtype == terms[0].dtype for x in (v, sc))
+        assert l.dtype == terms[0].dtype and l.shape[0] == B and l.shape[2:] == terms[0].shape[2:] and \
+            l.shape[1] >= (T - 1 if l0 is not None else T)
         nd = ChainNormal()
         nd.value, nd.loc, nd.scale = v.data_ptr(), l.data_ptr(), sc.data_ptr()
         for q in range(4):
             nd.v_stride[q], nd.l_stride[q], nd.s_stride[q] = v.stride(q), l.stride(q), sc.stride(q)
         nd.loc_mul, nd.log_scale = float(mul), int(bool(log_scale))
+        if l0 is not None:
+            require_device(l0, "timeseries initial state")
+            assert l0.dtype == terms[0].dtype and l0.shape == (B, 1, *terms[0].shape[2:])
+            nd.loc0 = l0.data_ptr()
+            for q in range(4):
+                nd.l0_stride[q] = l0.stride(q)
     rc = L.alan_chain_logmmexp_terms_normal(ptrs, strides, len(terms), C.byref(nd) if nd is not None else None, code,
                                             B, T, K, None, vec.data_ptr(), tree.data_ptr(), nbytes, current_stream(device))
     check(rc, "alan_chain_logmmexp_terms_normal")

@@ -7,7 +7,7 @@ reference).  Sampling is sequential over T on the host; ``log_prob`` produces th
 import torch as t
 import torch.nn as nn
 
-from .dims import PT, Dim, dims_of
+from .dims import PT, ShiftPT, Dim, dims_of
 from .dist import _DistSpec
 
 
@@ -81,14 +81,17 @@ class Timeseries(nn.Module):
         assert T_dim not in idims and len(idims) + 1 == len(sdims)
         (Kinit,) = list(idims - sdims)
         # previous state: x_{t-1}, re-labelled onto K_init; x_0's predecessor is the initial state
-        shifted = sample.order(K_dim)[Kinit].order(T_dim)[:-1]
         lead = [d for d in dims_of(init)]
         init_pos = init.order(*lead)
-        shifted_pos = shifted.order(*lead)               # [*lead, T-1, ...]
-        prev = t.cat([init_pos.unsqueeze(len(lead)), shifted_pos], len(lead))
-        prev = prev[(*lead, T_dim)]
+        from . import dist as D
+        full_pos = sample.order(K_dim)[Kinit].order(*lead, T_dim)          # the series on K_init: [*lead, T, ...]
         scope = dict(scope)
-        scope["prev"] = PT.of(prev)
+        if D.LAZY_TRANSITION and full_pos.is_cuda and not (t.is_grad_enabled() and (full_pos.requires_grad or init_pos.requires_grad)):
+            # not concatenated: the chain's first round reads the two sources (dims.ShiftPT); anyone else gets the cat
+            scope["prev"] = ShiftPT(init_pos, full_pos, len(lead), (*lead, T_dim))
+        else:
+            prev = t.cat([init_pos.unsqueeze(len(lead)), full_pos.narrow(len(lead), 0, full_pos.shape[len(lead)] - 1)], len(lead))
+            scope["prev"] = PT(prev, (*lead, T_dim))
         scope[self.init] = PT.of(init)
         order = None
         if dim_order is not None:

@@ -204,10 +204,13 @@ def pmc_traffic(name, key):
     --pmc runs as MI355X_MICROARCH.md prescribes: profiles/<name>).  Counters cannot be read from inside this process;
     null when the committed profile does not cover this configuration."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name)))
-        return d[key]["traffic_bytes"]
+        for cand in (name.replace("r2_", "r3_"), name):
+            p = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(p):
+                return json.load(open(p))[key]["traffic_bytes"]
     except Exception:
-        return None
+        pass
+    return None
 
 
 def fused_pmc_traffic(K, backward=False):

@@ -288,12 +288,17 @@ int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, 
  * `ts ~ Normal(c * prev, scale)` (Timeseries.py:205-245 evaluating TorchDimDist.py:127-162 on the [T, K_init, K] cross
  * product): log N(value; loc_mul * loc, scale), each operand a [B, T, K_init, K] view given by four element strides
  * (0 where it lacks a dim: value = x[t, k] has no K_init stride, loc = prev[t, k_init] no K stride).  That factor --
- * 40 MB at T=1000, K=100 -- is then never written.  normal == NULL: alan_chain_logmmexp_terms. */
+ * 40 MB at T=1000, K=100 -- is then never written.  normal == NULL: alan_chain_logmmexp_terms.  With loc0 the
+ * location is the previous state without its concatenation: loc0 at step 0, loc shifted by one step after it. */
 typedef struct {
     const void *value, *loc, *scale;      /* dtype as the terms */
     int64_t v_stride[4], l_stride[4], s_stride[4];     /* (sB, sT, sRow, sCol) */
     double loc_mul;
     int32_t log_scale;                    /* `scale` holds log(scale) */
+    const void *loc0;                     /* optional: the location of step 0, a [B, K_init, K] view (l0_stride[1] unused);
+                                             steps t >= 1 then read `loc` at step t - 1.  What Timeseries.py:205-245 builds
+                                             as cat(init, x[:-1]) -- the previous state -- taken from its two sources */
+    int64_t l0_stride[4];
 } alan_chain_normal_t;
 int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
                                      const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T, int64_t K,

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the bench line plus the rocprofv3 evidence that profiles/r3_* is built from.
+#   gpurun --timeout 1100 -- 'bash tools/collect_r3.sh'
+# then, back in the container:  python tools/summarise_r3.py
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r3_raw
+rm -rf $O && mkdir -p $O
+timeout -k 10 500 python bench.py > $O/bench_full.json 2> $O/bench_full.err || { echo "bench failed"; tail -5 $O/bench_full.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --no-extras > $O/stats.log 2>&1 || { echo "stats failed"; exit 1; }
+for spec in "ml 30 200" "ml 100 50" "vi 30 100" "rws 30 100" "bus 30 200" "bus 100 50" "ts 30 200" "ts 100 50"; do
+  set -- $spec
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/case_$1_$2 --output-format csv -- python3 tools/prof_case.py $1 $2 $3 > $O/case_$1_$2.log 2>&1 || { echo "FAILED $spec"; tail -5 $O/case_$1_$2.log; exit 1; }
+  cp "$(find $O/case_$1_$2 -name '*kernel_stats.csv' | head -1)" $O/case_$1_$2_kernel_stats.csv
+  echo "$3" > $O/case_$1_$2.n
+done
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/fused_stats --output-format csv -- python3 tools/profile_fused.py > $O/fused_stats.log 2>&1 || { echo "fused stats failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch --output-format csv -- python3 tools/profile_fused.py > $O/pmc_fetch.log 2>&1 || { echo "pmc fetch failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write --output-format csv -- python3 tools/profile_fused.py > $O/pmc_write.log 2>&1 || { echo "pmc write failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_rows_fetch --output-format csv -- python3 tools/profile_rows.py > $O/pmc_rows_fetch.log 2>&1 || { echo "pmc rows fetch failed"; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_rows_write --output-format csv -- python3 tools/profile_rows.py > $O/pmc_rows_write.log 2>&1 || { echo "pmc rows write failed"; exit 1; }
+# the per-wave timeline of the fused plate step (diagnostic build: make -C alan_amd/csrc TIMELINE=1) and its SQ counters
+timeout -k 10 100 python3 tools/nlse_timeline.py 300 30 18 > $O/timeline_k30.txt 2>&1 || echo "timeline K=30 failed"
+timeout -k 10 100 python3 tools/nlse_timeline.py 300 100 18 > $O/timeline_k100.txt 2>&1 || echo "timeline K=100 failed"
+bash tools/pmc_nlse.sh 300 100 18 6 > $O/pmc_sq_k100.txt 2>&1 || echo "SQ counters K=100 failed"
+bash tools/pmc_nlse.sh 300 30 18 20 > $O/pmc_sq_k30.txt 2>&1 || echo "SQ counters K=30 failed"
+./tools/_build/mfma_bf16x3_probe > $O/mfma_bf16x3_probe.txt 2>&1 || echo "probe failed"
+# keep what the summariser reads, drop the bulky traces
+find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
+find $O -path "*case_*" -name "*kernel_trace.csv" -delete
+echo collected; ls $O | head -40

@@ -58,6 +58,21 @@ print(f"{'per unit, first tile landed -> last done':44s} {np.median(per_unit):9.
 print(f"wave entry after the first wave's: median {np.median(real0):.0f} ns, p90 {np.percentile(real0, 90):.0f}, last {real0.max():.0f}")
 print(f"wave exit  after the first wave's entry: median {np.median(real1):.0f} ns, p90 {np.percentile(real1, 90):.0f}, last {real1.max():.0f}  "
       f"(= the kernel's span seen from inside)")
+# where the waves ran: (XCC, shader engine, CU) from HW_REG_XCC_ID / HW_REG_HW_ID, and how a wave's pace depends on company
+hw = tl[:, 10]
+xcc, hwid = (hw >> 32) & 0xf, hw & 0xffffffff
+cu = (xcc << 12) | (((hwid >> 13) & 0x7) << 8) | (((hwid >> 12) & 0x1) << 4) | ((hwid >> 8) & 0xf)      # se_id, sh_id, cu_id
+simd = (hwid >> 4) & 0x3
+per_cu = {}
+for c in cu:
+    per_cu[int(c)] = per_cu.get(int(c), 0) + 1
+counts = np.array(sorted(per_cu.values()))
+print(f"CUs used: {len(per_cu)}; waves per CU: min {counts.min()}, median {int(np.median(counts))}, max {counts.max()}; "
+      f"histogram " + ", ".join(f"{v} waves: {int((counts == v).sum())} CUs" for v in sorted(set(counts.tolist()))))
+company = np.array([per_cu[int(c)] for c in cu])
+for v in sorted(set(company.tolist())):
+    sel = company == v
+    print(f"  waves on a CU holding {v} of this launch's waves: {int(sel.sum())}, per unit median {np.median(per_unit[sel]):.0f} ns, lifetime median {np.median(life[sel]):.0f} ns")
 late = real0 > 1500
 print(f"waves entering more than 1.5 us after the first: {int(late.sum())} of {len(tl)} (a second round of workgroups)")
 hist, edges = np.histogram(real0, bins=12)

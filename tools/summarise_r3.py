@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/r3_raw/ (written on the GPU box by tools/collect_r3.sh) into the tracked round-3 summaries under
+profiles/:  r3_bench.json (the bench line), r3_bench_default_kernel_stats.{csv,md} (rocprofv3 --kernel-trace --stats of
+`python3 bench.py --no-extras`), r3_cases_kernel_stats.md (per-evaluation kernel budgets of the other workloads),
+r3_fused_kernel_pmc.{json,md} and r3_rows_kernel_pmc.{json,md} (FETCH_SIZE / WRITE_SIZE passes, corrected as
+MI355X_MICROARCH.md prescribes: separate --pmc runs, FETCH_SIZE doubled for wide coalesced reads)."""
+import csv, glob, json, os, shutil, io, contextlib, subprocess, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "r3_raw")
+OUT = os.path.join(ROOT, "profiles")
+csv.field_size_limit(1 << 30)
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(RAW, pattern), recursive=True)
+    assert hits, pattern
+    return max(hits, key=os.path.getmtime)        # (gpurun merges into the local copy: older collections may linger)
+
+
+bench = json.load(open(os.path.join(RAW, "bench_full.json")))
+json.dump(bench, open(os.path.join(OUT, "r3_bench.json"), "w"), indent=1)
+
+# ---- kernel stats of the default bench run
+src = one("stats/**/*kernel_stats.csv")
+shutil.copy(src, os.path.join(OUT, "r3_bench_default_kernel_stats.csv"))
+rows = list(csv.DictReader(open(src)))
+evals = max(int(r["Calls"]) for r in rows if "normal_lse_x3_kernel" in r["Name"])
+with open(os.path.join(OUT, "r3_bench_default_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extras` (round 3)\n\n"
+            "Full CSV: `r3_bench_default_kernel_stats.csv`.  Kernel names truncated.  The run evaluates the movielens K=30 "
+            f"ELBO {evals} times (warm-up, capture, 5 + 50 graph replays, then 50 eager for the per-kernel HIP events).\n\n"
+            "| kernel | calls | per eval | avg us | % |\n|---|---|---|---|---|\n")
+    for r in rows:
+        calls = int(r["Calls"])
+        if calls < evals // 4:
+            continue
+        f.write(f"| `{r['Name'][:100]}` | {calls} | {calls / evals:.1f} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |\n")
+    fk = [r for r in rows if "normal_lse_x3_kernel" in r["Name"]][0]
+    f.write(f"\n`alan::normal_lse_x3_kernel` (the dominant kernel: the fused plate step) averages "
+            f"{float(fk['AverageNs']) / 1e3:.1f} us in this trace; bench.py's live HIP-event measurement of the same launches "
+            f"(`r3_bench.json`, a separate process on the same box, hipExtLaunchKernelGGL start/stop events) gives "
+            f"{bench['roofline']['us_per_launch']:.1f} us.\n")
+
+# ---- the other workloads
+with open(os.path.join(OUT, "r3_cases_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats of `python3 tools/prof_case.py <case> <K> <n>` (round 3)\n\n"
+            "Graph replays (warm-up and capture included in the launch counts, hence the fractional launches per "
+            "evaluation).  ml = movielens elbo_nograd (K=100: Split('plate_1', 38), the rank's chunks as one slice), vi / rws "
+            "= one training iteration (sample -> elbo -> backward -> Adam), bus = bus_breakdown, ts = timeseries T=1000.\n\n")
+    for path in sorted(glob.glob(os.path.join(RAW, "case_*_kernel_stats.csv"))):
+        tag = os.path.basename(path)[len("case_"):-len("_kernel_stats.csv")]
+        n = int(open(os.path.join(RAW, f"case_{tag}.n")).read())
+        extra = 3 if tag.startswith(("vi", "rws")) else 6           # warm-up + capture passes
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kstats2.py"), path, str(n + extra), tag.replace("_", " K=")],
+                             capture_output=True, text=True).stdout
+        f.write(out + "\n")
+
+
+# ---- PMC passes
+def pmc(which, counter, match):
+    path = one(f"{which}/**/*counter_collection.csv")
+    acc = defaultdict(lambda: [0.0, 0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or not any(m in r["Kernel_Name"] for m in match):
+            continue
+        key = (r["Kernel_Name"].replace("void ", "").split("(")[0], int(r["Grid_Size"]))
+        a = acc[key]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+        a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return {k: (v[0] / v[1], v[1], v[2] / v[1]) for k, v in acc.items()}
+
+
+note = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); FETCH_SIZE doubled per "
+        "MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream -- calibrated for 16-byte-per-lane reads; the "
+        "fused kernels read 4 bytes per lane, so their absolute read figure is indicative only); KiB -> bytes")
+match = ("normal_lse_x3_kernel", "normal_lse_bwd_kernel")
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE", match), pmc("pmc_write", "WRITE_SIZE", match)
+res = {"source": note + " -- python3 tools/profile_fused.py", "kernels": {}}
+md = ["# HBM traffic of the fused plate step (round 3)\n", note + ".\n",
+      "| kernel | grid | launches | avg us | 2 x FETCH_SIZE (MB) | WRITE_SIZE (MB) | what it replaces |\n|---|---|---|---|---|---|---|"]
+sizes = {30: 4 * 300 * 30 ** 3, 100: 4 * 300 * 100 ** 3}
+for k in sorted(fetch, key=lambda k: (k[0], k[1])):
+    fb, n, us = fetch[k][0] * 1024 * 2, fetch[k][1], fetch[k][2]
+    wb = write.get(k, (0, 0, 0))[0] * 1024
+    K = 100 if us > 100 else 30                 # (profile_fused.py runs exactly two sizes: K=30 and K=100, M=300)
+    res["kernels"][f"{k[0]} grid {k[1]}"] = {"fetch_bytes": fb, "write_bytes": wb, "traffic_bytes": fb + wb, "launches": n,
+                                             "mean_duration_us": us, "factor_bytes_never_materialised": sizes[K]}
+    md.append(f"| `{k[0]}` | {k[1]} | {n} | {us:.1f} | {fb / 1e6:.2f} | {wb / 1e6:.2f} | a {sizes[K] / 1e6:.0f} MB factor written once and read once |")
+json.dump(res, open(os.path.join(OUT, "r3_fused_kernel_pmc.json"), "w"), indent=1)
+open(os.path.join(OUT, "r3_fused_kernel_pmc.md"), "w").write("\n".join(md) + "\n")
+
+fetch, write = pmc("pmc_rows_fetch", "FETCH_SIZE", ("rows_kernel",)), pmc("pmc_rows_write", "WRITE_SIZE", ("rows_kernel",))
+K, lit_M, big_M = 30, 300, 19200
+algo = {m: 4 * (m * K ** 3 + m * K + K * K) for m in (lit_M, big_M)}
+keys = sorted(fetch, key=lambda k: k[1])
+assert len(keys) == 2, keys
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 "
+                 "tools/profile_rows.py; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide "
+                 "coalesced stream); KiB -> bytes", "kernel": keys[0][0]}
+for name, k, m in (("literal_K30_M300", keys[0], lit_M), ("scaled_K30_M19200", keys[1], big_M)):
+    fb, wb = fetch[k][0] * 1024 * 2, write[k][0] * 1024
+    res[name] = {"fetch_bytes": fb, "write_bytes": wb, "algorithmic_bytes": algo[m], "traffic_bytes": fb + wb,
+                 "traffic_over_algorithmic": (fb + wb) / algo[m], "mean_duration_us": fetch[k][2]}
+json.dump(res, open(os.path.join(OUT, "r3_rows_kernel_pmc.json"), "w"), indent=1)
+with open(os.path.join(OUT, "r3_rows_kernel_pmc.md"), "w") as f:
+    f.write("# HBM traffic of the reduce_Ks kernel (rows.hip) on a materialised S-ML factor (round 3)\n\n" + res["source"] + ".\n\n"
+            "| case | algorithmic MB | 2 x FETCH_SIZE MB | WRITE_SIZE MB | traffic / algorithmic | avg us (profiled) |\n|---|---|---|---|---|---|\n")
+    for name in ("literal_K30_M300", "scaled_K30_M19200"):
+        r = res[name]
+        f.write(f"| {name} | {r['algorithmic_bytes'] / 1e6:.1f} | {r['fetch_bytes'] / 1e6:.1f} | {r['write_bytes'] / 1e6:.2f} | "
+                f"{r['traffic_over_algorithmic']:.3f} | {r['mean_duration_us']:.1f} |\n")
+# ---- the fused forward kernel's per-wave timeline, SQ counters, the bf16x3 probe
+for src, dst, head in (("timeline_k30.txt", "r3_timeline_K30.txt", "# python3 tools/nlse_timeline.py 300 30 18 (diagnostic build, make TIMELINE=1): where a wave of the K=30 launch spends its life\n"),
+                       ("timeline_k100.txt", "r3_timeline_K100.txt", "# python3 tools/nlse_timeline.py 300 100 18\n"),
+                       ("mfma_bf16x3_probe.txt", "r3_mfma_bf16x3_probe.txt", "# tools/mfma_bf16x3_probe.hip: numerics and cycles of the bf16x3 tile (f32 path: 442 ns per tile per SIMD)\n")):
+    p = os.path.join(RAW, src)
+    if os.path.exists(p):
+        body = "".join(l for l in open(p) if "amdgpu.ids" not in l)
+        open(os.path.join(OUT, dst), "w").write(head + body)
+for k in (30, 100):
+    p = os.path.join(ROOT, "gpurun_out", f"pmc_nlse_300_{k}", "summary.md")
+    if os.path.exists(p):
+        open(os.path.join(OUT, f"r3_fused_forward_sq_counters_K{k}.md"), "w").write(
+            f"# SQ counters of alan::normal_lse_x3_kernel at M=300, K={k}, E=18 (rocprofv3 --pmc, three passes, no tracing domains; tools/pmc_nlse.sh)\n\n"
+            "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES and "
+            "SQ_VALU_MFMA_BUSY_CYCLES count cycles.\n\n" + open(p).read())
+print("profiles/ written:", sorted(x for x in os.listdir(OUT) if x.startswith("r3_")))
