@@ -70,6 +70,17 @@ struct LinDesc {
     int32_t gks[LIN_NK], ods;
 };
 
+// Several INDEPENDENT small problems in one launch (alan_reduce_batch): the per-variable log-prob producers of a
+// plate are a handful of launch-latency-bound kernels (4-5 us each inside a replayed graph) that do not depend on
+// each other.  Workgroups are dealt to the problems in order; mode and lane-group shape are run-time here.
+struct SmallMulti {
+    int32_t n;
+    int32_t mode[SMALL_MULTI], logG[SMALL_MULTI], block[SMALL_MULTI];
+    uint32_t first_block[SMALL_MULTI + 1];
+    SmallDesc d[SMALL_MULTI];
+    LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
+};
+
 // Kernel argument of the small log-sum-exp + plate-sum kernel: out[keep] = sum_plate LSE_red(sum_f factor_f) + add_const
 // in ONE launch (reduce_Ks.py:249-251 then logpq.py:149) for problems too small for the rows kernel -- a lane group per
 // output walks the plate elements one after the other.  fp32, 32-bit offsets, <= SP_NK keep, SP_NP plate, SP_NR reduce dims.
@@ -140,6 +151,8 @@ int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype
 // `lin`: the LinDesc of the (at most one) problem whose mode[] entry is ALAN_MODE_BERNOULLI_LINEAR; its sd[] slot is unused
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
                        const LinDesc *lin = nullptr);
+// (its kernel argument alone; returns the number of workgroups the problems take together)
+uint32_t fill_small_multi(SmallMulti &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, const LinDesc *lin);
 int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);
 int launch_lin_grad(const LinDesc &ld, hipStream_t stream, const EvPair &ev);
 

@@ -18,108 +18,10 @@
 #include <cstddef>
 
 #include "plan.h"
+#include "small_device.h"
 
 namespace alan {
 
-// ------------------------------------------------------------------------------------------
-// One element of the reduce index: the mode's term from the loaded factor values (shared by both kernels).
-template <typename T, int MODE>
-__device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T wv, const float (&scale)[MAXF],
-                                           int nf, bool ok) {
-    if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE) {
-        // torch.distributions.Normal.log_prob: -(v-loc)^2/(2 var) - log(scale) - log(sqrt(2 pi));
-        // one term per (value, loc, scale) triple, weighted by the value factor's scale field
-        T lp = T(0);
-#pragma unroll
-        for (int tm = 0; tm < MAXF / 3; ++tm) {
-            if (3 * tm < nf) {
-                const T z = val[3 * tm] - (T)scale[3 * tm + 1] * val[3 * tm + 1];      // (loc's scale field: loc = c * raw)
-                const T sc = val[3 * tm + 2];
-                const bool logsc = MODE == ALAN_MODE_NORMAL_LOGSCALE || scale[3 * tm + 2] == 2.f;
-                const T one = logsc
-                    ? -(z * z) * (T(0.5) * Num<T>::exp_acc(T(-2) * sc)) - sc - T(0.91893853320467274178)
-                    : -(z * z) / (T(2) * sc * sc) - Num<T>::log(sc) - T(0.91893853320467274178);
-                lp += (T)scale[3 * tm] * one;
-            }
-        }
-        s += ok ? lp : T(0);
-    } else if (MODE == ALAN_MODE_PRODUCER_GRAD) {
-        // G * d log-prob / d (one argument); which argument is a launch-uniform switch (factor 0's scale field)
-        const int kind = (int)scale[0];
-        const T g = val[0];
-        T r;
-        if (kind == 4) {
-            const T xl = val[2];
-            const T sg = T(1) / (T(1) + Num<T>::exp_acc(-xl));             // d/dx [logsigmoid(x) - (1 - y) x] = y - sigmoid(x)
-            r = g * (val[1] - sg);
-        } else {
-            const T z = val[1] - val[2], sc = val[3];
-            const bool logsc = scale[3] == 2.f;
-            const T w = logsc ? Num<T>::exp_acc(T(-2) * sc) : T(1) / (sc * sc);  // 1 / scale^2
-            if (kind == 1)
-                r = -g * z * w;
-            else if (kind == 2)
-                r = g * z * w;
-            else
-                r = logsc ? g * (z * z * w - T(1)) : g * (z * z * w - T(1)) / sc;
-        }
-        s += ok ? r : T(0);
-    } else if (MODE == ALAN_MODE_BERNOULLI) {
-        // torch.distributions.Bernoulli.log_prob = -BCE_with_logits = logsigmoid(x) - (1 - y) x,
-        // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
-        const T y = val[0], xl = val[1];
-        const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
-        s += ok ? ls - (T(1) - y) * xl : T(0);
-    } else if (MODE == ALAN_MODE_DOT) {
-        s += ok ? val[0] * val[1] : T(0);
-    } else {
-        T x = T(0);
-#pragma unroll
-        for (int f = 0; f < MAXF; ++f)
-            if (f < nf) x += (T)scale[f] * val[f];
-        if (MODE == ALAN_MODE_LSE) {
-            if (ok) lse_push(m, s, x);
-        } else if (MODE == ALAN_MODE_SUM) {
-            s += ok ? x : T(0);
-        } else {
-            s += ok ? wv * Num<T>::exp(x) : T(0);
-        }
-    }
-}
-
-// Lanes of a group (or the 4 waves of a block) -> one value.
-template <typename T, int MODE, bool BLOCK>
-__device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
-    const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
-    if (MODE == ALAN_MODE_LSE) {
-        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) {
-            const T m2 = __shfl_xor(m, (int)ofs);
-            const T s2 = __shfl_xor(s, (int)ofs);
-            lse_merge(m, s, m2, s2);
-        }
-    } else {
-        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
-    }
-    if (BLOCK) {
-        __shared__ T sm[4], ss[4];
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            sm[wv] = m;
-            ss[wv] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            m = sm[0];
-            s = ss[0];
-            for (int i = 1; i < 4; ++i) {
-                if (MODE == ALAN_MODE_LSE)
-                    lse_merge(m, s, sm[i], ss[i]);
-                else
-                    s += ss[i];
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool BLOCK>
@@ -218,107 +120,6 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(const GroupDesc d, co
     }
 }
 
-// ------------------------------------------------------------------------------------------
-template <int MODE, bool BLOCK>
-__device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id) {
-    typedef float T;
-    const uint32_t G = BLOCK ? 256u : (1u << logG);
-    uint32_t grp, gl;
-    if (BLOCK) {
-        grp = block_id;
-        gl = threadIdx.x;
-    } else {
-        const uint32_t gid = block_id * 256u + threadIdx.x;
-        grp = gid >> logG;
-        gl = gid & (G - 1u);
-    }
-    const bool active = grp < d.n_out;
-    uint32_t o = active ? grp : d.n_out - 1u;
-
-    int32_t base[MAXF], wbase = 0, obase = 0;
-#pragma unroll
-    for (int f = 0; f < MAXF; ++f) base[f] = 0;
-#pragma unroll
-    for (int k = SMALL_NK - 1; k >= 0; --k) {
-        const uint32_t q = fd_div(o, d.kdiv[k]);
-        const int32_t idx = (int32_t)(o - q * d.kdiv[k].d);
-        o = q;
-#pragma unroll
-        for (int f = 0; f < MAXF; ++f) base[f] += idx * d.fks[f][k];
-        if (MODE == ALAN_MODE_WEXPSUM) wbase += idx * d.wks[k];
-        obase += idx * d.oks[k];
-    }
-    float sc[MAXF];
-#pragma unroll
-    for (int f = 0; f < MAXF; ++f) sc[f] = d.fscale[f];
-
-    constexpr int UNR = 4;
-    T m = Num<T>::ninf(), s = T(0);
-    for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
-        T val[UNR][MAXF];
-        T wv[UNR];
-        int32_t off0[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const uint32_t ru = r0 + (uint32_t)u * G;
-            uint32_t rr = ru < d.n_red ? ru : r0;     // clamped: the slot is masked in accumulate()
-            int32_t off[MAXF], woff = wbase;
-#pragma unroll
-            for (int f = 0; f < MAXF; ++f) off[f] = base[f];
-#pragma unroll
-            for (int k = SMALL_NR - 1; k >= 0; --k) {
-                const uint32_t q = fd_div(rr, d.rdiv[k]);
-                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
-                rr = q;
-#pragma unroll
-                for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
-                if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.wrs[k];
-            }
-            // unused factor slots alias factor 0 with zero strides: the load is harmless and never used
-#pragma unroll
-            for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];
-            wv[u] = MODE == ALAN_MODE_WEXPSUM ? d.w[woff] : 0.f;
-            off0[u] = off[0];
-        }
-        if ((MODE == ALAN_MODE_LSE || MODE == ALAN_MODE_SUM) && d.presum_n > 1) {
-            // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, eight loads per element in
-            // flight, added in slice order
-            constexpr int PF = 8;                     // (more costs every small kernel registers: 16 took them to 5 waves per SIMD)
-            for (int32_t c0 = 1; c0 < d.presum_n; c0 += PF) {
-                T part[UNR][PF];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                    for (int i = 0; i < PF; ++i) {
-                        const int32_t c = c0 + i < d.presum_n ? c0 + i : 0;
-                        part[u][i] = d.f[0][off0[u] + c * d.presum_stride];
-                    }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                    for (int i = 0; i < PF; ++i) val[u][0] += c0 + i < d.presum_n ? part[u][i] : T(0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
-    }
-    combine_lanes<T, MODE, BLOCK>(m, s, G);
-    if (active && gl == 0) {
-        T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
-        if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI ||
-            MODE == ALAN_MODE_PRODUCER_GRAD)
-            v *= d.out_scale;
-        if (d.ring_n) {
-            // one workgroup, one value (try_launch_small checked): deliver it to this replay's slot and move on
-            const int32_t slot = *d.ring_counter;
-            *d.ring_slots[slot] = v + d.add_const;
-            *d.ring_counter = slot + 1 == d.ring_n ? 0 : slot + 1;
-        } else {
-            d.out[obase] = v + d.add_const;
-        }
-    }
-}
 
 template <int MODE, bool BLOCK>
 __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, const int logG) {
@@ -405,131 +206,6 @@ int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStrea
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
-// ------------------------------------------------------------------------------------------
-// ALAN_MODE_BERNOULLI_LINEAR: the Bernoulli producer with its logits computed on the fly,
-//   l = sum_t ( a_t  |  sum_e a_t[e] * b_t[e] ),     out = out_scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const
-// (what the model's lambda -- `z @ x` -- and td.Bernoulli.log_prob evaluate as a batched GEMM, adds and a producer launch,
-// TorchDimDist.py:127-162).  A lane group per output element, lanes along the summed dims; each lane walks the dot
-// products of its element serially, all loads of up to 32 events in flight.
-// sum_e a[e] b[e] over `len` events: loads issued N at a time, in groups of four that are skipped (a scalar branch) when
-// they lie wholly beyond `len` -- an 18-event dot is 20 loads per operand in two round trips.
-template <int N>
-__device__ __forceinline__ float lin_dot(const float *pa, const float *pb, int len, int as, int bs) {
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (int e0 = 0; e0 < len; e0 += N) {
-        float av[N], bv[N];
-#pragma unroll
-        for (int g = 0; g < N / 4; ++g) {
-            if (e0 + 4 * g < len) {
-#pragma unroll
-                for (int i = 4 * g; i < 4 * g + 4; ++i) {
-                    const int e = min(e0 + i, len - 1);
-                    av[i] = pa[e * as], bv[i] = pb[e * bs];
-                }
-            } else {
-#pragma unroll
-                for (int i = 4 * g; i < 4 * g + 4; ++i) av[i] = 0.f, bv[i] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < N; i += 4) {
-            acc0 = fmaf(e0 + i + 0 < len ? av[i + 0] : 0.f, bv[i + 0], acc0);
-            acc1 = fmaf(e0 + i + 1 < len ? av[i + 1] : 0.f, bv[i + 1], acc1);
-            acc2 = fmaf(e0 + i + 2 < len ? av[i + 2] : 0.f, bv[i + 2], acc2);
-            acc3 = fmaf(e0 + i + 3 < len ? av[i + 3] : 0.f, bv[i + 3], acc3);
-        }
-    }
-    return (acc0 + acc1) + (acc2 + acc3);
-}
-
-template <bool BLOCK>
-__device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const uint32_t block_id) {
-    const uint32_t G = BLOCK ? 256u : (1u << logG);
-    uint32_t grp, gl;
-    if (BLOCK) {
-        grp = block_id;
-        gl = threadIdx.x;
-    } else {
-        const uint32_t gid = block_id * 256u + threadIdx.x;
-        grp = gid >> logG;
-        gl = gid & (G - 1u);
-    }
-    const bool active = grp < d.n_out;
-    uint32_t o = active ? grp : d.n_out - 1u;
-    int32_t abase[LIN_T], bbase[LIN_T], vbase = 0, obase = 0;
-#pragma unroll
-    for (int tm = 0; tm < LIN_T; ++tm) abase[tm] = bbase[tm] = 0;
-#pragma unroll
-    for (int k = LIN_NK - 1; k >= 0; --k) {
-        const uint32_t q = fd_div(o, d.kdiv[k]);
-        const int32_t idx = (int32_t)(o - q * d.kdiv[k].d);
-        o = q;
-#pragma unroll
-        for (int tm = 0; tm < LIN_T; ++tm) {
-            abase[tm] += idx * d.aks[tm][k];
-            bbase[tm] += idx * d.bks[tm][k];
-        }
-        vbase += idx * d.vks[k];
-        obase += idx * d.oks[k];
-    }
-    float s = 0.f, m = 0.f;
-    // one summed dim (bus_breakdown's plate of 150 observations): offsets are linear in r -- no index decomposition per
-    // element (it was a third of the instructions of an element at K = 100: 9 M elements)
-    const bool one_dim = d.rdiv[0].d == 1;
-    for (uint32_t r = gl; r < d.n_red; r += G) {
-        int32_t aoff[LIN_T], boff[LIN_T], voff = vbase;
-#pragma unroll
-        for (int tm = 0; tm < LIN_T; ++tm) {
-            aoff[tm] = abase[tm];
-            boff[tm] = bbase[tm];
-        }
-        if (one_dim) {
-#pragma unroll
-            for (int tm = 0; tm < LIN_T; ++tm) {
-                aoff[tm] += (int32_t)r * d.ars[tm][LIN_NR - 1];
-                boff[tm] += (int32_t)r * d.brs[tm][LIN_NR - 1];
-            }
-            voff += (int32_t)r * d.vrs[LIN_NR - 1];
-        } else {
-            uint32_t rr = r;
-#pragma unroll
-            for (int k = LIN_NR - 1; k >= 0; --k) {
-                const uint32_t q = fd_div(rr, d.rdiv[k]);
-                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
-                rr = q;
-#pragma unroll
-                for (int tm = 0; tm < LIN_T; ++tm) {
-                    aoff[tm] += idx * d.ars[tm][k];
-                    boff[tm] += idx * d.brs[tm][k];
-                }
-                voff += idx * d.vrs[k];
-            }
-        }
-        const float y = d.val[voff];
-        float xl = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < LIN_T; ++tm) {
-            if (tm >= d.nt) continue;
-            if (d.b[tm] == nullptr) {
-                xl += d.a[tm][aoff[tm]];
-                continue;
-            }
-            const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
-            const int len = d.len[tm], as = d.ads[tm], bs = d.bds[tm];
-            // (every load of a chunk issued before the first product: the kernel is a chain of load latencies -- four
-            // products in flight made movielens' 18-event dot five round trips.  16 at a time (groups of four beyond the
-            // length skipped): a chunk of 32 cost the kernel half its waves per SIMD in registers)
-            xl += lin_dot<16>(pa, pb, len, as, bs);
-        }
-        // logsigmoid(x) = min(x, 0) - log(1 + exp(-|x|)) on the fast transcendental instructions (1 ulp each; 1 + e in
-        // (1, 2] is rounded as the reference's log1p argument is): the accurate expf / log1pf were two thirds of an element
-        const float e = __builtin_amdgcn_exp2f(-fabsf(xl) * 1.44269504088896340736f);
-        const float ls = fminf(xl, 0.f) - __builtin_amdgcn_logf(1.f + e) * 0.69314718055994530942f;
-        s += ls - (1.f - y) * xl;
-    }
-    combine_lanes<float, ALAN_MODE_SUM, BLOCK>(m, s, G);
-    if (active && gl == 0) d.out[obase] = s * d.out_scale + d.add_const;
-}
 
 template <bool BLOCK>
 __global__ __launch_bounds__(256) void bernoulli_linear_kernel(const LinDesc d, const int logG) {
@@ -635,62 +311,12 @@ int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, con
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
-// Several INDEPENDENT small problems in one launch (alan_reduce_batch): the per-variable log-prob producers of a
-// plate are a handful of launch-latency-bound kernels (4-5 us each inside a replayed graph) that do not depend on
-// each other.  Workgroups are dealt to the problems in order; mode and lane-group shape are run-time here.
-struct SmallMulti {
-    int32_t n;
-    int32_t mode[SMALL_MULTI], logG[SMALL_MULTI], block[SMALL_MULTI];
-    uint32_t first_block[SMALL_MULTI + 1];
-    SmallDesc d[SMALL_MULTI];
-    LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
-};
-
-template <int MODE>
-__device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool block, uint32_t bid) {
-    if (block)
-        small_body<MODE, true>(d, 8, bid);
-    else
-        small_body<MODE, false>(d, logG, bid);
-}
 
 __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMulti m) {
-    int p = 0;
-    while (p + 1 < m.n && blockIdx.x >= m.first_block[p + 1]) ++p;       // workgroup-uniform
-    const uint32_t bid = blockIdx.x - m.first_block[p];
-    // m.d[p] through the kernel-argument segment itself (scalar loads at a uniform offset): indexing the by-value
-    // struct with a run-time p makes the compiler copy all of it to scratch first
-    typedef __attribute__((address_space(4))) const char *kernarg_ptr;
-    const SmallDesc &d = *reinterpret_cast<const SmallDesc *>(
-        (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallMulti, d) + (size_t)p * sizeof(SmallDesc)));
-    const bool block = m.block[p] != 0;
-    const int logG = m.logG[p];
-    switch (m.mode[p]) {
-        case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE>(d, logG, block, bid); break;
-        case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM>(d, logG, block, bid); break;
-        case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL>(d, logG, block, bid); break;
-        case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE>(d, logG, block, bid); break;
-        case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
-        case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
-        case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM>(d, logG, block, bid); break;   // (per-factor backward launches)
-        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT>(d, logG, block, bid); break;
-        case ALAN_MODE_BERNOULLI_LINEAR: {
-            const LinDesc &ld = *reinterpret_cast<const LinDesc *>(
-                (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(SmallMulti, lin)));
-            if (block)
-                lin_body<true>(ld, 8, bid);
-            else
-                lin_body<false>(ld, logG, bid);
-            break;
-        }
-        default: break;
-    }
+    small_multi_block<false>(0, blockIdx.x);
 }
 
-int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
-                       const LinDesc *lin) {
-    if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;
-    SmallMulti m;
+uint32_t fill_small_multi(SmallMulti &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, const LinDesc *lin) {
     std::memset(&m, 0, sizeof(m));
     m.n = n;
     if (lin) m.lin = *lin;
@@ -704,6 +330,14 @@ int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mo
         m.d[i] = sd[i];
     }
     m.first_block[n] = blocks;
+    return blocks;
+}
+
+int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
+                       const LinDesc *lin) {
+    if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;
+    SmallMulti m;
+    const uint32_t blocks = fill_small_multi(m, sd, gl, mode, n, lin);
     if (blocks == 0) return ALAN_OK;
     hipLaunchKernelGGL(reduce_small_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;

@@ -10,6 +10,7 @@ per positional dim (functorch ``Dim`` objects in production, strings in tests). 
   * plans the order in which K dims are eliminated (replaces opt_einsum.contract_path,
     reduce_Ks.py:264-265, which only ever chose an order).
 """
+import contextlib
 import math
 
 import torch as t
@@ -531,8 +532,10 @@ def _normal_lse_forward(a, log_scale, want_lse, partials=False):
         d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
     lse = _empty([d.M, d.NL, d.NS], t.float32, device) if want_lse else None
     d.lse_out = lse.data_ptr() if want_lse else None
-    if not N.run_normal_lse(d, device):
+    if not N.run_normal_lse(d, device, keepalive=(a, out, lse)):
         return None
+    if a["wide"]:
+        N.flush()                                        # (the conversion below reads the launch's output)
     return (out.double() if a["wide"] else out), lse
 
 
@@ -613,12 +616,16 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False, partials=Fa
     Differentiable in every argument (alan_normal_lse_backward).  Returns (out, (loc dim, scale dim)) or None when
     the library declines.  ``partials`` (gradient-free calls only): out may be [slices, l, s] -- the launch's per-slice
     partial sums, for a consumer that adds them on load (dims.PartialSumPT)."""
-    N.flush()          # consumers read what queued producer launches write (native.deferring)
+    tensors = [value[0], loc[0], scale[0], *[x for x, _ in smalls]]
+    recording = t.is_grad_enabled() and any(x.requires_grad for x in tensors)
+    if recording or not partials or any(x.dtype != t.float32 for x in tensors):
+        N.flush()      # consumers read what queued producer launches write (native.deferring)
+    # (else the queued producers may ride in this launch's prelude, native.run_normal_lse: nothing below reads a tensor)
     a = _normal_lse_args(value, loc, scale, smalls, plate, K)
     if a is None:
+        N.flush()
         return None
-    tensors = [value[0], loc[0], scale[0], *[x for x, _ in smalls]]
-    if t.is_grad_enabled() and any(x.requires_grad for x in tensors):
+    if recording:
         d = _normal_lse_desc(a, log_scale)
         d.out = d.value                                  # (planning only: any non-null pointer)
         L = N.lib()
@@ -635,6 +642,7 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False, partials=Fa
         return out, (a["dl"], a["ds"])
     res = _normal_lse_forward(a, log_scale, False, partials)       # (partials: out may come back [slices, l, s])
     if res is None:
+        N.flush()
         return None
     return res[0], (a["dl"], a["ds"])
 
@@ -855,7 +863,17 @@ def contract(factors, Ks, plate=(), final=False):
     Returns (result, dims, per-step record) -- the record is what sample_Ks-style consumers need.
     ``final``: this contraction ends an evaluation (its result is THE scalar): inside a graph capture its last launch
     may deliver through the ResultRing."""
-    N.flush()          # consumers read what queued producer launches write (native.deferring)
+    # consumers read what queued producer launches write (native.deferring) -- except the launches of an evaluation's
+    # FINAL contraction behind a queued fused plate step, which may join that launch as its tail (native.tail_attach):
+    # the first launch that cannot flushes the queue as usual
+    chain = final and N.fused_pending() and not t.is_grad_enabled()
+    if not chain:
+        N.flush()
+    with (N.tail_attach() if chain else contextlib.nullcontext()):
+        return _contract(factors, Ks, plate, final)
+
+
+def _contract(factors, Ks, plate, final):
     tok = _Tokens()
     factors = [(x, tok.many(d)) for x, d in factors]
     sizes = _space(factors)

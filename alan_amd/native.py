@@ -128,6 +128,11 @@ def lib():
         L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_normal_lse_n_partials.restype = C.c_int64
         L.alan_normal_lse_n_partials.argtypes = [C.POINTER(NormalLseDesc)]
+        PP = C.POINTER(C.POINTER(ReduceDesc))
+        L.alan_normal_lse_chained_check.restype = C.c_int
+        L.alan_normal_lse_chained_check.argtypes = [C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32]
+        L.alan_normal_lse_chained.restype = C.c_int
+        L.alan_normal_lse_chained.argtypes = [C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32, C.c_void_p, C.c_void_p]
         L.alan_normal_lse_backward.restype = C.c_int
         L.alan_normal_lse_backward.argtypes = [C.POINTER(NormalLseBackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_backward_workspace_bytes.restype = C.c_size_t
@@ -175,7 +180,7 @@ def lib():
 
 EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
-           "alan_normal_lse_n_partials",
+           "alan_normal_lse_n_partials", "alan_normal_lse_chained_check", "alan_normal_lse_chained",
            "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
@@ -234,6 +239,8 @@ class _Queue(threading.local):
     def __init__(self):
         self.pending = []        # [(desc, device, keepalive tensors)]
         self.depth = [0, 0]      # nesting of deferring() / may_defer()
+        self.fused = None        # a fused plate step waiting for its launch (_Fused), issued BEFORE ``pending``
+        self.tail_ok = 0         # nesting of tail_attach(): launches of an evaluation's final contraction
 
 
 _Q = _Queue()
@@ -261,6 +268,119 @@ def deferring():
         _Q.depth[0] -= 1
         if _Q.depth[0] == 0:
             _Q.pending.clear()          # (only non-empty after an exception)
+            _Q.fused = None
+
+
+# ---- the chained launch (alan_normal_lse_chained) ------------------------------------------------------------------
+# Inside ``deferring()`` a gradient-free fused plate step is itself only queued: the producers queued so far (and any
+# queued before it goes out) ride in its launch as the PRELUDE -- its first workgroups run them, or its tiles compute
+# them -- and the launches of the evaluation's final contraction (engine.contract(final=True), under ``tail_attach()``)
+# join it as the TAIL, run by its last-arriving workgroup: movielens' whole evaluation is then one launch instead of
+# three.  OFF by default -- measured slower (tools/chain_parts.py, round 3, K = 30: the plate step alone replays every
+# 14.3 us; + the two [M, K] producers computed in its tiles 19.2; + the other producers and the arrival counter 22.8; +
+# the tail 29.0 -- against 27.4 us for the three separate launches): on this chip an in-launch hand-off between
+# workgroups (write-through stores drained, an agent-scope add that returns, an acquire) costs the 4-5 us a dependent
+# launch costs, and a small problem's chain of load latencies is as long inside another launch as in its own.
+CHAIN_LAUNCHES = os.environ.get("ALAN_AMD_CHAIN", "0") == "1"
+CHAIN_TAIL = os.environ.get("ALAN_AMD_CHAIN_TAIL", "1") != "0"      # False: the final contraction stays a launch of its own
+CHAIN_MAX_PRELUDE, CHAIN_MAX_TAIL = 4, 2
+_CHAIN_STATE = {}        # device index -> 4 zeroed int32 (the launch leaves the counters zero)
+
+
+class _Fused:
+    def __init__(self, desc, device, prelude, keepalive):
+        self.desc, self.device, self.prelude, self.keepalive = desc, device, prelude, keepalive
+        self.tail = []
+
+    def arrays(self, prelude=None, tail=None):
+        pre = self.prelude if prelude is None else prelude
+        tl = self.tail if tail is None else tail
+        PA = (C.POINTER(ReduceDesc) * max(1, len(pre)))(*[C.pointer(d) for d, _, _ in pre])
+        TA = (C.POINTER(ReduceDesc) * max(1, len(tl)))(*[C.pointer(d) for d, _, _ in tl])
+        return PA, len(pre), TA, len(tl)
+
+    def check(self, prelude=None, tail=None):
+        PA, n, TA, m = self.arrays(prelude, tail)
+        return lib().alan_normal_lse_chained_check(C.byref(self.desc), PA, n, TA, m) == 0
+
+
+_CHAIN_STATE_FOR_CAPTURE = [None]     # set by whoever captures a graph: that graph's own words (allocated before the capture)
+
+
+def chain_state(device):
+    """The zeroed words a chained launch synchronises through: a captured graph's own (two graphs replayed on different
+    streams must not share them), else one set per device -- evaluations launched kernel by kernel from different streams
+    at the same time are not supported with CHAIN_LAUNCHES.  None while a capture is under way and no set exists yet
+    (allocating it then would put its fill kernel into the graph)."""
+    if _CHAIN_STATE_FOR_CAPTURE[0] is not None and _CHAIN_STATE_FOR_CAPTURE[0].device == device:
+        return _CHAIN_STATE_FOR_CAPTURE[0]
+    st = _CHAIN_STATE.get(device.index)
+    if st is None and not t.cuda.is_current_stream_capturing():
+        st = _CHAIN_STATE[device.index] = t.zeros(4, dtype=t.int32, device=device)
+    return st
+
+
+@contextlib.contextmanager
+def own_chain_state(device):
+    """Around the warm-up and capture of one graph: its chained launches get words of their own."""
+    saved, _CHAIN_STATE_FOR_CAPTURE[0] = _CHAIN_STATE_FOR_CAPTURE[0], t.zeros(4, dtype=t.int32, device=device)
+    try:
+        yield _CHAIN_STATE_FOR_CAPTURE[0]
+    finally:
+        _CHAIN_STATE_FOR_CAPTURE[0] = saved
+
+
+def fused_pending():
+    return _Q.fused is not None
+
+
+@contextlib.contextmanager
+def tail_attach():
+    """Around the launches of an evaluation's FINAL contraction: nothing but the caller reads their results, and it does
+    so only after the enclosing deferring() has flushed."""
+    _Q.tail_ok += 1
+    try:
+        yield
+    finally:
+        _Q.tail_ok -= 1
+        if _Q.tail_ok == 0:
+            flush()
+
+
+def _launch_fused():
+    f, _Q.fused = _Q.fused, None
+    L = lib()
+    stream = current_stream(f.device)
+    if not f.prelude and not f.tail:
+        rc = L.alan_normal_lse(C.byref(f.desc), None, 0, stream)
+        check(rc, "alan_normal_lse")
+        return
+    st = chain_state(f.device)
+    if st is None:                                       # (first seen inside a capture: the separate launches)
+        _flush_items(f.prelude)
+        check(L.alan_normal_lse(C.byref(f.desc), None, 0, stream), "alan_normal_lse")
+        for d, _, _ in f.tail:
+            check(L.alan_reduce(C.byref(d), None, 0, stream), "alan_reduce")
+        return
+    PA, n, TA, m = f.arrays()
+    rc = L.alan_normal_lse_chained(C.byref(f.desc), PA, n, TA, m, st.data_ptr(), stream)
+    check(rc, "alan_normal_lse_chained")
+
+
+def _try_tail(desc, device, keepalive):
+    """Attach an alan_reduce call to the pending fused launch as (the next step of) its tail.  True: attached."""
+    f = _Q.fused
+    if f is None or not _Q.tail_ok or not CHAIN_LAUNCHES or not CHAIN_TAIL or len(f.tail) >= CHAIN_MAX_TAIL or f.device != device:
+        return False
+    if any(dev != device for _, dev, _ in _Q.pending) or len(f.prelude) + len(_Q.pending) > CHAIN_MAX_PRELUDE:
+        return False
+    item = (desc, device, keepalive)
+    pre, tail = f.prelude + list(_Q.pending), f.tail + [item]
+    if not f.check(pre, tail):
+        return False
+    f.prelude, f.tail = pre, tail
+    _Q.pending.clear()
+    return True
 
 
 @contextlib.contextmanager
@@ -274,10 +394,24 @@ def may_defer():
 
 def flush():
     """Issue every queued launch now (in order)."""
+    if _Q.fused is not None:
+        f = _Q.fused
+        # producers queued behind the fused launch read nothing it writes: they ride in its prelude while there is room
+        if _Q.pending and len(f.prelude) + len(_Q.pending) <= CHAIN_MAX_PRELUDE and \
+                all(dev == f.device for _, dev, _ in _Q.pending) and f.check(f.prelude + list(_Q.pending)):
+            f.prelude = f.prelude + list(_Q.pending)
+            _Q.pending.clear()
+        _launch_fused()
     if not _Q.pending:
         return
     items = list(_Q.pending)
     _Q.pending.clear()
+    _flush_items(items)
+
+
+def _flush_items(items):
+    if not items:
+        return
     L = lib()
     device = items[0][1]
     if len(items) == 1:
@@ -307,6 +441,9 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
         _Q.pending.append((desc, device, keepalive))
         if len(_Q.pending) >= 8:
             flush()
+        return True
+    if _Q.fused is not None and _Q.tail_ok and not lin_grad and _TIMER[0] is None and not t.is_grad_enabled() and \
+            L.alan_reduce_workspace_bytes(C.byref(desc)) == 0 and _try_tail(desc, device, keepalive):
         return True
     flush()
     if _TIMER[0] is not None:
@@ -359,9 +496,18 @@ def arrival_counters(device):
     return c
 
 
-def run_normal_lse(desc, device):
+def run_normal_lse(desc, device, keepalive=()):
     """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
     L = lib()
+    if (CHAIN_LAUNCHES and _Q.depth[0] and _Q.fused is None and desc.keep_partials and not desc.lse_out and _TIMER[0] is None
+            and not t.is_grad_enabled() and not COMBINE_IN_LAUNCH and len(_Q.pending) <= CHAIN_MAX_PRELUDE
+            and all(dev == device for _, dev, _ in _Q.pending)):
+        f = _Fused(desc, device, list(_Q.pending), keepalive)
+        if f.check():
+            # queued: goes out with the producers as its prelude (and the final contraction as its tail) at the next flush
+            _Q.pending.clear()
+            _Q.fused = f
+            return True
     flush()
     if COMBINE_IN_LAUNCH and not desc.keep_partials and desc.NL * ((desc.NS + 31) // 32) <= N_COUNTERS:
         c = arrival_counters(device)

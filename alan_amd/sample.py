@@ -42,6 +42,8 @@ class _GraphedELBO:
         device = t.device("cuda", t.cuda.current_device())
         self.ring = E.ResultRing.create(device) if (ring and RESULT_RING) else None
         E._RING[0] = self.ring
+        own = N.own_chain_state(device)
+        self.chain_state = own.__enter__()           # (kept: the graph's chained launches synchronise through it)
         try:
             side = t.cuda.Stream()
             side.wait_stream(t.cuda.current_stream())
@@ -69,6 +71,7 @@ class _GraphedELBO:
                     expected = None if (c is None or expected is None) else expected + c
             check_no_memset_nodes(self.graph, "Sample.elbo_nograd(graph=True)", expected=expected)
         finally:
+            own.__exit__(None, None, None)
             N._TIMER[0] = timer
             E._RING[0] = None
         if self.ring is not None:
@@ -262,7 +265,7 @@ class Sample:
         from . import logpq as LP
         from . import split as SP
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS)
+                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS, N.CHAIN_LAUNCHES, N.CHAIN_TAIL)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)

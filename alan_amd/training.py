@@ -211,6 +211,9 @@ class GraphedEval:
         # the evaluation's last launch delivers through a result ring (engine.ResultRing): no copy after a replay
         self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING) else None
         E._RING[0] = self.ring
+        from . import native as N
+        own = N.own_chain_state(problem.device)
+        self.chain_state = own.__enter__()           # (kept: the graph's chained launches synchronise through it)
         try:
             side = t.cuda.Stream()
             side.wait_stream(t.cuda.current_stream())
@@ -225,6 +228,7 @@ class GraphedEval:
             with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.elbo = self._iteration()
         finally:
+            own.__exit__(None, None, None)
             E._RING[0] = None
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedEval")
         if self.ring is not None:

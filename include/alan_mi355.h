@@ -214,6 +214,31 @@ size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
 int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The plate step TOGETHER WITH the launches either side of it, as ONE launch -- what the reference runs as lp_getter +
+ * reduce_Ks at two plate levels (logpq.py:68-155: the plate's factors are produced, reduce_Ks.py:236-298 eliminates its
+ * K and logpq.py:149 sums it out; the result is a factor of the parent's reduce_Ks, Sample.py:69-86 for the top level):
+ *   prelude  up to 4 alan_reduce problems of the small single-launch kind (the log-prob producers alan_reduce_batch
+ *            would launch together: -(log Q + log K) of the plate's latent, the likelihood with linear logits, the parent
+ *            level's log P - log Q - log K), run by the launch's first workgroups.  They may write desc->small[] and the
+ *            tail's factors; they read nothing this launch writes.
+ *   desc     the plate step, keep_partials set: desc->out receives [alan_normal_lse_n_partials(desc), NL, NS].
+ *   tail     up to 2 alan_reduce problems of that kind run IN ORDER by the launch's last-arriving workgroup -- the
+ *            parent's contraction: typically tail[0] reads desc->out with a dim of role ALAN_PRESUM and the prelude's
+ *            outputs, tail[1] (K = 100: the second K peeled) reads tail[0]'s output; the last may deliver through a
+ *            result ring (ring_*, one output element).
+ *   state    16 bytes of device memory, zero before the FIRST call and never touched by the caller again (the launch
+ *            leaves the first 8 zero; bytes 8..11 become non-zero if a workgroup ever gave up waiting for the prelude --
+ *            never in a healthy launch -- and the results of that launch are NaN).  Launches that may run concurrently
+ *            (different streams) need separate `state`.
+ * Results are those of alan_reduce_batch(prelude); alan_normal_lse(desc); alan_reduce(tail[0]); alan_reduce(tail[1]).
+ * ALAN_ERR_UNSUPPORTED (from either function, nothing launched): some part is not of the single-launch small kind, or
+ * the plate step is not the bf16x3 kernel's -- issue the calls separately. */
+int alan_normal_lse_chained_check(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,
+                                  int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail);
+int alan_normal_lse_chained(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,
+                            int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state,
+                            void *stream);
+
 /* Backward of alan_normal_lse with respect to EVERY input, in one pass that recomputes the log-prob tiles on the matrix
  * cores as the forward does and never writes the [M, NL, NS, NK] factor or its gradient -- what autograd derives from
  * TorchDimDist.py:127-162 (torch.distributions.Normal.log_prob) + utils.py:147-152 + reduce_Ks.py:249-251 +

@@ -709,3 +709,36 @@ def test_merged_split_keeps_the_memory_bound(oracle_backend, monkeypatch):
     assert strat2.last_sizes == [38] * 7 + [34]
     ref = float(fx["elbo"]["split"])
     assert abs(chunked - ref) <= 1e-4 * abs(ref) and abs(merged - ref) <= 1e-4 * abs(ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,split", [(10, None), (30, None), (100, ("plate_1", 38))], ids=["K10", "K30", "K100_split38"])
+@pytest.mark.parametrize("tail", [False, True], ids=["prelude", "prelude+tail"])
+def test_chained_launch_equals_the_separate_launches(K, split, tail, monkeypatch):
+    """alan_normal_lse_chained (producers + fused plate step + final contraction as ONE launch; off by default: measured
+    slower) against the separate launches -- whose value the tests above pin to the reference's -- on particles drawn by
+    the Problem (the layout the bf16x3 kernel takes), eagerly and as a replayed graph; its synchronisation words are left
+    zero and no workgroup ever gave up waiting."""
+    from alan_amd import native as N
+    g = t.Generator().manual_seed(5)
+    x = t.randn(300, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(300, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")      # (fp32 data: fp64 takes the wide route)
+    prob = models.movielens(sizes={"plate_1": 300, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    t.manual_seed(3)
+    sample = prob.sample(K, reparam=False)
+    strat = alan.Split(*split) if split else alan.no_checkpoint
+    separate = float(sample.elbo_nograd(strat, graph=False))
+    monkeypatch.setattr(N, "CHAIN_LAUNCHES", True)
+    monkeypatch.setattr(N, "CHAIN_TAIL", tail)
+    launched = []
+    real = N._launch_fused
+    monkeypatch.setattr(N, "_launch_fused", lambda: (launched.append((len(N._Q.fused.prelude), len(N._Q.fused.tail))), real())[1])
+    eager = float(sample.elbo_nograd(strat, graph=False))
+    assert launched and launched[-1][0] >= 2 and (launched[-1][1] >= 1) == tail, launched
+    replayed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(4)]
+    t.cuda.synchronize()
+    for got in (eager, *replayed):
+        assert abs(got - separate) <= 2e-6 * abs(separate), (got, separate)
+    for st in (*N._CHAIN_STATE.values(), *[g.chain_state for g in sample.__dict__.get("_graphs", {}).values()]):
+        assert st.tolist() == [0, 0, 0, 0]
