@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
     small_body<MODE, BLOCK>(d, logG, blockIdx.x);
 }
 
+// ONE output from a long reduction -- the last launch of an evaluation: LSE over the parents' K x K grid of the plate
+// step's partial sums (34 slices of 900 values at K = 30, 5 of 10^4 at K = 100) plus the parents' own factors
+// (reduce_Ks.py:249-251 at the top level, Sample.py:69-86).  In the 256-thread kernel that is a chain of load rounds (a
+// thread has 4 elements x 8 slices in flight, a fifth of what it needs: 5.4 us at K = 30); here 1024 threads hold UNR x PF
+// = 40 loads each, all of a thread's share in two rounds, and the 16 waves' (max, sum) pairs meet through LDS.
+template <int MODE, int UNR, int PF>
+__global__ __launch_bounds__(1024) void reduce_wide_kernel(const SmallDesc d) {
+    small_body<MODE, true, false, 16, UNR, PF>(d, 10, 0);
+}
+
 // ------------------------------------------------------------------------------------------
 // Small log-sum-exp + plate sum in one launch (SmallPlateDesc): a lane group per output element; for each plate element
 // in turn the group reduces the REDUCE dims (lanes along them, shuffles), lane 0 adds the value to the plate sum.
@@ -447,6 +457,22 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
         sd.ring_n = ev.ring_n;
     }
     if (gd.n_out == 0) return ALAN_OK;
+    // one output, thousands of loads: the 1024-thread kernel (every load of a thread's share in flight in two rounds)
+    static const int wide_knob = env_knob("ALAN_WIDE_FINAL");                          // ablation knob: 0 = off
+    const int64_t slices = sd.presum_n > 1 ? sd.presum_n : 1;
+    if (wide_knob != 0 && gd.n_out == 1 && gl.block && (mode == ALAN_MODE_LSE || mode == ALAN_MODE_SUM) &&
+        (int64_t)sd.n_red * (slices + sd.nf - 1) >= 4096) {
+        const int per_thread = (int)((sd.n_red + 1023) / 1024);
+        auto wide = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, stream, ev.start, ev.stop, 0, sd); };
+        const bool lse = mode == ALAN_MODE_LSE;
+        if (slices >= 16 || per_thread <= 1)
+            lse ? wide(reduce_wide_kernel<ALAN_MODE_LSE, 1, 40>) : wide(reduce_wide_kernel<ALAN_MODE_SUM, 1, 40>);
+        else if (slices >= 6 || per_thread <= 4)
+            lse ? wide(reduce_wide_kernel<ALAN_MODE_LSE, 4, 10>) : wide(reduce_wide_kernel<ALAN_MODE_SUM, 4, 10>);
+        else
+            lse ? wide(reduce_wide_kernel<ALAN_MODE_LSE, 10, 4>) : wide(reduce_wide_kernel<ALAN_MODE_SUM, 10, 4>);
+        return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+    }
     switch (mode) {
         case ALAN_MODE_LSE: launch_small_T<ALAN_MODE_LSE>(sd, gl, stream, ev); break;
         case ALAN_MODE_SUM: launch_small_T<ALAN_MODE_SUM>(sd, gl, stream, ev); break;

@@ -85,8 +85,8 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
     }
 }
 
-// Lanes of a group (or the 4 waves of a block) -> one value.
-template <typename T, int MODE, bool BLOCK>
+// Lanes of a group (or the NW waves of a block) -> one value.
+template <typename T, int MODE, bool BLOCK, int NW = 4>
 __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
     const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
     if (MODE == ALAN_MODE_LSE) {
@@ -99,7 +99,7 @@ __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
         for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
     }
     if (BLOCK) {
-        __shared__ T sm[4], ss[4];
+        __shared__ T sm[NW], ss[NW];
         const int wv = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) {
             sm[wv] = m;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
         if (threadIdx.x == 0) {
             m = sm[0];
             s = ss[0];
-            for (int i = 1; i < 4; ++i) {
+            for (int i = 1; i < NW; ++i) {
                 if (MODE == ALAN_MODE_LSE)
                     lse_merge(m, s, sm[i], ss[i]);
                 else
@@ -120,16 +120,18 @@ __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool BLOCK, bool WT = false>
+// NW: waves of the workgroup (BLOCK: all of them on one output); UNR elements of the reduce index per thread and round, PF
+// slices of a partial-sum factor (role PRESUM) per element and round -- UNR x PF loads in flight.
+template <int MODE, bool BLOCK, bool WT = false, int NW = 4, int UNR = 4, int PF = 8>
 __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id) {
     typedef float T;
-    const uint32_t G = BLOCK ? 256u : (1u << logG);
+    const uint32_t G = BLOCK ? 64u * NW : (1u << logG);
     uint32_t grp, gl;
     if (BLOCK) {
         grp = block_id;
         gl = threadIdx.x;
     } else {
-        const uint32_t gid = block_id * 256u + threadIdx.x;
+        const uint32_t gid = block_id * (64u * NW) + threadIdx.x;
         grp = gid >> logG;
         gl = gid & (G - 1u);
     }
@@ -153,7 +155,6 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) sc[f] = d.fscale[f];
 
-    constexpr int UNR = 4;
     T m = Num<T>::ninf(), s = T(0);
     for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
         T val[UNR][MAXF];
@@ -184,7 +185,7 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
         if ((MODE == ALAN_MODE_LSE || MODE == ALAN_MODE_SUM) && d.presum_n > 1) {
             // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, eight loads per element in
             // flight, added in slice order
-            constexpr int PF = 8;                     // (more costs every small kernel registers: 16 took them to 5 waves per SIMD)
+            // (PF = 8 in the 256-thread kernels: more costs every one of them registers -- 16 took them to 5 waves per SIMD)
             for (int32_t c0 = 1; c0 < d.presum_n; c0 += PF) {
                 T part[UNR][PF];
 #pragma unroll
@@ -204,7 +205,7 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
         for (int u = 0; u < UNR; ++u)
             accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
     }
-    combine_lanes<T, MODE, BLOCK>(m, s, G);
+    combine_lanes<T, MODE, BLOCK, NW>(m, s, G);
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
         if (MODE == ALAN_MODE_NORMAL || MODE == ALAN_MODE_NORMAL_LOGSCALE || MODE == ALAN_MODE_BERNOULLI ||

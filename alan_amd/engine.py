@@ -786,7 +786,13 @@ def presum_dim(n):
 
 
 # --------------------------------------------------------------------------- elimination planner
-def plan_elimination(dimsets, sizes, Ks):
+LONG_SINGLE_REDUCTION = {True: 16384, False: 2048}
+"""Elements of a reduction with (almost) nothing kept above which one K is peeled per step: fp32 problems have the
+1024-thread kernel for one long output (reduce.hip, reduce_wide_kernel: K=100's 10^4-element top level in two rounds of
+loads), anything else a 256-thread workgroup that would walk it serially (38 us at K=100)."""
+
+
+def plan_elimination(dimsets, sizes, Ks, fp32=False):
     """Order of K eliminations.  Returns a list of steps ``(factor_ids, Ks_now)`` over a growing list of
     factors (each step appends its result).  Greedy smallest-intermediate-first variable elimination;
     a step absorbs every other K whose factors fit inside the step's index space, so e.g. the
@@ -838,7 +844,7 @@ def plan_elimination(dimsets, sizes, Ks):
             # one of the largest factor, so that step streams it with coalesced loads
             red = math.prod(sizes[kk] for kk in now)
             kept = math.prod(sizes[dd] for dd in union if dd not in now)
-            if red > 2048 and kept < 256:
+            if red > LONG_SINGLE_REDUCTION[bool(fp32)] and kept < 256:
                 big = max(grp, key=lambda i: math.prod(sizes[dd] for dd in live[i]))
                 pos = {dd: j for j, dd in enumerate(stored.get(big, ()))}
                 now = (max(now, key=lambda kk: pos.get(kk, -1)),)
@@ -884,7 +890,8 @@ def _contract(factors, Ks, plate, final):
     plate = tok.many(plate)
     # (the slice dim of a partial-sum factor, dims.PartialSumPT: invisible to the planner, summed as its step loads it)
     presum = {tok(d) for d in PRESUM_DIMS.values() if d in tok}
-    steps = plan_elimination([tuple(dd for dd in d if dd not in presum) for _, d in factors], sizes, Ks)
+    steps = plan_elimination([tuple(dd for dd in d if dd not in presum) for _, d in factors], sizes, Ks,
+                             fp32=all(x.dtype == t.float32 and x.is_cuda for x, _ in factors) and not t.is_grad_enabled())
     if not steps:
         steps = [(tuple(range(len(factors))), ())] if (plate or len(factors) > 1) else []
     pool = list(factors)
