@@ -180,8 +180,22 @@ class BoundPlate(nn.Module):
         Kdims = self.plate.groupvarname2Kdim(K)
         platenames_of = {id(d): n for n, d in all_platedims.items()}
         ip = pt_tree(self.plate, self.inputs_params_flat_pt(all_platedims), platenames_of)
-        with on_device(self.device):
-            tree = self.plate.sample(None, {}, ip, [], all_platedims, Kdims, sampler, reparam)
+        from . import dist as D
+        from .dims import PendingPT
+        batch = D._DrawBatch() if D.BATCH_DRAWS else None
+        saved, D._DRAW_BATCH[0] = D._DRAW_BATCH[0], batch
+        try:
+            with on_device(self.device):
+                tree = self.plate.sample(None, {}, ip, [], all_platedims, Kdims, sampler, reparam)
+        finally:
+            D._DRAW_BATCH[0] = saved
+        if batch is not None:
+            batch.flush()
+
+            def settle(tr):
+                return {k: (settle(v) if isinstance(v, dict) else v.settled() if isinstance(v, PendingPT) else v)
+                        for k, v in tr.items()}
+            tree = settle(tree)
         return tree, Kdims
 
     def sample(self, sample_size=1):

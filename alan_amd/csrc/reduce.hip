@@ -478,6 +478,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
         case ALAN_MODE_SUM: launch_small_T<ALAN_MODE_SUM>(sd, gl, stream, ev); break;
         case ALAN_MODE_WEXPSUM: launch_small_T<ALAN_MODE_WEXPSUM>(sd, gl, stream, ev); break;
         case ALAN_MODE_DOT: launch_small_T<ALAN_MODE_DOT>(sd, gl, stream, ev); break;
+        case ALAN_MODE_AFFINE: launch_small_T<ALAN_MODE_AFFINE>(sd, gl, stream, ev); break;
         case ALAN_MODE_NORMAL: launch_small_T<ALAN_MODE_NORMAL>(sd, gl, stream, ev); break;
         case ALAN_MODE_NORMAL_LOGSCALE: launch_small_T<ALAN_MODE_NORMAL_LOGSCALE>(sd, gl, stream, ev); break;
         case ALAN_MODE_BERNOULLI: launch_small_T<ALAN_MODE_BERNOULLI>(sd, gl, stream, ev); break;
@@ -508,6 +509,7 @@ int launch_group(const GroupDesc &gd, const GroupLaunch &gl, int mode, int compu
         case ALAN_MODE_SUM: return launch_group_T<T, ALAN_MODE_SUM>(gd, gl, stream, ev);  \
         case ALAN_MODE_WEXPSUM: return launch_group_T<T, ALAN_MODE_WEXPSUM>(gd, gl, stream, ev); \
         case ALAN_MODE_DOT: return launch_group_T<T, ALAN_MODE_DOT>(gd, gl, stream, ev); \
+        case ALAN_MODE_AFFINE: return launch_group_T<T, ALAN_MODE_AFFINE>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL: return launch_group_T<T, ALAN_MODE_NORMAL>(gd, gl, stream, ev); \
         case ALAN_MODE_BERNOULLI: return launch_group_T<T, ALAN_MODE_BERNOULLI>(gd, gl, stream, ev); \
         case ALAN_MODE_NORMAL_LOGSCALE: return launch_group_T<T, ALAN_MODE_NORMAL_LOGSCALE>(gd, gl, stream, ev); \

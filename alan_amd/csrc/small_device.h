@@ -69,7 +69,12 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
         const T ls = (xl < T(0) ? xl : T(0)) - Num<T>::log1p(Num<T>::exp_acc(xl < T(0) ? xl : -xl));
         s += ok ? ls - (T(1) - y) * xl : T(0);
     } else if (MODE == ALAN_MODE_DOT) {
-        s += ok ? val[0] * val[1] : T(0);
+        // (a third factor multiplies in, through exp when its scale field says it holds a logarithm)
+        const T third = nf > 2 ? (scale[2] == 2.f ? Num<T>::exp_acc(val[2]) : val[2]) : T(1);
+        s += ok ? val[0] * val[1] * third : T(0);
+    } else if (MODE == ALAN_MODE_AFFINE) {
+        const T sc = scale[2] == 2.f ? Num<T>::exp_acc(val[2]) : val[2];
+        s += ok ? val[0] + val[1] * sc : T(0);
     } else {
         T x = T(0);
 #pragma unroll
@@ -379,6 +384,7 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD, WT>(d, logG, block, bid); break;
         case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM, WT>(d, logG, block, bid); break;   // (per-factor backward launches)
         case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT, WT>(d, logG, block, bid); break;
+        case ALAN_MODE_AFFINE: small_either<ALAN_MODE_AFFINE, WT>(d, logG, block, bid); break;
         case ALAN_MODE_BERNOULLI_LINEAR: {
             const LinDesc &ld = *reinterpret_cast<const LinDesc *>(base + offsetof(SmallMulti, lin));
             if (block)

@@ -193,6 +193,27 @@ class ReparamPT(PT):
         return PT(self.x.detach(), self.dims)
 
 
+class PendingPT(ReparamPT):
+    """A Normal draw that waits in a batch of draws (dist._DrawBatch) for its launch: reading ``.x`` issues the batch.
+    Lives only inside one ancestral sampling pass (BoundPlate._sample replaces it by a ReparamPT / PT at the end)."""
+    __slots__ = ("_val", "_batch", "_shape", "_dtype", "_device")
+
+    def __init__(self, batch, dims, src, shape, dtype, device):
+        self._val, self._batch, self._shape, self._dtype, self._device = None, batch, tuple(shape), dtype, device
+        self.dims = tuple(dims)
+        self.ids = tuple(id(d) for d in self.dims)
+        self.src = src
+
+    @property
+    def x(self):
+        if self._val is None:
+            self._batch.flush()
+        return self._val
+
+    def settled(self):
+        return ReparamPT(self.x, self.dims, self.src) if self.src is not None else PT(self.x, self.dims)
+
+
 class ShiftPT(PT):
     """The previous state of a timeseries, ``prev[t] = first if t == 0 else rest[t - 1]`` along the time dim (what
     Timeseries.py:205-245 builds with a concatenation), not concatenated yet: ``.x`` does it the first time anyone asks,

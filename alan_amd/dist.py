@@ -9,13 +9,14 @@ eliminates is the CONTIGUOUS dim of the big factor -- the layout the rows kernel
 """
 import inspect
 import math
+import os
 import types
 
 import torch as t
 import torch.distributions as td
 import torch.nn as nn
 
-from .dims import PT, ExpPT, LazyNormalPT, LinearPT, ReparamPT, ScaledPT, ShiftPT, is_tensor, pt_align, pt_order
+from .dims import PT, ExpPT, LazyNormalPT, LinearPT, PendingPT, ReparamPT, ScaledPT, ShiftPT, is_tensor, pt_align, pt_order
 
 Number = (int, float)
 
@@ -339,24 +340,32 @@ small library launches (the sums of G and of G * eps over the broadcast dims, al
 together) instead of the five or six torch kernels autograd derives from exp, addcmul and the broadcasts."""
 
 
-def _sum_to(G, other, shape):
-    """sum of G (or of G * other) over the dims along which a parameter of shape ``shape`` was broadcast to G's."""
+def _sum_to(G, other, shape, log_third=None):
+    """sum of G (or of G * other, or of G * other * exp(log_third)) over the dims along which a parameter of shape
+    ``shape`` was broadcast to G's."""
     pad = G.ndim - len(shape)
     keep = [i for i in range(G.ndim) if i >= pad and shape[i - pad] != 1]
-    if len(keep) == G.ndim:
-        return (G if other is None else G * other).reshape(shape)
-    if G.is_cuda and G.dtype == t.float32 and (other is None or other.dtype == t.float32):
+    if G.is_cuda and G.dtype == t.float32 and (other is None or other.dtype == t.float32) and \
+            (len(keep) < G.ndim or log_third is not None):
         from . import engine as E
         from . import native as N
         axes = tuple(range(G.ndim))
         with N.may_defer():
             if other is None:
                 out = E._produce(N.MODE_SUM, [(G, axes)], tuple(keep))
-            else:
+            elif log_third is None:
                 out = E._produce(N.MODE_DOT, [(G, axes), (other.expand_as(G), axes)], tuple(keep))
+            else:
+                out = E._produce(N.MODE_DOT, [(G, axes), (other.expand_as(G), axes), (log_third.expand_as(G), axes)],
+                                 tuple(keep), scales=[1.0, 1.0, 2.0])
         return out.reshape(shape)
+    v = G if other is None else G * other
+    if log_third is not None:
+        v = v * log_third.exp()
+    if len(keep) == G.ndim:
+        return v.reshape(shape)
     red = [i for i in range(G.ndim) if i not in keep]
-    return (G if other is None else G * other).sum(red).reshape(shape)
+    return v.sum(red).reshape(shape)
 
 
 class _ReparamNormal(t.autograd.Function):
@@ -393,6 +402,115 @@ class _ReparamNormal(t.autograd.Function):
         if gs is not None and ctx.is_log:
             gs = gs * s                                       # d/d raw = d/d scale * exp(raw)
         return gl, (None if ctx.is_log else gs), (gs if ctx.is_log else None), None, None
+
+
+BATCH_DRAWS = os.environ.get("ALAN_AMD_BATCH_DRAWS", "1") != "0"
+"""Problem.sample: the Normal draws of the ancestral pass whose parameters do not depend on a sample still waiting are
+collected and issued together -- the affine maps x = loc + eps * exp(raw) of all of them as ONE library launch
+(alan_reduce_batch of ALAN_MODE_AFFINE problems, written straight in the sample's layout) behind the noise, and, under
+autograd, one node whose backward issues every variable's two reductions together (d loc = sum G, d raw = sum G * eps *
+exp(raw): no torch multiply, no exp).  A movielens VI iteration: 2 + 3 launches for the draws where there were 9, 2 for
+their backward where there were 6.  False: a draw is issued where the model meets it."""
+
+BATCH_NOISE = os.environ.get("ALAN_AMD_BATCH_NOISE", "1") != "0"
+"""The noise of a batch of draws from ONE normal_ call over one buffer (one kernel instead of one per variable).  The
+particles then differ from the ones torch's rsample would draw variable by variable under the same seed (same
+distribution); False keeps them identical."""
+
+_DRAW_BATCH = [None]
+
+
+class _DrawBatch:
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, la, sa, is_log, full, perm, dims, src, reparam):
+        shape = tuple(full[i] for i in perm) if perm is not None else tuple(full)
+        pt = PendingPT(self, dims, src, shape, la.dtype, la.device)
+        self.jobs.append((la, sa, is_log, t.Size(full), perm, pt, reparam))
+        return pt
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        for dev, dt in {(j[0].device, j[0].dtype) for j in jobs}:
+            mine = [j for j in jobs if j[0].device == dev and j[0].dtype == dt]
+            with t.no_grad():
+                if BATCH_NOISE:
+                    flat = t.empty(sum(j[3].numel() for j in mine), dtype=dt, device=dev).normal_()
+                    eps, o = [], 0
+                    for j in mine:
+                        eps.append(flat[o:o + j[3].numel()].view(j[3]))
+                        o += j[3].numel()
+                else:
+                    eps = [t.empty(j[3], dtype=dt, device=dev).normal_() for j in mine]
+                eps = [e if j[4] is None else e.permute(j[4]) for e, j in zip(eps, mine)]
+            rp = [k for k, j in enumerate(mine) if j[6]]
+            outs = [None] * len(mine)
+            if rp:
+                meta = tuple((mine[k][2], eps[k]) for k in rp)
+                res = _ReparamNormalBatch.apply(meta, *[x for k in rp for x in (mine[k][0], mine[k][1])])
+                for k, x in zip(rp, res):
+                    outs[k] = x
+            rest = [k for k in range(len(mine)) if not mine[k][6]]
+            if rest:
+                with t.no_grad():
+                    res = _affine_batch([(mine[k][0], mine[k][1], mine[k][2], eps[k]) for k in rest])
+                for k, x in zip(rest, res):
+                    outs[k] = x
+            for j, x in zip(mine, outs):
+                j[5]._val = x
+
+
+def _affine_batch(jobs):
+    """[(loc, scale or log-scale, is_log, eps)] -> [loc + eps * scale], each written contiguously with eps's shape; on the
+    GPU all of them as one multi-problem launch (ALAN_MODE_AFFINE)."""
+    from . import engine as E
+    from . import native as N
+    if not all(e.is_cuda and e.dtype == t.float32 and l.dtype == s_.dtype == t.float32 for l, s_, _, e in jobs):
+        return [t.addcmul(l, e, s_.exp() if lg else s_) for l, s_, lg, e in jobs]
+    outs = []
+    with N.deferring(), N.may_defer():
+        for l, s_, lg, e in jobs:
+            axes = tuple(range(e.ndim))
+            outs.append(E._produce(N.MODE_AFFINE, [(l.expand_as(e), axes), (e, axes), (s_.expand_as(e), axes)], axes,
+                                   scales=[1.0, 1.0, 2.0 if lg else 1.0]))
+    N.flush()                                             # (inside someone else's deferring() the exit above issues nothing)
+    return outs
+
+
+class _ReparamNormalBatch(t.autograd.Function):
+    """x_i = loc_i + eps_i * scale_i for a batch of Normal variables (what torch's Normal.rsample computes one variable
+    at a time, TorchDimDist.py:88-125), the noise given: one launch forward, and the backward of all of them -- d loc_i =
+    sum_b G_i, d scale_i = sum_b G_i eps_i, or d raw_i = sum_b G_i eps_i exp(raw_i) where the scale is exp(raw_i) -- as
+    one multi-problem launch per four reductions."""
+
+    @staticmethod
+    def forward(ctx, meta, *params):
+        jobs = [(params[2 * i], params[2 * i + 1], meta[i][0], meta[i][1]) for i in range(len(meta))]
+        outs = _affine_batch(jobs)
+        ctx.meta = meta
+        ctx.shapes = [(tuple(l.shape), tuple(s_.shape)) for l, s_, _, _ in jobs]
+        ctx.save_for_backward(*[j[1] for j in jobs])
+        return tuple(outs)
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, *Gs):
+        from . import native as N
+        grads = [None]
+        with N.deferring():
+            for i, ((is_log, eps), G) in enumerate(zip(ctx.meta, Gs)):
+                gl = gs = None
+                if G is not None:
+                    G = G.contiguous()
+                    if ctx.needs_input_grad[1 + 2 * i]:
+                        gl = _sum_to(G, None, ctx.shapes[i][0])
+                    if ctx.needs_input_grad[2 + 2 * i]:
+                        gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None)
+                grads += [gl, gs]
+        return tuple(grads)
 
 
 def _tkey(x):
@@ -515,8 +633,10 @@ class TorchDimDist:
                     full = t.Size([*[d.size for d in drawn], *rest])
                     pos = {id(d): k for k, d in enumerate(drawn)}
                     perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
-                    x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full,
-                                             None if perm == list(range(len(perm))) else perm)
+                    perm = None if perm == list(range(len(perm))) else perm
+                    if _DRAW_BATCH[0] is not None:
+                        return _DRAW_BATCH[0].add(la, sa, lazy, full, perm, sample_dims, src, True)
+                    x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full, perm)
                     return ReparamPT(x, sample_dims, src)
                 la, sa = pt_align(loc, self.all_arg_ids, pl), pt_align(sv, self.all_arg_ids, ps)
                 full = t.Size([*shape, *t.broadcast_shapes(la.shape, sa.shape)])
@@ -540,6 +660,12 @@ class TorchDimDist:
                 drawn = [*extra, *self.all_arg_dims]
                 pos = {id(d_): k for k, d_ in enumerate(drawn)}
                 perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
+                if _DRAW_BATCH[0] is not None and la.is_cuda and la.dtype == t.float32:
+                    lazy = isinstance(scale, ExpPT) and not scale.materialised
+                    if lazy:                              # (the exp of a learned log-scale happens in the launch)
+                        sa = pt_align(PT(scale.raw, scale.dims), ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
+                    return _DRAW_BATCH[0].add(la, sa, lazy, [*[d_.size for d_ in drawn], *rest],
+                                              None if perm == list(range(len(perm))) else perm, sample_dims, None, False)
                 eps = t.empty([*[d_.size for d_ in drawn], *rest], dtype=la.dtype, device=la.device).normal_().permute(perm)
                 x = t.addcmul(la, eps, sa, out=t.empty(eps.shape, dtype=la.dtype, device=la.device))
             return PT(x, sample_dims)

@@ -21,6 +21,7 @@ MODE_PRODUCER_GRAD = 6
 MODE_BERNOULLI_LINEAR = 7
 MODE_DOT = 8
 MODE_BERNOULLI_LINEAR_GRAD = 9
+MODE_AFFINE = 10
 MODE_FUSED_FWD, MODE_FUSED_BWD = 100, 101      # (KernelTimer record tags of alan_normal_lse / _backward; not library modes)
 GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
 

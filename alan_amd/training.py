@@ -185,7 +185,10 @@ class GraphedStep:
         self.opt.zero_grad(set_to_none=True)
         sample = self.problem.sample(self.K, reparam=(self.method == "vi"))
         elbo = sample.elbo_vi(self.strategy) if self.method == "vi" else sample.elbo_rws(self.strategy)
-        (-elbo).backward()
+        # ascent on the ELBO: the upstream gradient is the constant -1 (no negation kernel, nor its backward's)
+        if getattr(self, "_minus_one", None) is None or self._minus_one.dtype != elbo.dtype:
+            self._minus_one = t.full((), -1.0, dtype=elbo.dtype, device=elbo.device)
+        elbo.backward(self._minus_one)
         self.opt.step()
         return elbo.detach()
 

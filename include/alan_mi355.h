@@ -95,9 +95,16 @@ typedef enum {
                               is sum over ONE ALAN_DOT dim of their product.  At most 3 terms; fp32 only
                               (ALAN_ERR_UNSUPPORTED otherwise: evaluate the logits and use ALAN_MODE_BERNOULLI).
                               out = out.scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const */
-    ALAN_MODE_DOT = 8,     /* out = sum_R factor_0 * factor_1 (+ add_const): exactly 2 factors.  A term of such logits whose
+    ALAN_MODE_DOT = 8,     /* out = sum_R factor_0 * factor_1 [* g(factor_2)] (+ add_const): 2 factors, or 3 with g as in
+                              ALAN_MODE_AFFINE (the gradient of a reparameterised draw with respect to its log-scale:
+                              sum G * eps * exp(raw)).  A term of such logits whose
                               operands lack some dim of the likelihood's index space, evaluated once (what the lambda's
                               `phi @ bus_company_name` is); small ones join alan_reduce_batch launches */
+    ALAN_MODE_AFFINE = 10, /* out = sum_R [ factor_0 + factor_1 * g(factor_2) ] (+ add_const), g = exp where factor_2.scale == 2
+                              (its tensor holds a log-scale), else the identity: the reparameterised draw
+                              x = loc + eps * scale of a td.Normal (TorchDimDist.py:88-125 d.rsample; Param.py:18-25 the
+                              exp transformation of an OptParam scale) written straight in the sample's layout; several
+                              variables' draws join one alan_reduce_batch launch.  Exactly 3 factors. */
     ALAN_MODE_BERNOULLI_LINEAR_GRAD = 9  /* backward of ALAN_MODE_BERNOULLI_LINEAR with respect to the FIRST operand `a`
                               of its FIRST dot term (movielens: z of `z @ x`) -- what autograd derives from the lambda's
                               batched matmul and TorchDimDist.py:127-162.  The forward's factors and roles unchanged;

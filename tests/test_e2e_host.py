@@ -560,9 +560,12 @@ def test_reparameterised_sampling_through_one_autograd_node_gives_the_same_vi_gr
     particles; same ELBO and the same parameter gradients."""
     from alan_amd import dist as D
     fx = load_golden(fixture)
+    # (one noise call per variable, as torch's rsample makes them: the batch of draws then holds the very same particles)
+    monkeypatch.setattr(D, "BATCH_NOISE", False)
 
-    def run(fuse):
+    def run(fuse, batch):
         monkeypatch.setattr(D, "FUSE_REPARAM", fuse)
+        monkeypatch.setattr(D, "BATCH_DRAWS", batch)
         prob = models.BUILDERS[model](fx).to("cuda").float()
         t.manual_seed(11)
         sample = prob.sample(int(fx["K"]), reparam=True)
@@ -570,12 +573,50 @@ def test_reparameterised_sampling_through_one_autograd_node_gives_the_same_vi_gr
         elbo.backward()
         return float(elbo), {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None}
 
-    (e1, g1), (e0, g0) = run(True), run(False)
-    assert abs(e1 - e0) <= 1e-6 * abs(e0), (e1, e0)
-    assert g1.keys() == g0.keys() and len(g0) >= 2
-    for n in g0:
-        scale = float(g0[n].abs().max()) + 1e-6
-        t.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
+    # the draws of the ancestral pass as one batch (dist.BATCH_DRAWS: one affine launch, one backward node) / one node per
+    # variable / plain torch
+    (e2, g2), (e1, g1), (e0, g0) = run(True, True), run(True, False), run(False, False)
+    for e, g in ((e2, g2), (e1, g1)):
+        assert abs(e - e0) <= 1e-6 * abs(e0), (e, e0)
+        assert g.keys() == g0.keys() and len(g0) >= 2
+        for n in g0:
+            scale = float(g0[n].abs().max()) + 1e-6
+            t.testing.assert_close(g[n], g0[n], rtol=2e-4, atol=2e-5 * scale, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reparam", [False, True], ids=["plain", "reparam"])
+def test_batched_draws_have_the_proposals_distribution(reparam):
+    """dist.BATCH_DRAWS with its single noise call (BATCH_NOISE: other particles than torch's variable-by-variable
+    rsample under the same seed): every latent's particles have the proposal's mean, spread and mass within one sigma,
+    and different latents' particles are uncorrelated (they share one noise buffer)."""
+    g = t.Generator().manual_seed(5)
+    x = t.randn(40, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(40, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 40, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    with t.no_grad():                                   # a proposal that is not standard: loc 0.7, scale exp(-0.4)
+        for n, p in prob.named_parameters():
+            p.fill_(-0.4 if n.endswith("_scale") else 0.7)
+    params = {n: round(float(p.flatten()[0]), 5) for n, p in prob.named_parameters()}
+    assert set(params.values()) == {0.7, -0.4}, params
+    t.manual_seed(0)
+    K = 4000
+    sample = prob.sample(K, reparam=reparam)
+    pts = sample._pt_detached
+    latents = {"mu_z": pts["mu_z"].x, "psi_z": pts["psi_z"].x, "z": pts["plate_1"]["z"].x}
+    import math
+    for name, v in latents.items():
+        v = v.double()
+        n = v.numel()
+        loc, scale = 0.7, math.exp(-0.4)
+        assert abs(float(v.mean()) - loc) < 6 * scale / math.sqrt(n), (name, float(v.mean()))
+        assert abs(float(v.std()) - scale) < 6 * scale / math.sqrt(2 * n), (name, float(v.std()))
+        inside = float(((v - loc).abs() < scale).double().mean())
+        assert abs(inside - 0.6827) < 6 * math.sqrt(0.6827 * 0.3173 / n), (name, inside)
+    a, b = latents["mu_z"].flatten()[: 18 * K].double(), latents["psi_z"].flatten()[: 18 * K].double()
+    corr = float(((a - a.mean()) * (b - b.mean())).mean() / (a.std() * b.std()))
+    assert abs(corr) < 6 / math.sqrt(a.numel()), corr
 
 
 @pytest.mark.gpu
@@ -657,6 +698,7 @@ def test_reparameterisation_nodes_on_other_model_shapes(build, monkeypatch):
     events with per-plate-element parameters, a Group of seven variables on one K."""
     from alan_amd import dist as D
     res = {}
+    monkeypatch.setattr(D, "BATCH_NOISE", False)      # (one noise call per variable: torch's particles under this seed)
     for fuse in (True, False):
         monkeypatch.setattr(D, "FUSE_REPARAM", fuse)
         prob, K = build()
