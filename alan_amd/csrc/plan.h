@@ -170,6 +170,36 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype);
 int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, void *workspace,
                 size_t workspace_bytes, hipStream_t stream, const EvPair &ev = EvPair());
 
+// pair.hip: a log-sum-exp whose output is bigger than every factor (two factors that meet only in the reduce dim), tiles
+// of the output with the factors' rows staged in LDS; optional plate sum inside the workgroup.
+constexpr int PAIR_NB = 3, PAIR_NP = 2, PAIR_T = 16, PAIR_RMAX = 256;
+
+struct PairDesc {
+    // the factors by side -- row side: carries the tile dim i (or neither tile dim), col side: carries j -- in MAXF / 2 slots
+    // each; a slot nobody uses repeats the side's first factor with weight 0 (no branch around a load)
+    const float *f[2][MAXF / 2];
+    float w[2][MAXF / 2];
+    int32_t ns[2];                            // slots in use per side
+    int32_t sa[2][MAXF / 2], sx[2][MAXF / 2];             // strides over a and over the side's tile dim
+    int32_t sb[2][MAXF / 2][PAIR_NB], sp[2][MAXF / 2][PAIR_NP];
+    float *out;
+    int32_t R, NI, NJ, n_plate, ntj;
+    float add_const;
+    FastDiv bdiv[PAIR_NB], pdiv[PAIR_NP];     // batch (kept) dims and plate dims, right-aligned; unused: size 1
+    FastDiv rdiv;                             // by R
+    int32_t a_fast[2];                        // staging: lanes along a (else along the tile dim)
+    int32_t split;                            // a plate element per workgroup (gridDim.z), partial results in ws
+    float *ws;
+    int32_t osb[PAIR_NB], osi, osj;
+};
+
+
+bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint32_t plate, PairDesc &pd, dim3 &grid,
+                  size_t &lds_bytes);
+size_t pair_workspace_bytes(const PairDesc &pd, dim3 grid);
+int launch_pair(const PairDesc &pd, dim3 grid, size_t lds_bytes, void *workspace, size_t workspace_bytes,
+                hipStream_t stream, const EvPair &ev);
+
 // normal.hip: register-blocked Normal producer (value / loc / scale on disjoint dims).
 // (dry: only answer whether it would take the problem)
 int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, double add_const, hipStream_t stream,

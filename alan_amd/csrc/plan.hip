@@ -817,6 +817,12 @@ extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     }
     if (!plate || !red) return 0;
     {
+        PairDesc pd;
+        dim3 grid;
+        size_t lds;
+        if (pair_prepare(*d, keep, red, plate, pd, grid, lds)) return (pair_workspace_bytes(pd, grid) + 255) & ~(size_t)255;
+    }
+    {
         Canon c;
         RowsPlan rp;
         if (plan_fused_plate(*d, keep, red, plate, c, rp)) return (rp.partial_bytes + 255) & ~(size_t)255;
@@ -899,9 +905,30 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
             return run_single(s2, keep, 1u << p, d->mode, d->out, d->add_const, stream);
         }
     }
+    {
+        // an output bigger than every factor (two factors meeting only in the reduce dim): tiles staged in LDS
+        PairDesc pd;
+        dim3 grid;
+        size_t lds;
+        if (pair_prepare(*d, keep, red, plate, pd, grid, lds))
+            return launch_pair(pd, grid, lds, workspace, workspace_bytes, stream, ev);
+    }
     if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream, ev);
 
     // ---- log-sum-exp over REDUCE, then sum over PLATE (logpq.py:128,149)
+    static const int sp_knob = env_knob("ALAN_SMALL_PLATE");                          // ablation knob: 0 = two launches
+    static const int sp_first = env_knob("ALAN_SMALL_PLATE_FIRST");                   // tuning knob: elements below which
+    {
+        // a factor of a few hundred KB is not a stream: the rows kernel's windows and two-stage plate sum cost it 15 us
+        // (bus_breakdown's Year plate at K = 100, 20,000 elements) where the lane-group kernel takes 5
+        int64_t elems = 1;
+        for (int i = 0; i < d->ndim; ++i) elems *= d->size[i];
+        SmallPlateDesc sp;
+        GroupLaunch gl;
+        if (sp_knob != 0 && !d->lse_out.data && elems <= (sp_first != ENV_UNSET ? (int64_t)sp_first : (1ll << 17)) &&
+            small_plate_prepare(*d, sp, gl))
+            return launch_small_plate(sp, gl, stream, ev);
+    }
     {
         Canon c;
         RowsPlan rp;
@@ -909,7 +936,6 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
             return launch_rows(c, rp, ALAN_MODE_LSE, d->add_const, workspace, workspace_bytes, stream, ev);
     }
     {
-        static const int sp_knob = env_knob("ALAN_SMALL_PLATE");                      // ablation knob: 0 = two launches
         SmallPlateDesc sp;
         GroupLaunch gl;
         if (sp_knob != 0 && small_plate_prepare(*d, sp, gl)) return launch_small_plate(sp, gl, stream, ev);

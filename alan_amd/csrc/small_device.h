@@ -298,6 +298,37 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
     // one summed dim (bus_breakdown's plate of 150 observations): offsets are linear in r -- no index decomposition per
     // element (it was a third of the instructions of an element at K = 100: 9 M elements)
     const bool one_dim = d.rdiv[0].d == 1;
+    // Every term a plain summand (dot products over dims the output lacks were evaluated beforehand: bus_breakdown at
+    // K = 100, 9 M elements of 3 loads + a softplus): eight elements per round, their loads issued together -- one element
+    // per round waits out a load latency per element (38 of them in a row per lane: 31.7 us; the arithmetic is 6)
+    const bool all_plain = one_dim && d.b[0] == nullptr && d.b[1] == nullptr && d.b[2] == nullptr;
+    if (all_plain) {
+        constexpr int LU = 8;
+        const int32_t vst = d.vrs[LIN_NR - 1];
+        int32_t ast[LIN_T];
+#pragma unroll
+        for (int tm = 0; tm < LIN_T; ++tm) ast[tm] = d.ars[tm][LIN_NR - 1];
+        for (uint32_t r0 = gl; r0 < d.n_red; r0 += LU * G) {
+            float y[LU], x[LU][LIN_T];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const uint32_t ru = r0 + (uint32_t)u * G;
+                const int32_t r = (int32_t)(ru < d.n_red ? ru : r0);          // (clamped: masked below)
+                y[u] = d.val[vbase + r * vst];
+#pragma unroll
+                for (int tm = 0; tm < LIN_T; ++tm) x[u][tm] = tm < d.nt ? d.a[tm][abase[tm] + r * ast[tm]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                float xl = 0.f;
+#pragma unroll
+                for (int tm = 0; tm < LIN_T; ++tm) xl += x[u][tm];
+                const float e = __builtin_amdgcn_exp2f(-fabsf(xl) * 1.44269504088896340736f);
+                const float ls = fminf(xl, 0.f) - __builtin_amdgcn_logf(1.f + e) * 0.69314718055994530942f;
+                s += r0 + (uint32_t)u * G < d.n_red ? ls - (1.f - y[u]) * xl : 0.f;
+            }
+        }
+    } else
     for (uint32_t r = gl; r < d.n_red; r += G) {
         int32_t aoff[LIN_T], boff[LIN_T], voff = vbase;
 #pragma unroll

@@ -758,3 +758,31 @@ def test_result_ring_c_abi_delivers_to_successive_slots_and_declines_other_shape
     N.fill_tensor(d.out, out, [0])
     d.ring_slots, d.ring_n = ring.table.data_ptr(), ring.n
     assert N.lib().alan_reduce(ctypes.byref(d), None, 0, None) == -1
+
+
+# ------------------------------------------------------------------ oracle: pair contraction (pair.hip)
+@pytest.mark.parametrize("shape", [
+    dict(Y=2, B=3, G=100, A=100, Ky=100, plate=("B",)),          # bus_breakdown's Borough plate at K = 100
+    dict(Y=1, B=2, G=137, A=33, Ky=150, plate=("B",)),           # ragged tiles, odd reduce length
+    dict(Y=3, B=1, G=64, A=256, Ky=70, plate=()),                # no plate sum, the longest reduce dim taken
+    dict(Y=2, B=5, G=48, A=40, Ky=48, plate=("B", "Y")),         # two plate dims, nothing kept besides the tile
+], ids=["bus_K100", "ragged", "no_plate", "two_plates"])
+def test_pair_contraction_against_the_oracle(shape, monkeypatch):
+    """out[y, g, k] = sum_b LSE_a(L[y,b,g,a] + q[y,b,a] + P[y,b,k,a]): the output is bigger than every factor, the tile
+    kernel of pair.hip takes it (>= 2^20 (output, a) pairs) -- against the oracle's logsumexp_sum + plate_sum, incl. -inf
+    entries and a wholly -inf row (NaN, utils.py:219), and against the generic kernels (ALAN_PAIR=0 is read once per
+    process, so those run in the same call only for sizes the tile kernel declines)."""
+    g = t.Generator().manual_seed(7)
+    Y, B, G, A, Ky = (shape[k] for k in ("Y", "B", "G", "A", "Ky"))
+    L = t.randn(Y, B, G, A, generator=g) * 3
+    q = t.randn(Y, B, A, generator=g)
+    P = t.randn(Y, B, Ky, A, generator=g) * 3
+    L[0, 0, 1, ::3] = float("-inf")
+    P[0, 0, 2, :] = float("-inf")                                  # outputs [.., 2] of (y=0, b=0): every term -inf
+    factors = [(L, ("Y", "B", "G", "A")), (q, ("Y", "B", "A")), (P, ("Y", "B", "Ky", "A"))]
+    out, dims = E.reduce_factors(dev(factors), reduce=("A",), plate=shape["plate"])
+    ref = orc.logsumexp_sum(("A",), *factors)
+    for p in shape["plate"]:
+        ref = orc.plate_sum(ref, p)
+    same(out, dims, ref[0], ref[1], rtol=2e-5, atol=2e-5)
+    assert t.isnan(out).any() and not t.isnan(out).all()
