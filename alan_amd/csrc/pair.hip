@@ -7,7 +7,7 @@
 // (K_alpha, K_year) -- eliminating K_alpha leaves [K_global, K_year] per (Year, Borough): 6 log-space products of
 // [100 x 100] . [100 x 100] at K = 100, 6 M (output, a) pairs from two 240 KB factors.  The generic kernel gives every
 // output its own lane group that walks `a` through global memory (12 M strided loads: 28.6 us); here a workgroup owns a
-// 16 x 16 tile of (i, j), stages the two tiles' rows over `a` in LDS once -- each factor element is read once per tile
+// 8 x 8 tile of (i, j), stages the two tiles' rows over `a` in LDS once -- each factor element is read once per tile
 // it touches, with `a` (their contiguous dim) along the lanes -- and a thread takes its output's exact max and its sum
 // of exps from LDS (two passes, as utils.py:218-220 does), adding the plate elements in order (deterministic).
 // NOT the matrix cores: a log-space product has no linear-space GEMM without giving up the exact max of each output.
@@ -18,12 +18,20 @@
 
 namespace alan {
 
+// BERN: the same tiles with another function of the summed term -- the Bernoulli likelihood of observations y[b, a] whose
+// logits are row + col (ALAN_MODE_BERNOULLI_LINEAR with plain terms only: bus_breakdown's `alpha + phi @ x1 + psi @ x2`
+// once the dot products, which lack the K_alpha dim, have been evaluated: 9 M elements at K = 100),
+//   out[b, i, j] = out_scale * sum_a [ logsigmoid(l) - (1 - y[b, a]) l ] + add_const,    l = row[a, i] + col[a, j].
+template <bool BERN>
 __global__ __launch_bounds__(256) void pair_lse_kernel(const PairDesc d) {
     extern __shared__ __align__(16) float lds[];
     constexpr int HS = MAXF / 2;
     const int tid = threadIdx.x, R = d.R, R1 = R | 1;
     float *row = lds, *col = lds + PAIR_T * R1;          // [16][R1] each: a thread walks its own row of each
-    const int ti = tid >> 4, tj = tid & 15;
+    float *yl = col + PAIR_T * R1;                       // BERN: [R]
+    // four lanes per output, each a quarter of the reduce dim (interleaved): 64 outputs per workgroup -- an output per lane
+    // would be fewer waves than the chip has SIMDs at bus_breakdown's size (60,000 outputs), each alone with its LDS latency
+    const int q4 = tid & 3, tj = (tid >> 2) & (PAIR_T - 1), ti = tid >> 5;
     const int tile_i = blockIdx.x / d.ntj, tile_j = blockIdx.x - tile_i * d.ntj;
     const int i0 = tile_i * PAIR_T, j0 = tile_j * PAIR_T;
     // the kept batch index of this workgroup
@@ -44,6 +52,16 @@ __global__ __launch_bounds__(256) void pair_lse_kernel(const PairDesc d) {
 #pragma unroll
                 for (int h = 0; h < HS; ++h) bb[sd][h] += idx * d.sb[sd][h][k];
             ob += idx * d.osb[k];
+        }
+    }
+    int32_t yb = 0;
+    if (BERN) {
+        uint32_t o = blockIdx.y;
+#pragma unroll
+        for (int k = PAIR_NB - 1; k >= 0; --k) {
+            const uint32_t q = fd_div(o, d.bdiv[k]);
+            yb += (int32_t)(o - q * d.bdiv[k].d) * d.y_sb[k];
+            o = q;
         }
     }
     const float ninf = -__builtin_huge_valf();
@@ -81,11 +99,15 @@ __global__ __launch_bounds__(256) void pair_lse_kernel(const PairDesc d) {
             if (a_fast)
                 x = (int)fd_div((uint32_t)e, d.rdiv), a = e - x * R;
             else
-                a = e >> 4, x = e & 15;
+                a = e / PAIR_T, x = e & (PAIR_T - 1);
         };
         float lr[NE][HS], lc[NE][HS];
+        const float yv = BERN ? d.y[yb + min(tid, R - 1) * d.y_sa] : 0.f;
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
+#pragma unroll
+            for (int h = 0; h < HS; ++h) lr[u][h] = lc[u][h] = 0.f;
+            if (256 * u >= PAIR_T * R) continue;       // (uniform: a whole round beyond the tile -- no load, no wait)
             const int e = min(tid + 256 * u, PAIR_T * R - 1);
             int xr, ar, xc, ac;
             split(e, d.a_fast[0], xr, ar);
@@ -114,32 +136,57 @@ __global__ __launch_bounds__(256) void pair_lse_kernel(const PairDesc d) {
                 col[xc * R1 + ac] = cv;
             }
         }
+        if (BERN && tid < R) yl[tid] = yv;
         __syncthreads();
-        // ---- this thread's output: exact max, then the sum of exps (utils.py:218-220)
         const float *rp = row + ti * R1, *cp = col + tj * R1;
-        float m0 = ninf, m1 = ninf, m2 = ninf, m3 = ninf;
-        int a = 0;
-        for (; a + 4 <= R; a += 4) {
+        if (BERN) {
+            // logsigmoid(x) - (1 - y) x on the fast transcendental instructions, as the lane-group kernel evaluates it
+            float s0 = 0.f, s1 = 0.f;
+            int a = q4;
+            for (; a + 4 < R; a += 8) {
+                const float x0 = rp[a] + cp[a], x1 = rp[a + 4] + cp[a + 4];
+                const float e0 = __builtin_amdgcn_exp2f(-fabsf(x0) * 1.44269504088896340736f);
+                const float e1 = __builtin_amdgcn_exp2f(-fabsf(x1) * 1.44269504088896340736f);
+                s0 += fminf(x0, 0.f) - __builtin_amdgcn_logf(1.f + e0) * 0.69314718055994530942f - (1.f - yl[a]) * x0;
+                s1 += fminf(x1, 0.f) - __builtin_amdgcn_logf(1.f + e1) * 0.69314718055994530942f - (1.f - yl[a + 4]) * x1;
+            }
+            for (; a < R; a += 4) {
+                const float x0 = rp[a] + cp[a];
+                const float e0 = __builtin_amdgcn_exp2f(-fabsf(x0) * 1.44269504088896340736f);
+                s0 += fminf(x0, 0.f) - __builtin_amdgcn_logf(1.f + e0) * 0.69314718055994530942f - (1.f - yl[a]) * x0;
+            }
+            s0 += s1;
+            s0 += __shfl_xor(s0, 1);
+            s0 += __shfl_xor(s0, 2);
+            s1 = 0.f;
+            total += (s0 + s1) * d.out_scale;
+            continue;
+        }
+        // ---- this thread's output: exact max, then the sum of exps (utils.py:218-220)
+        float m0 = ninf, m1 = ninf;
+        int a = q4;
+        for (; a + 4 < R; a += 8) {
             m0 = fmaxf(m0, rp[a] + cp[a]);
-            m1 = fmaxf(m1, rp[a + 1] + cp[a + 1]);
-            m2 = fmaxf(m2, rp[a + 2] + cp[a + 2]);
-            m3 = fmaxf(m3, rp[a + 3] + cp[a + 3]);
+            m1 = fmaxf(m1, rp[a + 4] + cp[a + 4]);
         }
-        for (; a < R; ++a) m0 = fmaxf(m0, rp[a] + cp[a]);
-        // (fmaxf drops a NaN operand: a NaN term must poison the result as torch's amax does)
-        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; a < R; a += 4) m0 = fmaxf(m0, rp[a] + cp[a]);
+        // (fmaxf drops a NaN operand: a NaN term must poison the result as torch's amax does -- it does through the sum)
+        float m = fmaxf(m0, m1);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        m = fmaxf(m, __shfl_xor(m, 2));
+        float s0 = 0.f, s1 = 0.f;
         const float mf = (m == ninf || m == -ninf) ? 0.f : m;
-        for (a = 0; a + 4 <= R; a += 4) {
+        for (a = q4; a + 4 < R; a += 8) {
             s0 += __expf(rp[a] + cp[a] - mf);
-            s1 += __expf(rp[a + 1] + cp[a + 1] - mf);
-            s2 += __expf(rp[a + 2] + cp[a + 2] - mf);
-            s3 += __expf(rp[a + 3] + cp[a + 3] - mf);
+            s1 += __expf(rp[a + 4] + cp[a + 4] - mf);
         }
-        for (; a < R; ++a) s0 += __expf(rp[a] + cp[a] - mf);
-        total += lse_finish(m, (s0 + s1) + (s2 + s3));    // (a NaN term: exp(NaN) = NaN reaches the sum)
+        for (; a < R; a += 4) s0 += __expf(rp[a] + cp[a] - mf);
+        s0 += s1;
+        s0 += __shfl_xor(s0, 1);
+        s0 += __shfl_xor(s0, 2);
+        total += lse_finish(m, s0);                       // (a NaN term: exp(NaN) = NaN reaches the sum)
     }
-    if (i0 + ti < d.NI && j0 + tj < d.NJ) {
+    if (q4 == 0 && i0 + ti < d.NI && j0 + tj < d.NJ) {
         if (d.split)
             d.ws[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * d.NI + i0 + ti) * d.NJ + j0 + tj] = total;
         else
@@ -170,10 +217,21 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
                   size_t &lds_bytes) {
     static const int knob = env_knob("ALAN_PAIR");                                   // ablation knob: 0 = off
     if (knob == 0) return false;
-    if (d.mode != ALAN_MODE_LSE || d.n_factors < 2 || d.n_factors > MAXF) return false;
+    const bool bern = d.mode == ALAN_MODE_BERNOULLI_LINEAR;
+    if ((d.mode != ALAN_MODE_LSE && !bern) || d.n_factors < 2 || d.n_factors > MAXF) return false;
     if (d.weight.data || d.lse_out.data || d.ring_n || d.out.dtype != ALAN_F32 || !d.out.data) return false;
     for (int f = 0; f < d.n_factors; ++f)
         if (d.factor[f].dtype != ALAN_F32 || !d.factor[f].data) return false;
+    // BERN: factor 0 is the observations; every other factor a plain term of its own (term ids 1, 2, ...: no dot
+    // products, no DOT dims) -- and no plate sum, which that mode does not have
+    const int f0 = bern ? 1 : 0;
+    if (bern) {
+        if (plate || d.n_factors < 3) return false;
+        for (int f = 1; f < d.n_factors; ++f)
+            if ((int)d.factor[f].scale != f) return false;
+        for (int i = 0; i < d.ndim; ++i)
+            if (d.role[i] == ALAN_DOT && d.size[i] > 1) return false;
+    }
     // the one reduce dim; kept dims; plate dims (sizes > 1 only)
     int ia = -1, kd[MAXD], nk = 0, pl[MAXD], np = 0;
     for (int i = 0; i < d.ndim; ++i) {
@@ -194,8 +252,9 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
     for (int x = 0; x < nk; ++x)
         for (int y = x + 1; y < nk; ++y) {
             bool ok = true;
-            for (int f = 0; f < d.n_factors; ++f)
+            for (int f = f0; f < d.n_factors; ++f)
                 if (d.factor[f].stride[kd[x]] != 0 && d.factor[f].stride[kd[y]] != 0) ok = false;
+            if (bern && (d.factor[0].stride[kd[x]] != 0 || d.factor[0].stride[kd[y]] != 0)) ok = false;
             const int64_t n = d.size[kd[x]] * d.size[kd[y]];
             if (ok && n > best) best = n, bi = kd[x], bj = kd[y];
         }
@@ -230,7 +289,17 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
     int n_side[2] = {0, 0};
     int64_t big[2] = {-1, -1};
     pd.a_fast[0] = pd.a_fast[1] = 1;
-    for (int f = 0; f < d.n_factors; ++f) {
+    if (bern) {
+        const alan_tensor_t &y = d.factor[0];
+        if (!reach_ok(y)) return false;
+        for (int i = 0; i < d.ndim; ++i)
+            if (y.stride[i] < 0) return false;
+        pd.y = (const float *)y.data;
+        pd.y_sa = (int32_t)y.stride[ia];
+        for (int k = 0; k < nb; ++k) pd.y_sb[PAIR_NB - nb + k] = (int32_t)y.stride[bdims[k]];
+        pd.out_scale = d.out.scale;
+    }
+    for (int f = f0; f < d.n_factors; ++f) {
         const alan_tensor_t &x = d.factor[f];
         if (!reach_ok(x)) return false;
         for (int i = 0; i < d.ndim; ++i)
@@ -238,7 +307,7 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
         const int sd = x.stride[bj] != 0 ? 1 : 0, h = n_side[sd]++;
         if (h == MAXF / 2) return false;
         pd.f[sd][h] = (const float *)x.data;
-        pd.w[sd][h] = x.scale;
+        pd.w[sd][h] = bern ? 1.f : x.scale;
         pd.sa[sd][h] = (int32_t)x.stride[ia];
         pd.sx[sd][h] = (int32_t)x.stride[sd ? bj : bi];
         for (int k = 0; k < nb; ++k) pd.sb[sd][h][PAIR_NB - nb + k] = (int32_t)x.stride[bdims[k]];
@@ -280,12 +349,13 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
     // 3 plate elements each, a third of the chip's CUs with one wave per SIMD -- and a second launch that adds the plate
     // elements in order
     static const int split_knob = env_knob("ALAN_PAIR_SPLIT");                         // ablation knob: 0 = off
+    pd.bern = bern ? 1 : 0;
     if (split_knob != 0 && n_plate >= 2 && n_plate <= 65535 && (int64_t)grid.x * grid.y < 512 &&
         n_batch * pd.NI * pd.NJ < (1ll << 31)) {
         pd.split = 1;
         grid.z = (uint32_t)n_plate;
     }
-    lds_bytes = (size_t)2 * PAIR_T * (pd.R | 1) * sizeof(float);
+    lds_bytes = ((size_t)2 * PAIR_T * (pd.R | 1) + (bern ? pd.R : 0)) * sizeof(float);
     return true;
 }
 
@@ -300,7 +370,10 @@ int launch_pair(const PairDesc &pd_, dim3 grid, size_t lds_bytes, void *workspac
         if (!workspace || workspace_bytes < pair_workspace_bytes(pd, grid)) return ALAN_ERR_WORKSPACE;
         pd.ws = (float *)workspace;
     }
-    hipExtLaunchKernelGGL(pair_lse_kernel, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
+    if (pd.bern)
+        hipExtLaunchKernelGGL(pair_lse_kernel<true>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
+    else
+        hipExtLaunchKernelGGL(pair_lse_kernel<false>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
     if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     if (pd.split) {
         const uint32_t n = grid.y * (uint32_t)pd.NI * (uint32_t)pd.NJ;

@@ -172,7 +172,7 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
 
 // pair.hip: a log-sum-exp whose output is bigger than every factor (two factors that meet only in the reduce dim), tiles
 // of the output with the factors' rows staged in LDS; optional plate sum inside the workgroup.
-constexpr int PAIR_NB = 3, PAIR_NP = 2, PAIR_T = 16, PAIR_RMAX = 256;
+constexpr int PAIR_NB = 3, PAIR_NP = 2, PAIR_T = 8, PAIR_RMAX = 256;
 
 struct PairDesc {
     // the factors by side -- row side: carries the tile dim i (or neither tile dim), col side: carries j -- in MAXF / 2 slots
@@ -191,6 +191,10 @@ struct PairDesc {
     int32_t split;                            // a plate element per workgroup (gridDim.z), partial results in ws
     float *ws;
     int32_t osb[PAIR_NB], osi, osj;
+    int32_t bern;                             // the Bernoulli-of-linear-logits variant: observations y[b, a]
+    const float *y;
+    int32_t y_sa, y_sb[PAIR_NB];
+    float out_scale;
 };
 
 

@@ -658,7 +658,19 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     for (int i = 0; i < n; ++i) {
         if (descs[i]->mode == ALAN_MODE_BERNOULLI_LINEAR) {
             // one per multi launch (its argument has its own slot there); a second one goes out alone, below
-            other[i] = have_lin || descs[i]->ev_start || descs[i]->ev_stop || lin_prepare(*descs[i], lin, gl[m]) != ALAN_OK;
+            bool tiles = false;                       // (plain terms, millions of elements: the tile kernel, a launch of its own)
+            {
+                uint32_t keep = 0, red = 0;
+                for (int k = 0; k < descs[i]->ndim && k < MAXD; ++k) {
+                    if (descs[i]->role[k] == ALAN_KEEP) keep |= 1u << k;
+                    if (descs[i]->role[k] == ALAN_REDUCE) red |= 1u << k;
+                }
+                PairDesc pd;
+                dim3 grid;
+                size_t lds;
+                tiles = descs[i]->ndim <= MAXD && pair_prepare(*descs[i], keep, red, 0, pd, grid, lds);
+            }
+            other[i] = tiles || have_lin || descs[i]->ev_start || descs[i]->ev_stop || lin_prepare(*descs[i], lin, gl[m]) != ALAN_OK;
             if (!other[i]) {
                 have_lin = true;
                 mode[m] = ALAN_MODE_BERNOULLI_LINEAR;
@@ -852,6 +864,18 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         EvPair ev;
         ev.start = (hipEvent_t)d->ev_start;
         ev.stop = (hipEvent_t)d->ev_stop;
+        if (d->mode == ALAN_MODE_BERNOULLI_LINEAR) {
+            // plain terms that meet only in the summed dim, millions of elements: output tiles with the terms staged in LDS
+            uint32_t keep = 0, red = 0;
+            for (int i = 0; i < d->ndim; ++i) {
+                if (d->role[i] == ALAN_KEEP) keep |= 1u << i;
+                if (d->role[i] == ALAN_REDUCE) red |= 1u << i;
+            }
+            PairDesc pd;
+            dim3 grid;
+            size_t lds;
+            if (pair_prepare(*d, keep, red, 0, pd, grid, lds)) return launch_pair(pd, grid, lds, nullptr, 0, stream, ev);
+        }
         return d->mode == ALAN_MODE_BERNOULLI_LINEAR ? launch_lin(ld, gl, stream, ev) : launch_lin_grad(ld, stream, ev);
     }
     uint32_t keep, red, plate;

@@ -87,6 +87,26 @@ def test_bus_breakdown_logits_sum_of_terms_and_strided_operands():
     t.testing.assert_close(keep4.cpu().double(), want4, rtol=3e-6, atol=2e-5)
 
 
+@pytest.mark.parametrize("Ka,Kg,Y,B,I", [(100, 100, 2, 3, 150), (37, 130, 1, 2, 255), (64, 48, 3, 1, 9)],
+                         ids=["bus_K100", "ragged", "short_sum"])
+def test_plain_terms_meeting_only_in_the_summed_dim_take_the_tile_kernel(Ka, Kg, Y, B, I):
+    """logits = alpha[Ka, Y, B] + d1[Y, B, I, Kg] + d2[Kg, Y, B, I] (bus_breakdown once its dot products, which lack the
+    K_alpha dim, are evaluated): >= 2^20 elements go to pair.hip's tiles (the Bernoulli variant), smaller ones to the
+    lane-group kernel -- both against torch in fp64; permuted storage of every operand."""
+    g = t.Generator().manual_seed(13)
+    alpha = t.randn(Ka, Y, B, generator=g).to(DEV)
+    d1 = (2 * t.randn(Y, B, I, Kg, generator=g)).to(DEV)
+    d2 = t.randn(Kg, Y, B, I, generator=g).to(DEV)
+    obs = (t.rand(I, B, Y, generator=g) < 0.5).float().to(DEV).permute(2, 1, 0)
+    val = (obs, ("Y", "B", "I"))
+    terms = [((alpha, ("Ka", "Y", "B")),), ((d1, ("Y", "B", "I", "Kg")),), ((d2, ("Kg", "Y", "B", "I")),)]
+    for out_dims, aff in ((("Y", "B", "Ka", "Kg"), (1.0, 0.0)), (("Kg", "Y", "B", "Ka"), (-1.0, 0.25))):
+        got = E.bernoulli_linear_logprob(val, terms, out_dims, aff)
+        cpu = lambda term: tuple((x.cpu(), d) for x, d in term)
+        want = aff[0] * _ref(obs.cpu(), val[1], [cpu(tm) for tm in terms], out_dims) + aff[1]
+        t.testing.assert_close(got.cpu().double(), want, rtol=3e-6, atol=3e-5 * I ** 0.5)
+
+
 def test_unsupported_shapes_are_declined_not_miscomputed():
     g = t.Generator().manual_seed(2)
     z, x = t.randn(4, 6, 3, generator=g).to(DEV), t.randn(6, 5, 3, generator=g).to(DEV)
