@@ -1215,6 +1215,186 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_pair_backward_kernel(
     }
 }
 
+// The same backward for fp32 with its three K x K x K products on the matrix cores and its phases rebuilt around the
+// launch's latencies (round 3; T = 1000: K = 30 was 10 launches of 17 us whatever the number of pairs -- conditional
+// loads each followed by its own wait, row maxima walked by 60 of the 256 threads --, K = 100 10 launches of 142 us of
+// vector-unit multiply-adds):
+//   loads      every element of P, C and G of a thread's share requested before the first is used (indices clamped, no
+//              branch around a load), eight rounds at a time;
+//   maxima / sums of a row or column: one wave per row, lanes along it, a shuffle tree (all four waves busy);
+//   products   v_mfma_f32_32x32x2_f32 on 32 x 32 output tiles, operands read from LDS as the instruction wants them -- A
+//              one (row, k) per lane, B one (k, column) -- out of matrices with an ODD row stride, so a row walk and a
+//              column walk are both conflict-free and no transposed copy is needed; tiles dealt to the waves; rows and
+//              columns beyond K are clamped reads times a zero mask (no padded copies: three K x K matrices are 121 KB at
+//              K = 100).  The eps-floor paths (amax ties) are kept exactly as in the vector kernel.
+// NT: threads of the workgroup -- 1024 above K = 48 (three K x K matrices fill most of a CU's LDS: one workgroup per CU
+// whatever its size, so sixteen waves share the tiles and keep four times the loads in flight), 256 below.
+template <int NT>
+__global__ __launch_bounds__(NT) void chain_pair_backward_mfma_kernel(
+    const float *src, int64_t sB, int64_t sT, int64_t sRow, int64_t sCol, int n_src, int K,
+    const float *G,                                       // [B][gridDim.x][K][K], or nullptr at the root
+    const float *root, int64_t rB, int64_t rRow, int64_t rCol, const float *vec, const float *grad_vec,
+    const float *grad_chain, float *dsrc) {               // [B][n_src][K][K]
+    typedef float T;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int KS = K | 1;
+    T *Pe = reinterpret_cast<T *>(smem_raw);
+    T *Ce = Pe + (size_t)K * KS;
+    T *Gp = Ce + (size_t)K * KS;
+    T *pm = Gp + (size_t)K * KS, *cm = pm + K, *pw = cm + K, *cw = pw + K;
+    const int tid = threadIdx.x, KK = K * K, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.y, node = blockIdx.x;
+    const int t0 = 2 * (int)node, t1 = t0 + 1;
+    const T NINF = Num<T>::ninf();
+    auto upstream_root = [&](int i, int j) -> T {
+        T g = grad_chain ? grad_chain[(b * K + i) * K + j] : T(0);
+        if (grad_vec) {
+            const T v = vec[b * K + i];
+            if (v != NINF) g += grad_vec[b * K + i] * Num<T>::exp_acc(root[b * rB + i * rRow + j * rCol] - v);
+        }
+        return g;
+    };
+    T *dP = dsrc + (b * n_src + t0) * (int64_t)KK;
+    const T *Gn = G ? G + (b * gridDim.x + node) * (int64_t)KK : nullptr;
+    if (t1 >= n_src) {                                    // leftover of this round (utils.py:488-495)
+        for (int e = tid; e < KK; e += NT) dP[e] = Gn ? Gn[e] : upstream_root(e / K, e % K);
+        return;
+    }
+    T *dC = dP + KK;
+    const T *Pg = src + b * sB + (int64_t)t0 * sT, *Cg = src + b * sB + (int64_t)t1 * sT;
+    // (e / K without the integer-division sequence: a float estimate and one correction each way, exact for e < 2^22)
+    const float invK = 1.f / (float)K;
+    auto row_of = [&](int e) {
+        int i = (int)((float)e * invK);
+        i -= (i * K > e) ? 1 : 0;
+        i += ((i + 1) * K <= e) ? 1 : 0;
+        return i;
+    };
+    // ---- loads
+    constexpr int CH = 8;
+    for (int e0 = tid; e0 < KK; e0 += NT * CH) {
+        T pv[CH], cv[CH], gv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (e0 - tid + NT * u >= KK) {     // (uniform: a whole round beyond the matrices)
+                pv[u] = cv[u] = gv[u] = T(0);
+                continue;
+            }
+            const int e = min(e0 + NT * u, KK - 1), i = row_of(e), j = e - i * K;
+            pv[u] = Pg[i * sRow + j * sCol];
+            cv[u] = Cg[i * sRow + j * sCol];
+            gv[u] = Gn ? Gn[e] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int e = e0 + NT * u;
+            if (e < KK) {
+                const int i = row_of(e), j = e - i * K;
+                Pe[i * KS + j] = pv[u], Ce[i * KS + j] = cv[u];
+                Gp[i * KS + j] = Gn ? gv[u] : upstream_root(i, j);         // (the root: one launch of one pair)
+            }
+        }
+    }
+    __syncthreads();
+    // ---- row maxima of P, column maxima of C: a thread per row / column walks it -- the reads of a walk do not depend on
+    // each other (they pipeline), and with the odd row stride a column walk is as conflict-free as a row walk
+    for (int rc = tid; rc < 2 * K; rc += NT) {
+        const bool is_row = rc < K;
+        const int idx = is_row ? rc : rc - K;
+        const T *p0 = is_row ? Pe + idx * KS : Ce + idx;
+        const int st = is_row ? 1 : KS;
+        T m0 = NINF, m1 = NINF, m2 = NINF, m3 = NINF;
+        int x = 0;
+        for (; x + 4 <= K; x += 4) {
+            m0 = fmaxf(m0, p0[x * st]), m1 = fmaxf(m1, p0[(x + 1) * st]);
+            m2 = fmaxf(m2, p0[(x + 2) * st]), m3 = fmaxf(m3, p0[(x + 3) * st]);
+        }
+        for (; x < K; ++x) m0 = fmaxf(m0, p0[x * st]);
+        (is_row ? pm : cm)[idx] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    }
+    __syncthreads();
+    for (int e = tid; e < KK; e += NT) {
+        const int i = row_of(e), j = e - i * K;
+        Pe[i * KS + j] = Num<T>::exp_acc(Pe[i * KS + j] - pm[i]);
+        Ce[i * KS + j] = Num<T>::exp_acc(Ce[i * KS + j] - cm[j]);
+    }
+    __syncthreads();
+    // ---- 32 x 32 tiles on the matrix cores.  Lane (c = lane & 31, h = lane >> 5): step s of a tile takes A[row c][k = 2 s +
+    // h] and B[k = 2 s + h][column c]; accumulator register r holds row (r & 3) + 8 (r >> 2) + 4 h of column c.
+    const int c = lane & 31, h = lane >> 5, nt = (K + 31) >> 5;
+    auto tile = [&](auto a_at, auto b_at, int i0, int j0) {
+        chain_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ra = min(i0 + c, K - 1), cb = min(j0 + c, K - 1);
+        const bool oka = i0 + c < K, okb = j0 + c < K;
+        // four steps' operands read before their four matrix instructions (a step's reads depend on nothing: an
+        // un-unrolled loop would wait out an LDS latency per step)
+        constexpr int SU = 4;
+        for (int k0 = 0; k0 < K; k0 += 2 * SU) {
+            float av[SU], bv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int kk = k0 + 2 * u + h, k = min(kk, K - 1);
+                const bool okk = kk < K;                  // (selects, not products with 0: 0 x inf would be NaN)
+                av[u] = oka && okk ? a_at(ra, k) : 0.f;
+                bv[u] = okb && okk ? b_at(k, cb) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // G' = G / (Pe @ Ce + eps), in place over the staged G
+    for (int tk = wave; tk < nt * nt; tk += NT / 64) {
+        const int i0 = 32 * (tk / nt), j0 = 32 * (tk % nt);
+        const chain_f32x16 acc = tile([&](int i, int k) { return Pe[i * KS + k]; }, [&](int k, int j) { return Ce[k * KS + j]; }, i0, j0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = j0 + c;
+            if (i < K && j < K) Gp[i * KS + j] = Gp[i * KS + j] / (acc[r] + Num<T>::eps);
+        }
+    }
+    __syncthreads();
+    // ---- the amax paths: eps * sum(G') shared among the maxima of a row of P / a column of C
+    for (int rc = tid; rc < 2 * K; rc += NT) {
+        const bool is_row = rc < K;
+        const int idx = is_row ? rc : rc - K;
+        const T *g0 = is_row ? Gp + idx * KS : Gp + idx, *e0 = is_row ? Pe + idx * KS : Ce + idx;
+        const int st = is_row ? 1 : KS;
+        T s0 = T(0), s1 = T(0), n0 = T(0), n1 = T(0);
+        int x = 0;
+        for (; x + 2 <= K; x += 2) {
+            s0 += g0[x * st], s1 += g0[(x + 1) * st];
+            n0 += e0[x * st] == T(1) ? T(1) : T(0), n1 += e0[(x + 1) * st] == T(1) ? T(1) : T(0);
+        }
+        for (; x < K; ++x) s0 += g0[x * st], n0 += e0[x * st] == T(1) ? T(1) : T(0);
+        (is_row ? pw : cw)[idx] = Num<T>::eps * (s0 + s1) / (n0 + n1);
+    }
+    __syncthreads();
+    // ---- dP = Pe * (G' @ Ce^T) and dC = Ce * (Pe^T @ G'): 2 nt^2 tiles dealt to the waves
+    for (int tk = wave; tk < 2 * nt * nt; tk += NT / 64) {
+        const bool second = tk >= nt * nt;
+        const int t2 = second ? tk - nt * nt : tk, i0 = 32 * (t2 / nt), j0 = 32 * (t2 % nt);
+        chain_f32x16 acc;
+        if (!second)        // dP[i, k] : A[i][j] = G'[i][j], B[j][k] = Ce[k][j]
+            acc = tile([&](int i, int j) { return Gp[i * KS + j]; }, [&](int j, int k) { return Ce[k * KS + j]; }, i0, j0);
+        else                // dC[k, j] : A[k][r] = Pe[r][k], B[r][j] = G'[r][j]
+            acc = tile([&](int k, int r) { return Pe[r * KS + k]; }, [&](int r, int j) { return Gp[r * KS + j]; }, i0, j0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = j0 + c;
+            if (i < K && j < K) {
+                if (!second) {
+                    const T pe = Pe[i * KS + j];
+                    dP[i * K + j] = pe * acc[r] + (pe == T(1) ? pw[i] : T(0));
+                } else {
+                    const T ce = Ce[i * KS + j];
+                    dC[i * K + j] = ce * acc[r] + (ce == T(1) ? cw[j] : T(0));
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
                               int64_t sCol, const void *tree, const void *out_vec, const void *grad_vec,
@@ -1225,7 +1405,18 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
     const TreeLayout tl = tree_layout(B, Tn, K, sizeof(T));
     if (tl.L > 1 && (!ws || ws_bytes < tl.bytes)) return ALAN_ERR_WORKSPACE;
     auto kern = K <= 48 ? chain_pair_backward_kernel<T, 2> : chain_pair_backward_kernel<T, 4>;
-    if (smem > 64 * 1024)
+    static const int bwd_mfma_knob = env_knob("ALAN_CHAIN_BWD_MFMA");                 // ablation knob: 0 = the vector kernel
+    bool mfma = false;
+    size_t smem_m = 0;
+    if constexpr (sizeof(T) == 4) {
+        smem_m = (3 * (size_t)K * (size_t)(K | 1) + 4 * (size_t)K) * sizeof(float);
+        mfma = bwd_mfma_knob != 0 && K >= 2 && smem_m <= 160 * 1024;
+        if (mfma && smem_m > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)chain_pair_backward_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem_m) != hipSuccess)
+            return ALAN_ERR_LAUNCH;
+    }
+    if (!mfma && smem > 64 * 1024)
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return ALAN_ERR_LAUNCH;
     const T *root = (const T *)((const char *)tree + tl.off[tl.L]);
@@ -1236,6 +1427,20 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
                       cC = bottom ? sCol : 1;
         const T *G = top ? (const T *)nullptr : (const T *)((const char *)ws + tl.off[r]);
         T *dsrc = bottom ? (T *)grad_ms : (T *)((char *)ws + tl.off[r - 1]);
+        if constexpr (sizeof(T) == 4) {
+            if (mfma) {
+                if (K > 48)
+                    hipLaunchKernelGGL(chain_pair_backward_mfma_kernel<1024>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(1024),
+                                       smem_m, stream, src, cB, cT, cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K),
+                                       (int64_t)K, (int64_t)1, (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
+                else
+                    hipLaunchKernelGGL(chain_pair_backward_mfma_kernel<256>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(256),
+                                       smem_m, stream, src, cB, cT, cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K),
+                                       (int64_t)K, (int64_t)1, (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
+                if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+                continue;
+            }
+        }
         hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
                            cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K), (int64_t)K, (int64_t)1,
                            (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
