@@ -66,12 +66,29 @@ struct ChainKernArg {
 };
 static_assert(sizeof(ChainKernArg) <= 4096, "kernel arguments: 4 KB");
 
-template <int EQ, int NST, int NLW, bool FLAT, bool REC>
+// SYNC = false: nothing inside the launch waits for anything else in it -- every small factor of the body is computed
+// in its tiles (REC) and there is no tail, so the prelude's workgroups only have to finish before the launch does: plain
+// stores, no counters, no polls.  (What the hand-offs cost, measured: tools/chain_parts.py.)
+template <int EQ, int NST, int NLW, bool FLAT, bool REC, bool SYNC = true>
 __global__ __launch_bounds__(256, 2) void normal_lse_x3_chain_kernel(const ChainKernArg a) {
     const ChainArgs &c = a.c;
     const int tid = threadIdx.x;
     const uint32_t wg = blockIdx.x;
     __shared__ int is_last;
+    if (!SYNC) {
+        if ((int)wg < c.n_aux) {
+            for (uint32_t vb = wg; vb < c.pre_blocks; vb += (uint32_t)c.n_aux) {
+                small_multi_block<false>(offsetof(ChainKernArg, pre), vb);
+                __syncthreads();
+            }
+        } else {
+            const uint32_t r = wg - (uint32_t)c.n_aux;
+            const uint32_t q1 = fd_div(r, c.gxd), bx = r - q1 * c.gx;
+            const uint32_t bz = fd_div(q1, c.gyd), by = q1 - bz * c.gy;
+            normal_lse_x3_body<EQ, NST, NLW, FLAT, false, REC>(a.d, (int)bx, (int)by, (int)bz, (int)c.gx, (int)c.gy, X3Chain(), a.rec);
+        }
+        return;
+    }
     if ((int)wg < c.n_aux) {
         for (uint32_t vb = wg; vb < c.pre_blocks; vb += (uint32_t)c.n_aux) {
             small_multi_block<true>(offsetof(ChainKernArg, pre), vb);
@@ -138,6 +155,7 @@ struct ChainPlan {
     X3Prep xp;
     uint32_t grid = 0;
     bool rec = false;
+    bool syncfree = false;                // no hand-off inside the launch: no tail, no body small factor from the prelude
 };
 
 // ---- prelude problems the body computes in its tiles (normal_lse_x3.h, REC) instead of reading their output ----------
@@ -342,6 +360,7 @@ int plan_chain(const alan_normal_lse_desc_t *a, const alan_reduce_desc_t *const 
         c.tail_mode[s] = m1, c.tail_logG[s] = g1.logG, c.tail_block[s] = g1.block ? 1 : 0, c.tail_blocks[s] = g1.grid;
     }
     p.grid = (uint32_t)c.n_aux + c.n_main;
+    p.syncfree = n_tail == 0 && !c.body_waits && p.rec;
     return ALAN_OK;
 }
 
@@ -351,7 +370,8 @@ extern "C" int alan_normal_lse_chained_check(const alan_normal_lse_desc_t *a, co
                                              int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail) {
     ChainPlan p;
     int dummy[4];
-    return plan_chain(a, prelude, n_prelude, tail, n_tail, dummy, p);
+    const int rc = plan_chain(a, prelude, n_prelude, tail, n_tail, dummy, p);
+    return rc != ALAN_OK ? rc : p.syncfree ? ALAN_OK : ALAN_CHAIN_HANDOFFS;
 }
 
 extern "C" int alan_normal_lse_chained(const alan_normal_lse_desc_t *a, const alan_reduce_desc_t *const *prelude,
@@ -375,7 +395,8 @@ extern "C" int alan_normal_lse_chained(const alan_normal_lse_desc_t *a, const al
                                      : launch(normal_lse_x3_chain_kernel<EQV, 4, 1, false, false>))                    \
              : p.xp.nst == 2 ? (flat ? launch(normal_lse_x3_chain_kernel<EQV, 2, 1, true, false>)                      \
                                      : launch(normal_lse_x3_chain_kernel<EQV, 2, 1, false, false>))                    \
-             : p.xp.nlw == 2 ? (p.rec ? launch(normal_lse_x3_chain_kernel<EQV, 1, 2, false, true>)                     \
+             : p.xp.nlw == 2 ? (p.syncfree ? launch(normal_lse_x3_chain_kernel<EQV, 1, 2, false, true, false>)          \
+                                : p.rec    ? launch(normal_lse_x3_chain_kernel<EQV, 1, 2, false, true>)                 \
                                       : launch(normal_lse_x3_chain_kernel<EQV, 1, 2, false, false>))                   \
                              : (flat ? launch(normal_lse_x3_chain_kernel<EQV, 1, 1, true, false>)                      \
                                      : launch(normal_lse_x3_chain_kernel<EQV, 1, 1, false, false>));                   \

@@ -456,36 +456,60 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (REC) {
-            const float *hv = recl + h * RL::EQP;         // this half's events of every vector
+            // this half's events of a vector: EQP consecutive floats, 16-byte aligned -- three ds_read_b128 per vector
+            auto vec = [&](int v, float (&o)[RL::EQP]) {
+                const f32x4v *p4 = reinterpret_cast<const f32x4v *>(recl + v * RL::VEC + h * RL::EQP);
+#pragma unroll
+                for (int i = 0; i < RL::EQP / 4; ++i) {
+                    const f32x4v x = p4[i];
+                    o[4 * i] = x[0], o[4 * i + 1] = x[1], o[4 * i + 2] = x[2], o[4 * i + 3] = x[3];
+                }
+            };
             float tot = 0.f;
             if (rc.has_normal) {
-                float acc = 0.f, lg = 0.f;
+                float lo[RL::EQP], wv[RL::EQP], lg[RL::EQP];
+                vec(0, lo), vec(1, wv), vec(2, lg);
+                float acc = 0.f, lgs = 0.f;
 #pragma unroll
                 for (int q = 0; q < EQ; ++q) {
-                    const float df = zv[q] - hv[q];
-                    acc = fmaf(df * df, hv[RL::VEC + q], acc);
-                    lg += hv[2 * RL::VEC + q];
+                    const float df = zv[q] - lo[q];
+                    acc = fmaf(df * df, wv[q], acc);
+                    lgs += lg[q];
                 }
-                float part = acc + lg;
+                float part = acc + lgs;
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
                 part = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 tot += rc.n_scale * (-part - (float)E * 0.91893853320467274178f) + rc.n_add;
             }
             if (rc.N > 0) {
-                float bsum = 0.f;
+                // the dots of every n over this half's events, the halves' sums exchanged; then lane half 0 takes the
+                // even n's softplus and lane half 1 the odd ones (the transcendental instructions are quarter rate)
+                float bsum = 0.f, xl[X3_REC_NMAX];
 #pragma unroll
                 for (int n = 0; n < X3_REC_NMAX; ++n) {
-                    if (n >= rc.N) break;                 // (uniform)
+                    xl[n] = 0.f;
+                    if (n >= rc.N) continue;              // (uniform)
+                    float xv[RL::EQP];
+                    vec(3 + n, xv);
                     float dot = 0.f;
 #pragma unroll
-                    for (int q = 0; q < EQ; ++q) dot = fmaf(zv[q], hv[(3 + n) * RL::VEC + q], dot);
+                    for (int q = 0; q < EQ; ++q) dot = fmaf(zv[q], xv[q], dot);
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dot), __float_as_uint(dot), false, false);
-                    const float xl = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                    // logsigmoid(x) - (1 - y) x, as reduce.hip's linear-logits producer evaluates it
-                    const float ee = __builtin_amdgcn_exp2f(-fabsf(xl) * NL_LOG2E);
-                    const float ls = fminf(xl, 0.f) - __builtin_amdgcn_logf(1.f + ee) * NL_LN2;
-                    bsum += ls - (1.f - recl[RL::YOFF + n]) * xl;
+                    xl[n] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 }
+#pragma unroll
+                for (int n2 = 0; n2 < X3_REC_NMAX; n2 += 2) {
+                    if (n2 >= rc.N) continue;             // (uniform)
+                    // one instruction stream for two n: lane half 0 evaluates n2, lane half 1 n2 + 1
+                    const float x = h ? xl[n2 + 1] : xl[n2];
+                    const float y = recl[RL::YOFF + n2 + h];
+                    // logsigmoid(x) - (1 - y) x, as reduce.hip's linear-logits producer evaluates it
+                    const float ee = __builtin_amdgcn_exp2f(-fabsf(x) * NL_LOG2E);
+                    const float ls = fminf(x, 0.f) - __builtin_amdgcn_logf(1.f + ee) * NL_LN2;
+                    bsum += n2 + h < rc.N ? ls - (1.f - y) * x : 0.f;
+                }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bsum), __float_as_uint(bsum), false, false);
+                bsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 tot += rc.b_scale * bsum + rc.b_add;
             }
             hsum += tot;

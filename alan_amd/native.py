@@ -276,13 +276,20 @@ def deferring():
 # Inside ``deferring()`` a gradient-free fused plate step is itself only queued: the producers queued so far (and any
 # queued before it goes out) ride in its launch as the PRELUDE -- its first workgroups run them, or its tiles compute
 # them -- and the launches of the evaluation's final contraction (engine.contract(final=True), under ``tail_attach()``)
-# join it as the TAIL, run by its last-arriving workgroup: movielens' whole evaluation is then one launch instead of
-# three.  OFF by default -- measured slower (tools/chain_parts.py, round 3, K = 30: the plate step alone replays every
-# 14.3 us; + the two [M, K] producers computed in its tiles 19.2; + the other producers and the arrival counter 22.8; +
-# the tail 29.0 -- against 27.4 us for the three separate launches): on this chip an in-launch hand-off between
-# workgroups (write-through stores drained, an agent-scope add that returns, an acquire) costs the 4-5 us a dependent
-# launch costs, and a small problem's chain of load latencies is as long inside another launch as in its own.
-CHAIN_LAUNCHES = os.environ.get("ALAN_AMD_CHAIN", "0") == "1"
+# can join it as the TAIL, run by its last-arriving workgroup.
+#   CHAIN_LAUNCHES = 1: only launches in which nothing waits for anything else (alan_normal_lse_chained_check == 0: the
+#       plate's [plate, K] producers computed in the plate step's tiles, the parent level's producers as extra
+#       workgroups, no tail) -- movielens at K <= 32: two launches per evaluation instead of three;
+#   CHAIN_LAUNCHES = 2: every chained launch the library takes, hand-offs and tail included (one launch per evaluation);
+#   CHAIN_LAUNCHES = 0 (default): every call a launch of its own.
+# Both chained forms are measured NO FASTER than the three launches (round 3, K = 30, tools/chain_parts.py and
+# tools/chain_check.py: the plate step alone replays every 14.3 us; with the two [M, K] producers computed in its tiles
+# 19.2-19.6; with the other producers and the arrival counter 22.8; with the tail 29.0 -- evaluations of 28.1 (sync-free)
+# and 29-30 us (everything) against 27.4-27.6 us for three launches).  An in-launch hand-off between workgroups
+# (write-through stores drained, an agent-scope add that returns, an acquire) costs the 4-5 us a dependent launch costs on
+# this chip, a small problem's chain of load latencies is as long inside another launch as in its own, and the in-tile
+# producers are recomputed by each of the 15 workgroups that share a plate slice.
+CHAIN_LAUNCHES = int(os.environ.get("ALAN_AMD_CHAIN", "0"))
 CHAIN_TAIL = os.environ.get("ALAN_AMD_CHAIN_TAIL", "1") != "0"      # False: the final contraction stays a launch of its own
 CHAIN_MAX_PRELUDE, CHAIN_MAX_TAIL = 4, 2
 _CHAIN_STATE = {}        # device index -> 4 zeroed int32 (the launch leaves the counters zero)
@@ -301,8 +308,10 @@ class _Fused:
         return PA, len(pre), TA, len(tl)
 
     def check(self, prelude=None, tail=None):
+        """Does the library take this chained launch, and does the CHAIN_LAUNCHES policy want it?"""
         PA, n, TA, m = self.arrays(prelude, tail)
-        return lib().alan_normal_lse_chained_check(C.byref(self.desc), PA, n, TA, m) == 0
+        rc = lib().alan_normal_lse_chained_check(C.byref(self.desc), PA, n, TA, m)
+        return rc == 0 or (rc == 1 and CHAIN_LAUNCHES >= 2)
 
 
 _CHAIN_STATE_FOR_CAPTURE = [None]     # set by whoever captures a graph: that graph's own words (allocated before the capture)
@@ -371,7 +380,7 @@ def _launch_fused():
 def _try_tail(desc, device, keepalive):
     """Attach an alan_reduce call to the pending fused launch as (the next step of) its tail.  True: attached."""
     f = _Q.fused
-    if f is None or not _Q.tail_ok or not CHAIN_LAUNCHES or not CHAIN_TAIL or len(f.tail) >= CHAIN_MAX_TAIL or f.device != device:
+    if f is None or not _Q.tail_ok or CHAIN_LAUNCHES < 2 or not CHAIN_TAIL or len(f.tail) >= CHAIN_MAX_TAIL or f.device != device:
         return False
     if any(dev != device for _, dev, _ in _Q.pending) or len(f.prelude) + len(_Q.pending) > CHAIN_MAX_PRELUDE:
         return False

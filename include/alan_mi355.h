@@ -239,7 +239,13 @@ int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t 
  *            (different streams) need separate `state`.
  * Results are those of alan_reduce_batch(prelude); alan_normal_lse(desc); alan_reduce(tail[0]); alan_reduce(tail[1]).
  * ALAN_ERR_UNSUPPORTED (from either function, nothing launched): some part is not of the single-launch small kind, or
- * the plate step is not the bf16x3 kernel's -- issue the calls separately. */
+ * the plate step is not the bf16x3 kernel's -- issue the calls separately.
+ * alan_normal_lse_chained_check tells the two kinds of chained launch apart: ALAN_OK -- nothing inside the launch waits
+ * for anything else in it (no tail, and every desc->small[] the prelude writes is a function of the value rows that the
+ * plate step computes in its own tiles instead: the Normal -(log Q + log K) and the linear-logits likelihood at NS <= 32;
+ * THOSE prelude outputs are then never written) -- or ALAN_CHAIN_HANDOFFS (> 0): workgroups hand results to each other
+ * through `state`, which costs what a dependent launch costs on this chip (measured: tools/chain_parts.py). */
+#define ALAN_CHAIN_HANDOFFS 1
 int alan_normal_lse_chained_check(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,
                                   int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail);
 int alan_normal_lse_chained(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,

@@ -755,8 +755,8 @@ def test_merged_split_keeps_the_memory_bound(oracle_backend, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,split", [(10, None), (30, None), (100, ("plate_1", 38))], ids=["K10", "K30", "K100_split38"])
-@pytest.mark.parametrize("tail", [False, True], ids=["prelude", "prelude+tail"])
-def test_chained_launch_equals_the_separate_launches(K, split, tail, monkeypatch):
+@pytest.mark.parametrize("mode,tail", [(1, False), (2, False), (2, True)], ids=["sync_free", "prelude", "prelude+tail"])
+def test_chained_launch_equals_the_separate_launches(K, split, mode, tail, monkeypatch):
     """alan_normal_lse_chained (producers + fused plate step + final contraction as ONE launch; off by default: measured
     slower) against the separate launches -- whose value the tests above pin to the reference's -- on particles drawn by
     the Problem (the layout the bf16x3 kernel takes), eagerly and as a replayed graph; its synchronisation words are left
@@ -770,14 +770,20 @@ def test_chained_launch_equals_the_separate_launches(K, split, tail, monkeypatch
     t.manual_seed(3)
     sample = prob.sample(K, reparam=False)
     strat = alan.Split(*split) if split else alan.no_checkpoint
+    monkeypatch.setattr(N, "CHAIN_LAUNCHES", 0)
     separate = float(sample.elbo_nograd(strat, graph=False))
-    monkeypatch.setattr(N, "CHAIN_LAUNCHES", True)
+    monkeypatch.setattr(N, "CHAIN_LAUNCHES", mode)
     monkeypatch.setattr(N, "CHAIN_TAIL", tail)
     launched = []
     real = N._launch_fused
     monkeypatch.setattr(N, "_launch_fused", lambda: (launched.append((len(N._Q.fused.prelude), len(N._Q.fused.tail))), real())[1])
     eager = float(sample.elbo_nograd(strat, graph=False))
-    assert launched and launched[-1][0] >= 2 and (launched[-1][1] >= 1) == tail, launched
+    if mode == 1 and K > 32:
+        # (the default policy chains only launches without hand-offs: at K = 100 the [plate, K] producers are not
+        # computed in the tiles, so the plate step goes out alone)
+        assert all(n == (0, 0) for n in launched), launched
+    else:
+        assert launched and launched[-1][0] >= 2 and (launched[-1][1] >= 1) == tail, launched
     replayed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(4)]
     t.cuda.synchronize()
     for got in (eager, *replayed):

@@ -14,14 +14,14 @@ for K in (3, 10, 30, 100):
     sample = B.draw(prob, K)
     strat = alan.no_checkpoint if K < 100 else alan.Split("plate_1", 38)
     vals = {}
-    for chain in (False, True):
+    for chain in (0, 2):
         N.CHAIN_LAUNCHES = chain
         with t.no_grad():
             vals[chain] = [float(sample.elbo_nograd(strat, graph=False)) for _ in range(3)]
         t.cuda.synchronize()
     st = [x.tolist() for x in N._CHAIN_STATE.values()]
-    print(f"K={K}: separate {vals[False]}  chained {vals[True]}  state {st}", flush=True)
-MODES = {"separate": (False, False), "prelude": (True, False), "full": (True, True)}
+    print(f"K={K}: separate {vals[0]}  chained {vals[2]}  state {st}", flush=True)
+MODES = {"separate": (0, False), "sync-free": (1, False), "prelude": (2, False), "full": (2, True)}
 for K in (30, 100):
     strat = alan.no_checkpoint if K < 100 else alan.Split("plate_1", 38)
     for rep in range(2):
