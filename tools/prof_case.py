@@ -15,7 +15,7 @@ if which in ("vi", "rws"):
     # as bench.py's training_iteration leg: fused=True = one multi-tensor kernel per Adam step
     opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, fused=True, maximize=True) if which == "rws"
            else t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True, fused=True))
-    step = GraphedStep(prob, K, opt, method=which)
+    step = GraphedStep(prob, K, opt, method=which, computation_strategy=bench.strategy_for(1, K))
     for _ in range(n):
         v = step()
 else:

@@ -127,4 +127,42 @@ for k in (30, 100):
             f"# SQ counters of alan::normal_lse_x3_kernel at M=300, K={k}, E=18 (rocprofv3 --pmc, three passes, no tracing domains; tools/pmc_nlse.sh)\n\n"
             "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES and "
             "SQ_VALU_MFMA_BUSY_CYCLES count cycles.\n\n" + open(p).read())
+# ---- bus_breakdown K=100: HBM traffic of the tile kernels (pair.hip) and of the rest of the evaluation
+try:
+    match = ("pair_lse_kernel", "pair_sum_kernel", "reduce_small", "reduce_group", "bernoulli_linear", "Cijk")
+    fetch, write = pmc("pmc_bus_fetch", "FETCH_SIZE", match), pmc("pmc_bus_write", "WRITE_SIZE", match)
+    Kb, Y, B, I = 100, 2, 3, 150
+    algo = {"pair_lse_kernel<true>": 4 * (Y * B * Kb + 2 * Y * B * I * Kb + Y * B * I + Y * B * Kb * Kb),
+            "pair_lse_kernel<false>": 4 * (2 * Y * B * Kb * Kb + Y * B * Kb + B * Y * Kb * Kb)}
+    md = ["# HBM traffic of a bus_breakdown K=100 evaluation (round 3; python3 tools/prof_case.py bus 100 30)\n", note + ".\n",
+          "Algorithmic bytes: every distinct input element once + the output once (the Bernoulli tile kernel reads alpha, the two "
+          "evaluated dot terms [Y,B,I,K] and the observations and writes [Y,B,K,K]; the log-sum-exp tile kernel reads two "
+          "[Y,B,K,K] factors and one [Y,B,K] and writes [3 plate elements, Y, K, K] partial results).\n",
+          "| kernel | grid | launches | avg us | 2 x FETCH_SIZE (MB) | WRITE_SIZE (MB) | algorithmic (MB) | traffic / algorithmic | GB/s of algorithmic |\n|---|---|---|---|---|---|---|---|---|"]
+    res = {"source": note + " -- python3 tools/prof_case.py bus 100 30", "kernels": {}}
+    for k in sorted(fetch, key=lambda k: -fetch[k][2]):
+        fb, n, us = fetch[k][0] * 1024 * 2, fetch[k][1], fetch[k][2]
+        wb = write.get(k, (0, 0, 0))[0] * 1024
+        a = next((v for kk, v in algo.items() if kk in k[0]), None)
+        res["kernels"][f"{k[0]} grid {k[1]}"] = {"fetch_bytes": fb, "write_bytes": wb, "launches": n, "mean_duration_us": us, "algorithmic_bytes": a}
+        md.append(f"| `{k[0][:70]}` | {k[1]} | {n} | {us:.1f} | {fb / 1e6:.2f} | {wb / 1e6:.2f} | " +
+                  (f"{a / 1e6:.2f} | {(fb + wb) / a:.2f} | {a / us / 1e3:.0f} |" if a else "| | |"))
+    json.dump(res, open(os.path.join(OUT, "r3_bus_K100_pmc.json"), "w"), indent=1)
+    open(os.path.join(OUT, "r3_bus_K100_pmc.md"), "w").write("\n".join(md) + "\n")
+except AssertionError as e:
+    print("no bus K=100 PMC passes:", e)
+# ---- plain-text evidence collected later in the round
+for src, dst, head in (("chain_bwd_trace_K30.txt", "r3_chain_backward_launches_K30.txt", "# bash tools/chain_bwd_trace.sh 30: the last forward + backward of chain_logmmexp at T=1000, K=30, launch by launch (matrix-core backward)\n"),
+                       ("chain_bwd_trace_K30_vector.txt", "r3_chain_backward_launches_K30_vector.txt", "# ALAN_CHAIN_BWD_MFMA=0 bash tools/chain_bwd_trace.sh 30: the vector-unit backward of rounds 1-2\n"),
+                       ("chain_bwd_trace_K100.txt", "r3_chain_backward_launches_K100.txt", "# bash tools/chain_bwd_trace.sh 100 (matrix-core backward)\n"),
+                       ("chain_bwd_trace_K100_vector.txt", "r3_chain_backward_launches_K100_vector.txt", "# ALAN_CHAIN_BWD_MFMA=0 bash tools/chain_bwd_trace.sh 100: the vector-unit backward of rounds 1-2\n"),
+                       ("replay_floor.txt", "r3_replay_floor_probe.txt", "# python3 tools/replay_floor_probe.py 2000: what a replayed evaluation costs as a function of its launch count\n"),
+                       ("chain_parts_K30.txt", "r3_chained_launch_parts_K30.txt", "# python3 tools/chain_parts.py 30: the chained launch (alan_normal_lse_chained) replayed with subsets of its parts\n"),
+                       ("chain_parts_K100.txt", "r3_chained_launch_parts_K100.txt", "# python3 tools/chain_parts.py 100\n"),
+                       ("chain_check.txt", "r3_chained_launch_ab.txt", "# python3 tools/chain_check.py: movielens evaluations as separate launches / sync-free chained / chained with hand-offs / one launch\n"),
+                       ("batched_draws_ab.txt", "r3_batched_draws_ab.txt", "# tools/train_step_bench.py with dist.BATCH_DRAWS off / on (one process each, same box)\n")):
+    p = os.path.join(RAW, src)
+    if os.path.exists(p):
+        body = "".join(l for l in open(p) if "amdgpu.ids" not in l and "UserWarning" not in l and "refine_names" not in l)
+        open(os.path.join(OUT, dst), "w").write(head + body)
 print("profiles/ written:", sorted(x for x in os.listdir(OUT) if x.startswith("r3_")))
