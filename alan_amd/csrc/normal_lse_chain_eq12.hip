@@ -1,0 +1,6 @@
+// The chained launch's kernels for event-length bucket EQ = 12 (normal_lse_chain_impl.h).
+#include "normal_lse_chain_impl.h"
+
+namespace alan {
+int chain_launch_eq12(const ChainPlan &p, hipStream_t stream) { return chain_launch_eq<12>(p, stream); }
+}  // namespace alan
