@@ -144,14 +144,14 @@ int match_linear_recipe(const alan_normal_lse_desc_t &a, const alan_reduce_desc_
 int plan_chain(const alan_normal_lse_desc_t *a, const alan_reduce_desc_t *const *prelude, int32_t n_prelude,
                const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state, ChainPlan &p) {
     if (!a || n_prelude < 0 || n_tail < 0 || (n_prelude && !prelude) || (n_tail && !tail) || !state) return ALAN_ERR_BAD_DESC;
-    if (n_prelude > SMALL_MULTI || n_tail > CHAIN_TAIL) return ALAN_ERR_UNSUPPORTED;
+    if (n_prelude > CHAIN_MULTI || n_tail > CHAIN_TAIL) return ALAN_ERR_UNSUPPORTED;
     if (!a->keep_partials || a->counters || a->lse_out || a->ev_start || a->ev_stop) return ALAN_ERR_UNSUPPORTED;
     std::memset(&p.k, 0, sizeof(p.k));
     // ---- prelude problems the body computes in its tiles: their outputs leave the body's list of small factors.  Only
     // where a value tile serves few (loc row, scale tile) units is that cheaper than reading them -- K <= 32, two loc rows
     // per wave: at K = 100 a hundred workgroups would each recompute a plate slice's factors
     alan_normal_lse_desc_t body = *a;
-    bool in_tile[SMALL_MULTI] = {false, false, false, false};
+    bool in_tile[CHAIN_MULTI] = {false, false, false, false};
     static const int rec_knob = env_knob("ALAN_CHAIN_REC");                             // ablation knob: 0 = off
     p.rec = false;
     if (rec_knob != 0 && a->NS <= 32 && a->NL >= 8) {
@@ -188,10 +188,10 @@ int plan_chain(const alan_normal_lse_desc_t *a, const alan_reduce_desc_t *const 
     c.gxd = make_fastdiv(c.gx), c.gyd = make_fastdiv(c.gy);
     c.state = (int32_t *)state;
     // ---- the prelude: every problem one small-kernel launch, at most one of them the linear-logits producer
-    SmallDesc sd[SMALL_MULTI];
-    GroupLaunch gl[SMALL_MULTI];
+    SmallDesc sd[CHAIN_MULTI];
+    GroupLaunch gl[CHAIN_MULTI];
     LinDesc lin;
-    int mode[SMALL_MULTI];
+    int mode[CHAIN_MULTI];
     bool have_lin = false;
     std::memset(sd, 0, sizeof(sd));
     int na = 0;

@@ -37,7 +37,7 @@ struct ChainKernArg {
     X3Desc d;
     ChainArgs c;
     X3Recipes rec;
-    SmallMulti pre;
+    SmallMultiT<CHAIN_MULTI> pre;
     SmallDesc tail[CHAIN_TAIL];
 };
 static_assert(sizeof(ChainKernArg) <= 4096, "kernel arguments: 4 KB");
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_chain_kernel(const Chain
     if (!SYNC) {
         if ((int)wg < c.n_aux) {
             for (uint32_t vb = wg; vb < c.pre_blocks; vb += (uint32_t)c.n_aux) {
-                small_multi_block<false>(offsetof(ChainKernArg, pre), vb);
+                small_multi_block<false, CHAIN_MULTI>(offsetof(ChainKernArg, pre), vb);
                 __syncthreads();
             }
         } else {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void normal_lse_x3_chain_kernel(const Chain
     }
     if ((int)wg < c.n_aux) {
         for (uint32_t vb = wg; vb < c.pre_blocks; vb += (uint32_t)c.n_aux) {
-            small_multi_block<true>(offsetof(ChainKernArg, pre), vb);
+            small_multi_block<true, CHAIN_MULTI>(offsetof(ChainKernArg, pre), vb);
             __syncthreads();                                  // (the block-wide combine's LDS words, before the next problem)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then one lane signals

@@ -1,6 +1,8 @@
 // Host-side planning: canonicalise an alan_reduce_desc_t (drop unit dims, order dims for
 // coalescing, merge contiguous dims) and pick a kernel + launch geometry.
 #pragma once
+#include <cstring>
+
 #include "common.h"
 
 namespace alan {
@@ -31,7 +33,8 @@ struct GroupDesc {
 // kernel walks its 1.4 KB descriptor with run-time loops, i.e. a chain of ~10 dependent scalar loads, which
 // is most of the duration of a launch that reads a few hundred elements.
 constexpr int SMALL_NK = 3, SMALL_NR = 2;
-constexpr int SMALL_MULTI = 4;     // problems per reduce_small_multi_kernel launch
+constexpr int SMALL_MULTI = 8;     // problems per reduce_small_multi_kernel launch (its kernel argument: 3.3 KB of the 4 KB)
+constexpr int CHAIN_MULTI = 4;     // problems in the prelude of a chained launch (normal_lse_chain.hip: its argument holds more)
 
 struct SmallDesc {
     const float *f[MAXF];
@@ -73,13 +76,15 @@ struct LinDesc {
 // Several INDEPENDENT small problems in one launch (alan_reduce_batch): the per-variable log-prob producers of a
 // plate are a handful of launch-latency-bound kernels (4-5 us each inside a replayed graph) that do not depend on
 // each other.  Workgroups are dealt to the problems in order; mode and lane-group shape are run-time here.
-struct SmallMulti {
+template <int NP>
+struct SmallMultiT {
     int32_t n;
-    int32_t mode[SMALL_MULTI], logG[SMALL_MULTI], block[SMALL_MULTI];
-    uint32_t first_block[SMALL_MULTI + 1];
-    SmallDesc d[SMALL_MULTI];
+    int32_t mode[NP], logG[NP], block[NP];
+    uint32_t first_block[NP + 1];
+    SmallDesc d[NP];
     LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
 };
+typedef SmallMultiT<SMALL_MULTI> SmallMulti;
 
 // Kernel argument of the small log-sum-exp + plate-sum kernel: out[keep] = sum_plate LSE_red(sum_f factor_f) + add_const
 // in ONE launch (reduce_Ks.py:249-251 then logpq.py:149) for problems too small for the rows kernel -- a lane group per
@@ -152,7 +157,24 @@ int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
                        const LinDesc *lin = nullptr);
 // (its kernel argument alone; returns the number of workgroups the problems take together)
-uint32_t fill_small_multi(SmallMulti &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, const LinDesc *lin);
+template <int NP>
+inline uint32_t fill_small_multi(SmallMultiT<NP> &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n,
+                                 const LinDesc *lin) {
+    std::memset(&m, 0, sizeof(m));
+    m.n = n;
+    if (lin) m.lin = *lin;
+    uint32_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        m.mode[i] = mode[i];
+        m.logG[i] = gl[i].logG;
+        m.block[i] = gl[i].block ? 1 : 0;
+        m.first_block[i] = blocks;
+        blocks += gl[i].grid;
+        m.d[i] = sd[i];
+    }
+    m.first_block[n] = blocks;
+    return blocks;
+}
 int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);
 int launch_lin_grad(const LinDesc &ld, hipStream_t stream, const EvPair &ev);
 

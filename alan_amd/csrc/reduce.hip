@@ -326,23 +326,6 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
     small_multi_block<false>(0, blockIdx.x);
 }
 
-uint32_t fill_small_multi(SmallMulti &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, const LinDesc *lin) {
-    std::memset(&m, 0, sizeof(m));
-    m.n = n;
-    if (lin) m.lin = *lin;
-    uint32_t blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        m.mode[i] = mode[i];
-        m.logG[i] = gl[i].logG;
-        m.block[i] = gl[i].block ? 1 : 0;
-        m.first_block[i] = blocks;
-        blocks += gl[i].grid;
-        m.d[i] = sd[i];
-    }
-    m.first_block[n] = blocks;
-    return blocks;
-}
-
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
                        const LinDesc *lin) {
     if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;

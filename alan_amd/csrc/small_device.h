@@ -395,8 +395,9 @@ __device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool 
 // Virtual workgroup `vb` of a SmallMulti that sits in the kernel-argument segment at byte offset `arg_off` (its
 // descriptors are read through the segment itself -- scalar loads at a uniform offset: indexing the by-value struct with a
 // run-time p makes the compiler copy all of it to scratch first).  Every thread of the workgroup calls it (barriers inside).
-template <bool WT>
+template <bool WT, int NP = SMALL_MULTI>
 __device__ __forceinline__ void small_multi_block(const size_t arg_off, const uint32_t vb) {
+    typedef SmallMultiT<NP> SmallMulti;
     typedef __attribute__((address_space(4))) const char *kernarg_ptr;
     const char *base = (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + arg_off);
     const SmallMulti &m = *reinterpret_cast<const SmallMulti *>(base);

@@ -449,7 +449,7 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
         if _POISON_QUEUED and len(keepalive) > 1 and keepalive[1] is not None:
             keepalive[1].fill_(float("nan"))       # debugging aid: a premature read of a queued output shows up as NaN
         _Q.pending.append((desc, device, keepalive))
-        if len(_Q.pending) >= 8:
+        if len(_Q.pending) >= 16:
             flush()
         return True
     if _Q.fused is not None and _Q.tail_ok and not lin_grad and _TIMER[0] is None and not t.is_grad_enabled() and \

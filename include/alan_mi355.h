@@ -163,7 +163,7 @@ int alan_reduce(const alan_reduce_desc_t *desc, void *workspace, size_t workspac
 /* n <= 64 INDEPENDENT alan_reduce problems (no one reads another's output; none needs a workspace or carries timing
  * events).  The small single-stage ones among them -- the per-variable log-prob producers of a plate
  * (TorchDimDist.py:127-162 per variable, logpq.py:221-222), each a launch-latency-bound kernel of its own otherwise --
- * go out first, up to 4 problems per kernel launch; the others follow as alan_reduce would launch them. */
+ * go out first, up to 8 problems per kernel launch; the others follow as alan_reduce would launch them. */
 int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t n, void *stream);
 
 /* Backward of an ALAN_MODE_LSE call (with or without PLATE dims) with respect to EVERY factor in one pass over the
