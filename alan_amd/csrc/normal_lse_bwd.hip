@@ -21,10 +21,10 @@
 #include <cstring>
 
 #include "plan.h"
+#include "normal_lse_x3.h"
 
 namespace alan {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct NLBDesc {
@@ -68,7 +68,29 @@ __host__ __device__ inline NLBLds nlb_lds(int EH, int NS, int NL, int E) {
 // where a tile grid per plate element has 1,200).  A tile then ends one plate element (rows below `bnd`) and begins the
 // next: the forward's log-sum-exp of either is held per lane and chosen per group of four accumulator rows; everything
 // else -- V, U, d value, d small -- is indifferent to which plate element a row belongs to.
-template <int EH, bool SMALL_ONLY, bool FLAT = false>
+// X2 (round 3): the V and U products -- 32 of a tile's 42 matrix steps -- on v_mfma_f32_32x32x16_bf16 with 2-way split
+// operands (x = hi + lo, both bf16, round-to-nearest: 16 mantissa bits; the product as hi hi + hi lo + lo hi, every
+// bf16 x bf16 product exact in the fp32 accumulator: relative error <= 2^-15 per term where the fp32 chain has 2^-24, far
+// inside what a gradient is compared at).  Six instructions of 32 cycles replace sixteen of 64 per product, and -- unlike
+// the fp32 matrix instructions -- leave the vector unit running beside them; the operands are the registers the fp32 form
+// used, eight per instruction: a lane half's rows (r = 8 t .. 8 t + 7) on both sides of the contraction.  The tile X itself
+// (D chain, exps) stays fp32.
+__device__ __forceinline__ void nlb_split8(const float (&x)[8], u32x4v &hi, u32x4v &lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned h2 = nl_cvt_pk(x[2 * q], x[2 * q + 1]);
+        hi[q] = h2;
+        lo[q] = nl_cvt_pk(x[2 * q] - __uint_as_float(h2 << 16), x[2 * q + 1] - __uint_as_float(h2 & 0xffff0000u));
+    }
+}
+__device__ __forceinline__ f32x16 nlb_mfma_x2(const u32x4v &ah, const u32x4v &al, const u32x4v &bh, const u32x4v &bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, ah), __builtin_bit_cast(bf16x8v, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, ah), __builtin_bit_cast(bf16x8v, bl), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, al), __builtin_bit_cast(bf16x8v, bh), c, 0, 0, 0);
+    return c;
+}
+
+template <int EH, bool SMALL_ONLY, bool FLAT = false, bool X2 = false>
 __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,6 +200,15 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
                 for (int r = 0; r < 16; ++r) vacc[r] = 0.f;
             }
         }
+        u32x4v wUh[2], wUl[2];                              // X2: w' of this scale tile, split once
+        if (X2 && !SMALL_ONLY) {
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const float w8[8] = {wU[2 * t2][0], wU[2 * t2][1], wU[2 * t2][2], wU[2 * t2][3],
+                                     wU[2 * t2 + 1][0], wU[2 * t2 + 1][1], wU[2 * t2 + 1][2], wU[2 * t2 + 1][3]};
+                nlb_split8(w8, wUh[t2], wUl[t2]);
+            }
+        }
         for (int l = ys * 4 + wave; l < NL; l += 4 * gy) {
             // per-lane scalars of this tile: upstream gradient and the forward's log-sum-exp at (m, l, s)
             const float Gs = s_ok ? d.gout[(int64_t)l * d.g_sl + (int64_t)s * d.g_ss] : 0.f;
@@ -216,9 +247,22 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
                 for (int r = 0; r < 16; ++r) dfT[r] = vT[r] - muT;
             }
             // V[s, e] += sum_k X[k, s] d2[k, e]: step r pairs rows k_r(0), k_r(1) -- exactly what register r holds
+            if (X2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                vacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], dfT[r] * dfT[r], vacc, 0, 0, 0);
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    float x8[8], d8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x8[i] = acc[8 * t2 + i], d8[i] = dfT[8 * t2 + i] * dfT[8 * t2 + i];
+                    u32x4v xh, xl, dh, dl;
+                    nlb_split8(x8, xh, xl);
+                    nlb_split8(d8, dh, dl);
+                    vacc = nlb_mfma_x2(xh, xl, dh, dl, vacc);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    vacc = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], dfT[r] * dfT[r], vacc, 0, 0, 0);
+            }
             // transpose X through the wave's LDS tile: [k][s] image, then 16 consecutive s per lane
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * h) * NLB_TS + j] = acc[r];
@@ -236,11 +280,25 @@ __global__ __launch_bounds__(256) void normal_lse_bwd_kernel(const NLBDesc d) {
             f32x16 u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[r] = 0.f;
+            if (X2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const float x8[8] = {xt[2 * t2][0], xt[2 * t2][1], xt[2 * t2][2], xt[2 * t2][3],
+                                         xt[2 * t2 + 1][0], xt[2 * t2 + 1][1], xt[2 * t2 + 1][2], xt[2 * t2 + 1][3]};
+                    u32x4v xh, xl;
+                    nlb_split8(x8, xh, xl);
+                    u = nlb_mfma_x2(xh, xl, wUh[t2], wUl[t2], u);
+                    // (the first instruction of a chain from C = 0 may be given a destination over a dead operand under
+                    // -amdgpu-mfma-vgpr-form: keep the operands alive past it, as the forward does)
+                    if (t2 == 0) asm volatile("" ::"v"(u[0]), "v"(xh), "v"(xl), "v"(wUh[0]), "v"(wUl[0]));
+                }
+            } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    u = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[q][c], wU[q][c], u, 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        u = __builtin_amdgcn_mfma_f32_32x32x2f32(xt[q][c], wU[q][c], u, 0, 0, 0);
+            }
             // T = (v - mu) * U  (U itself in column E): d value / d small accumulate, d loc leaves as a partial
             float p = 0.f;
 #pragma unroll
@@ -445,6 +503,8 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     if (!workspace || workspace_bytes < p.bytes) return ALAN_ERR_WORKSPACE;
     const alan_normal_lse_desc_t &a = b->fwd;
     if (p.small_only && !b->grad_small) return ALAN_OK;                       // nothing wanted
+    static const int x2_knob = env_knob("ALAN_NLB_X2");                               // ablation knob: 0 = fp32 V and U products
+    const bool x2 = x2_knob != 0;
     char *ws = (char *)workspace;
     NLBDesc d;
     std::memset(&d, 0, sizeof(d));
@@ -478,8 +538,12 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     };
 #define NLB_CASE(EHV)                                                                        \
     case EHV:                                                                                \
-        rc = p.flat ? (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true, true>) : launch(normal_lse_bwd_kernel<EHV, false, true>)) \
-                    : (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true>) : launch(normal_lse_bwd_kernel<EHV, false>)); \
+        rc = p.flat ? (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true, true>)                                   \
+                                    : x2 ? launch(normal_lse_bwd_kernel<EHV, false, true, true>)                       \
+                                         : launch(normal_lse_bwd_kernel<EHV, false, true>))                            \
+                    : (p.small_only ? launch(normal_lse_bwd_kernel<EHV, true>)                                         \
+                                    : x2 ? launch(normal_lse_bwd_kernel<EHV, false, false, true>)                      \
+                                         : launch(normal_lse_bwd_kernel<EHV, false>));                                 \
         break;
     switch (p.eh) {
         NLB_CASE(4)

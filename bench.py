@@ -247,8 +247,10 @@ def fused_roofline(records, tag, what, traffic=None):
                     "implementation has).  The forward executes each fp32 product as six exact bf16 x bf16 products of 3-way "
                     "split operands on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error against fp64 equal to the fp32 "
                     "fma chain's, tools/mfma_bf16x3_probe.hip); it is bound by the vector unit (A-operand split, one exp "
-                    "per element), not by the matrix cores.  The backward still runs on fp32 MFMA, whose results the vector "
-                    "unit consumes without overlap (tools/mfma_f32_probe.hip: 0.60 of peak is that kernel's ceiling)"}
+                    "per element), not by the matrix cores.  The backward recomputes the tile on fp32 MFMA (whose results "
+                    "the vector unit consumes without overlap, tools/mfma_f32_probe.hip) and takes its two 32-deep products "
+                    "-- 32 of its 42 matrix steps -- on v_mfma_f32_32x32x16_bf16 with 2-way split operands (16-bit "
+                    "mantissas: hi hi + hi lo + lo hi, fp32 accumulate; ALAN_NLB_X2=0 is the all-fp32 form)"}
 
 
 def literal_hbm_reading(us_per_launch, K, M=None):
@@ -576,7 +578,7 @@ def main():
                     p_tr.sample(K, reparam=True).elbo_vi(alan.no_checkpoint).backward()
                 t.cuda.synchronize()
             rfb = fused_roofline(ktb.results(), native.MODE_FUSED_BWD, "alan::normal_lse_bwd_kernel (every gradient of the "
-                                 "plate step in one pass: D recomputed, V and U products on the matrix cores)",
+                                 "plate step in one pass: D recomputed in fp32, V and U products as bf16x2 on the matrix cores)",
                                  traffic=fused_pmc_traffic(K, backward=True))
             if rfb is not None:                          # (flops from the shape: native.run_normal_lse_backward)
                 tr["fused_backward_kernel"] = rfb
