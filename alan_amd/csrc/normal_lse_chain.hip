@@ -182,6 +182,15 @@ int plan_chain(const alan_normal_lse_desc_t *a, const alan_reduce_desc_t *const 
     if (p.rec) p.xp.lds += 4 * sizeof(float) * (p.xp.eq == 4 ? X3RecLayout<4>::FLOATS : p.xp.eq == 8 ? X3RecLayout<8>::FLOATS :
                                                   p.xp.eq == 10 ? X3RecLayout<10>::FLOATS : p.xp.eq == 12 ? X3RecLayout<12>::FLOATS :
                                                   X3RecLayout<17>::FLOATS);
+    {
+        // diagnostic knob (tools/chain_parts.py): 1 = the in-tile producers' kernel with nothing to compute, 2 = only the
+        // Normal term, 3 = only the linear-logits term -- wrong results, for timing the parts
+        static const int nop_knob = env_knob("ALAN_CHAIN_REC_NOP");
+        if (p.rec && nop_knob != ENV_UNSET) {
+            if (nop_knob == 1 || nop_knob == 3) p.k.rec.has_normal = 0;
+            if (nop_knob == 1 || nop_knob == 2) p.k.rec.N = 0;
+        }
+    }
     p.k.d = p.xp.x;
     ChainArgs &c = p.k.c;
     c.gx = p.xp.gx, c.gy = p.xp.gy, c.n_main = p.xp.gx * p.xp.gy * p.xp.gz;

@@ -245,39 +245,12 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
     int rgs[X3_REC_SLOTS], rlp[X3_REC_SLOTS], rkind[X3_REC_SLOTS];
     float pv[X3_REC_SLOTS], pvn[X3_REC_SLOTS];
     int rec_n = 0;
-    if (REC) {
-        const int N = rc.N, nE = rc.has_normal ? E : 0;
-        rec_n = 2 * nE + N * E + N;
-#pragma unroll
-        for (int sl = 0; sl < X3_REC_SLOTS; ++sl) {
-            const int idx = lane + 64 * sl;
-            const float *gp = d.val;
-            int gs = 0, lp = -1, kind = 0;
-            if (idx < nE) {
-                gp = rc.loc + idx * rc.l_se, gs = rc.l_sm, lp = (idx & 1) * RL::EQP + (idx >> 1);
-            } else if (idx < 2 * nE) {
-                const int e = idx - nE;
-                gp = rc.scl + e * rc.s_se, gs = rc.s_sm, lp = RL::VEC + (e & 1) * RL::EQP + (e >> 1), kind = 1;
-            } else if (idx < 2 * nE + N * E) {
-                const int tq = idx - 2 * nE, n = (int)(((uint32_t)tq * d.rcp_e) >> 16), e = tq - n * E;
-                gp = rc.x + n * rc.x_sn + e * rc.x_se, gs = rc.x_sm, lp = (3 + n) * RL::VEC + (e & 1) * RL::EQP + (e >> 1);
-            } else if (idx < rec_n) {
-                const int n = idx - 2 * nE - N * E;
-                gp = rc.y + n * rc.y_sn, gs = rc.y_sm, lp = RL::YOFF + n;
-            }
-            rgp[sl] = gp, rgs[sl] = gs, rlp[sl] = lp, rkind[sl] = kind;
-            pv[sl] = pvn[sl] = 0.f;
-        }
-        // (padding events and unused vectors read as zero: w = 0 switches a padded event off)
-        for (int i = lane; i < RL::FLOATS; i += 64) recl[i] = 0.f;
-    }
     auto load_rec = [&](int m, float (&x)[X3_REC_SLOTS]) {
 #pragma unroll
         for (int sl = 0; sl < X3_REC_SLOTS; ++sl)
             if (64 * sl < rec_n) x[sl] = rgp[sl][(int64_t)m * rgs[sl]];        // (lanes beyond the block: a valid address, unused)
     };
     float zc[NX], zn[NX], hc[4], hn[4];
-    if (REC && n_tiles > 0) load_rec(m0, pv);
     if (n_tiles > 0) {
         if (CHAIN) {                                  // (the first tile's small factors: behind the barrier)
             if (FLAT)
@@ -351,6 +324,35 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
                     if ((st * (NV - 3 * EQ) + v) % 4 == wave) bw[((st * NSTEP + (v >> 2)) * 64 + lane) * 4 + (v & 3)] = 0u;
         }
     }
+    // REC: the block's per-lane tables and its first loads, behind everything the barrier below waits for (in front of
+    // the first value tile's loads they delayed every wave's critical path by their ~150 instructions)
+    if (REC) {
+        const int N = rc.N, nE = rc.has_normal ? E : 0;
+        rec_n = 2 * nE + N * E + N;
+#pragma unroll
+        for (int sl = 0; sl < X3_REC_SLOTS; ++sl) {
+            const int idx = lane + 64 * sl;
+            const float *gp = d.val;
+            int gs = 0, lp = -1, kind = 0;
+            if (idx < nE) {
+                gp = rc.loc + idx * rc.l_se, gs = rc.l_sm, lp = (idx & 1) * RL::EQP + (idx >> 1);
+            } else if (idx < 2 * nE) {
+                const int e = idx - nE;
+                gp = rc.scl + e * rc.s_se, gs = rc.s_sm, lp = RL::VEC + (e & 1) * RL::EQP + (e >> 1), kind = 1;
+            } else if (idx < 2 * nE + N * E) {
+                const int tq = idx - 2 * nE, n = (int)(((uint32_t)tq * d.rcp_e) >> 16), e = tq - n * E;
+                gp = rc.x + n * rc.x_sn + e * rc.x_se, gs = rc.x_sm, lp = (3 + n) * RL::VEC + (e & 1) * RL::EQP + (e >> 1);
+            } else if (idx < rec_n) {
+                const int n = idx - 2 * nE - N * E;
+                gp = rc.y + n * rc.y_sn, gs = rc.y_sm, lp = RL::YOFF + n;
+            }
+            rgp[sl] = gp, rgs[sl] = gs, rlp[sl] = lp, rkind[sl] = kind;
+            pv[sl] = pvn[sl] = 0.f;
+        }
+        // (padding events and unused vectors read as zero: w = 0 switches a padded event off)
+        for (int i = lane; i < RL::FLOATS; i += 64) recl[i] = 0.f;
+    }
+    if (REC && n_tiles > 0) load_rec(m0, pv);
     NL_STAMP(1);
     bool pre_ok = true;
     __shared__ int pre_failed;
