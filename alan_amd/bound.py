@@ -272,7 +272,21 @@ class Problem(nn.Module):
         evaluation stays valid for as long as these do not change (in-place updates -- optimiser steps, load_state_dict
         -- keep them; a sub-module's .to() / .double(), load_state_dict(assign=True) or a replaced Parameter do not, and
         a cached tensor list would have kept the old tensors alive and their addresses unchanged)."""
-        return tuple((x.data_ptr(), x.numel()) for x in (*self.parameters(), *self.buffers()))
+        # (the tensors are read from every module's own _parameters / _buffers dicts on every call; what is remembered is
+        # only the LIST of modules -- nn.Module.parameters() spends most of its time re-walking the module tree, a third of
+        # a replayed evaluation's host time -- and that list is rebuilt whenever a module gained or lost a child)
+        mods = self.__dict__.get("_fp_modules")
+        if mods is None or sum(len(m._modules) for m in mods) != self.__dict__.get("_fp_children"):
+            mods = list(self.modules())
+            self.__dict__["_fp_modules"] = mods
+            self.__dict__["_fp_children"] = sum(len(m._modules) for m in mods)
+        out, seen = [], set()
+        for m in mods:
+            for x in (*m._parameters.values(), *m._buffers.values()):
+                if x is not None and id(x) not in seen:
+                    seen.add(id(x))
+                    out.append((x.data_ptr(), x.numel()))
+        return tuple(out)
 
     def check_device(self):
         if not (self.device == self.P.device and self.device == self.Q.device):
