@@ -340,11 +340,24 @@ small library launches (the sums of G and of G * eps over the broadcast dims, al
 together) instead of the five or six torch kernels autograd derives from exp, addcmul and the broadcasts."""
 
 
-def _sum_to(G, other, shape, log_third=None):
-    """sum of G (or of G * other, or of G * other * exp(log_third)) over the dims along which a parameter of shape
-    ``shape`` was broadcast to G's."""
+def _sum_to(G, other, shape, log_third=None, plus=None):
+    """sum of G (or of G * other, or of G * other * exp(log_third) [+ c * plus[0] with plus = (tensor broadcastable to G,
+    c)]) over the dims along which a parameter of shape ``shape`` was broadcast to G's."""
     pad = G.ndim - len(shape)
     keep = [i for i in range(G.ndim) if i >= pad and shape[i - pad] != 1]
+    if plus is not None:
+        assert other is not None and log_third is not None
+        if G.is_cuda and G.dtype == t.float32 and other.dtype == t.float32 and plus[0].dtype == t.float32:
+            from . import engine as E
+            from . import native as N
+            axes = tuple(range(G.ndim))
+            with N.may_defer():
+                out = E._produce(N.MODE_DOT, [(G, axes), (other.expand_as(G), axes), (log_third.expand_as(G), axes),
+                                              (plus[0].expand_as(G), axes)], tuple(keep), scales=[1.0, 1.0, 2.0, float(plus[1])])
+            return out.reshape(shape)
+        v = G * other * log_third.exp() + plus[1] * plus[0]
+        red = [i for i in range(G.ndim) if i not in keep]
+        return (v.sum(red) if red else v).reshape(shape)
     if G.is_cuda and G.dtype == t.float32 and (other is None or other.dtype == t.float32) and \
             (len(keep) < G.ndim or log_third is not None):
         from . import engine as E
@@ -424,10 +437,10 @@ class _DrawBatch:
     def __init__(self):
         self.jobs = []
 
-    def add(self, la, sa, is_log, full, perm, dims, src, reparam):
+    def add(self, la, sa, is_log, full, perm, dims, src, reparam, holder=None):
         shape = tuple(full[i] for i in perm) if perm is not None else tuple(full)
         pt = PendingPT(self, dims, src, shape, la.dtype, la.device)
-        self.jobs.append((la, sa, is_log, t.Size(full), perm, pt, reparam))
+        self.jobs.append((la, sa, is_log, t.Size(full), perm, pt, reparam, holder))
         return pt
 
     def flush(self):
@@ -449,7 +462,7 @@ class _DrawBatch:
             rp = [k for k, j in enumerate(mine) if j[6]]
             outs = [None] * len(mine)
             if rp:
-                meta = tuple((mine[k][2], eps[k]) for k in rp)
+                meta = tuple((mine[k][2], eps[k], mine[k][7]) for k in rp)
                 res = _ReparamNormalBatch.apply(meta, *[x for k in rp for x in (mine[k][0], mine[k][1])])
                 for k, x in zip(rp, res):
                     outs[k] = x
@@ -491,6 +504,9 @@ class _ReparamNormalBatch(t.autograd.Function):
         jobs = [(params[2 * i], params[2 * i + 1], meta[i][0], meta[i][1]) for i in range(len(meta))]
         outs = _affine_batch(jobs)
         ctx.meta = meta
+        for m in meta:                                     # (this node will add log q's share of d raw itself: OWN_LOGQ_FOLD)
+            if m[2] is not None and m[0]:
+                m[2]["node"] = True
         ctx.shapes = [(tuple(l.shape), tuple(s_.shape)) for l, s_, _, _ in jobs]
         ctx.save_for_backward(*[j[1] for j in jobs])
         return tuple(outs)
@@ -501,14 +517,23 @@ class _ReparamNormalBatch(t.autograd.Function):
         from . import native as N
         grads = [None]
         with N.deferring():
-            for i, ((is_log, eps), G) in enumerate(zip(ctx.meta, Gs)):
+            for i, ((is_log, eps, holder), G) in enumerate(zip(ctx.meta, Gs)):
                 gl = gs = None
+                own = holder.pop("own", None) if holder is not None else None
+                if G is None and own is not None:         # (nobody but its own log q used the sample)
+                    G = t.zeros(eps.shape, dtype=eps.dtype, device=eps.device)
                 if G is not None:
                     G = G.contiguous()
                     if ctx.needs_input_grad[1 + 2 * i]:
                         gl = _sum_to(G, None, ctx.shapes[i][0])
                     if ctx.needs_input_grad[2 + 2 * i]:
-                        gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None)
+                        plus = None
+                        if own is not None:
+                            # log q's upstream gradient, laid out over the sample's leading dims and broadcast over the
+                            # event dims: d raw gets coef * its sum over the same broadcast dims, in the same launch
+                            Gq, coef = own
+                            plus = (Gq.reshape(tuple(Gq.shape) + (1,) * (G.ndim - Gq.ndim)), coef)
+                        gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None, plus=plus)
                 grads += [gl, gs]
         return tuple(grads)
 
@@ -550,6 +575,37 @@ class _OwnSampleLogProb(t.autograd.Function):
         if log_scale:
             return None, None, None, (g if a == -1.0 else g * (-a))
         return None, None, None, g * (-a) / scale
+
+
+OWN_LOGQ_FOLD = os.environ.get("ALAN_AMD_OWN_FOLD", "1") != "0"
+"""The log-scale gradient that a variable's own log q contributes (-1 per unit of upstream gradient, _OwnSampleLogProb) is
+handed to the node that drew the sample (_ReparamNormalBatch), whose backward writes the parameter's WHOLE gradient with
+one launch (four-factor ALAN_MODE_DOT) -- instead of a sum launch here and an add kernel where autograd joins the two
+contributions: two launches fewer per latent variable of a VI iteration."""
+
+
+class _OwnSampleLogProbFolded(t.autograd.Function):
+    """_OwnSampleLogProb whose backward does not return the log-scale's gradient but leaves it with the sample's node
+    (``holder``), which runs after this one -- the sample is an input here, so autograd orders them."""
+
+    @staticmethod
+    def forward(ctx, spec, value, loc, scale, holder):
+        from . import engine as E
+        vd, ld, sd, od, log_scale, affine = spec
+        out = E.normal_logprob((value.detach(), vd), (loc.detach(), ld), (scale.detach(), sd), od,
+                               log_scale=log_scale, affine=affine)
+        ctx.spec, ctx.holder = spec, holder
+        return out
+
+    @staticmethod
+    @t.autograd.function.once_differentiable
+    def backward(ctx, G):
+        vd, ld, sd, od, log_scale, affine = ctx.spec
+        # G is laid out over od = the sample's leading dims, in the sample's order (checked at the call site)
+        prev = ctx.holder.get("own")
+        G = G.contiguous()
+        ctx.holder["own"] = (G if prev is None else prev[0] + G, -float(affine[0]))
+        return None, None, None, None, None
 
 
 def _peek(p):
@@ -621,7 +677,7 @@ class TorchDimDist:
                 # one autograd node: exp of the raw scale, the noise and the affine map inside; its backward is two
                 # small library reductions (see _ReparamNormal)
                 # (the tensors themselves are kept: while the sample lives nothing else can take their addresses)
-                src = (_tkey(loc.x), loc.ids, _tkey(sv.x), sv.ids, lazy, loc.x, sv.x)
+                src = (_tkey(loc.x), loc.ids, _tkey(sv.x), sv.ids, lazy, loc.x, sv.x, {})
                 pl = self.sample_batch_ndim - self.arg_batch_ndim["loc"]
                 ps = self.sample_batch_ndim - self.arg_batch_ndim["scale"]
                 if not sample_shape:
@@ -635,7 +691,7 @@ class TorchDimDist:
                     perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
                     perm = None if perm == list(range(len(perm))) else perm
                     if _DRAW_BATCH[0] is not None:
-                        return _DRAW_BATCH[0].add(la, sa, lazy, full, perm, sample_dims, src, True)
+                        return _DRAW_BATCH[0].add(la, sa, lazy, full, perm, sample_dims, src, True, holder=src[7])
                     x = _ReparamNormal.apply(la, None if lazy else sa, sa if lazy else None, full, perm)
                     return ReparamPT(x, sample_dims, src)
                 la, sa = pt_align(loc, self.all_arg_ids, pl), pt_align(sv, self.all_arg_ids, ps)
@@ -756,6 +812,11 @@ class TorchDimDist:
                     and x.src[:5] == (_tkey(loc.x), loc.ids, _tkey(sx), scale.ids, lazy):
                 # x is this distribution's own reparameterised sample: the log-prob's total gradient reaches the
                 # (log) scale only
+                holder = x.src[7] if len(x.src) > 7 else None
+                if OWN_LOGQ_FOLD and lazy and holder is not None and holder.get("node") and x.x.requires_grad \
+                        and tuple(id(d_) for d_ in out_dims) == tuple(x.ids) and x.x.dtype == t.float32 \
+                        and float(ab[0]) == float(holder.setdefault("coef", float(ab[0]))):
+                    return PT(_OwnSampleLogProbFolded.apply(spec, x.x, loc.x, sx, holder), out_dims)
                 return PT(_OwnSampleLogProb.apply(spec, x.x, loc.x, sx), out_dims)
             return PT(_FusedNormalLogProb.apply(spec, x.x, loc.x, sx), out_dims)
         if kind == "bernoulli":
