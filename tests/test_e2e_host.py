@@ -790,3 +790,34 @@ def test_chained_launch_equals_the_separate_launches(K, split, mode, tail, monke
         assert abs(got - separate) <= 2e-6 * abs(separate), (got, separate)
     for st in (*N._CHAIN_STATE.values(), *[g.chain_state for g in sample.__dict__.get("_graphs", {}).values()]):
         assert st.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown")])
+def test_own_log_q_gradient_folded_into_the_draw_node_is_the_same_gradient(fixture, model, monkeypatch):
+    """dist.OWN_LOGQ_FOLD: log q's share of a log-scale's gradient handed to the node that drew the sample (one launch
+    writes the parameter's whole gradient) against the separate autograd contribution: same particles, same ELBO, the
+    same parameter gradients; and the fold is actually taken (fewer launches)."""
+    from alan_amd import dist as D
+    fx = load_golden(fixture)
+    res = {}
+    for fold in (True, False):
+        monkeypatch.setattr(D, "OWN_LOGQ_FOLD", fold)
+        taken = []
+        real = D._OwnSampleLogProbFolded.apply
+        monkeypatch.setattr(D._OwnSampleLogProbFolded, "apply", staticmethod(lambda *a: (taken.append(1), real(*a))[1]))
+        prob = models.BUILDERS[model](fx).to("cuda").float()
+        t.manual_seed(21)
+        sample = prob.sample(int(fx["K"]), reparam=True)
+        elbo = sample.elbo_vi(alan.no_checkpoint)
+        elbo.backward()
+        res[fold] = (float(elbo), {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None},
+                     len(taken))
+        monkeypatch.setattr(D._OwnSampleLogProbFolded, "apply", real)
+    (e1, g1, n1), (e0, g0, n0) = res[True], res[False]
+    assert n1 >= 2 and n0 == 0, (n1, n0)
+    assert abs(e1 - e0) <= 1e-6 * abs(e0)
+    assert g1.keys() == g0.keys() and len(g0) >= 2
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g1[n], g0[n], rtol=2e-5, atol=2e-6 * scale, msg=lambda m: f"{n}: {m}")
