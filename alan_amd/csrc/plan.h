@@ -32,7 +32,7 @@ struct GroupDesc {
 // everywhere, 32-bit strides.  Everything a thread needs arrives in one round of scalar loads -- the generic
 // kernel walks its 1.4 KB descriptor with run-time loops, i.e. a chain of ~10 dependent scalar loads, which
 // is most of the duration of a launch that reads a few hundred elements.
-constexpr int SMALL_NK = 3, SMALL_NR = 2;
+constexpr int SMALL_NK = 4, SMALL_NR = 2;
 constexpr int SMALL_MULTI = 8;     // problems per reduce_small_multi_kernel launch (its kernel argument: 3.3 KB of the 4 KB)
 constexpr int CHAIN_MULTI = 4;     // problems in the prelude of a chained launch (normal_lse_chain.hip: its argument holds more)
 
