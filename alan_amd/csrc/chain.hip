@@ -691,12 +691,27 @@ struct WaveOuts {
     int n[WAVE_ROUNDS];
 };
 
+// The parent's contraction of a single chain, run by the last launch's one workgroup behind its last round
+// (alan_chain_final_t): out = log(sum_k exp(x_k - max) + eps) + max + add_const, x_k = vec[k] + sum_f extra_f[k]
+// (reduce_Ks.py:249-251 + utils.py:218-220 on [K_init] vectors: an evaluation's last launch, one fewer).
+struct WaveFinal {
+    const float *extra[3];
+    int32_t stride[3];
+    int32_t n_extra, on;
+    float add_const;
+    float *out;
+    float *const *ring_slots;
+    int32_t *ring_counter;
+    int32_t ring_n;
+};
+
 // MAXT: the largest workgroup the instantiation is launched with (launches of <= 3 rounds: 256 threads -- one wave per
 // SIMD, so the loads of the on-load terms have registers to be in flight in)
 template <int NADD, bool NORM = false, int MAXT = 1024>   // further terms added to the input on load (ChainAdd): 0..2 tensors, the Normal term
 __global__ __launch_bounds__(MAXT) void chain_wave_kernel(const float *ms, int64_t sB, int64_t sT, int64_t sRow,
                                                           int64_t sCol, int n_in, int K, int rounds, const WaveOuts outs,
-                                                          float *vec_out, const ChainAdd<float> ad) {
+                                                          float *vec_out, const ChainAdd<float> ad,
+                                                          const WaveFinal fin = WaveFinal()) {
     extern __shared__ __align__(16) float wl[];
     const int NW = blockDim.x >> 6;                      // waves = products of the first round = 2^(rounds - 1)
     float *tiles = wl;                                   // NW tiles written by rounds 0, 2, 4, then NW / 2 by rounds 1, 3
@@ -849,7 +864,31 @@ __global__ __launch_bounds__(MAXT) void chain_wave_kernel(const float *ms, int64
 #pragma unroll
         for (int c = 0; c < 16; ++c) sum += expf(x[c] - mref);
         sum += __shfl_xor(sum, 32);
-        if (lane < K) vec_out[b * K + lane] = logf(sum) + mref;
+        const float v = logf(sum) + mref;
+        if (lane < K) vec_out[b * K + lane] = v;
+        if (fin.on) {                                      // (one chain: b = 0)
+            float x = lane < K ? v : NINF;
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+                if (f < fin.n_extra) x += fin.extra[f][min(lane, K - 1) * fin.stride[f]];
+            float fm = x, fs = lane < K ? 1.f : 0.f;        // (x - max, summed: the lane's own term is exp(0))
+            // lanes >= K hold (-inf, 0): lse_merge leaves them out; a NaN term poisons the sum
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) {
+                const float m2 = __shfl_xor(fm, ofs), s2 = __shfl_xor(fs, ofs);
+                lse_merge(fm, fs, m2, s2);
+            }
+            if (lane == 0) {
+                const float res = lse_finish(fm, fs) + fin.add_const;
+                if (fin.ring_n) {
+                    const int32_t slot = *fin.ring_counter;
+                    *fin.ring_slots[slot] = res;
+                    *fin.ring_counter = slot + 1 == fin.ring_n ? 0 : slot + 1;
+                } else {
+                    *fin.out = res;
+                }
+            }
+        }
     }
 }
 
@@ -881,7 +920,7 @@ template <typename T>
 static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
                      int64_t sCol, void *out_chain, void *out_vec, void *ws, size_t ws_bytes, hipStream_t stream,
                      const void *const *more = nullptr, const int64_t *more_strides = nullptr, int n_more = 0,
-                     const alan_chain_normal_t *normal = nullptr) {
+                     const alan_chain_normal_t *normal = nullptr, const alan_chain_final_t *final_ = nullptr) {
     ChainAdd<T> ad0, none;
     std::memset(&ad0, 0, sizeof(ad0));
     std::memset(&none, 0, sizeof(none));
@@ -966,9 +1005,19 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             if (r == 0 && normal)
                 wk = nadd == 0 ? chain_wave_kernel<0, true, 256> : nadd == 1 ? chain_wave_kernel<1, true, 256>
                                                                               : chain_wave_kernel<2, true, 256>;
+            WaveFinal wf;
+            std::memset(&wf, 0, sizeof(wf));
+            if (last && final_) {
+                wf.on = 1, wf.n_extra = final_->n_extra, wf.add_const = (float)final_->add_const;
+                for (int f = 0; f < final_->n_extra; ++f)
+                    wf.extra[f] = (const float *)final_->extra[f], wf.stride[f] = (int32_t)final_->stride[f];
+                wf.out = (float *)final_->out;
+                wf.ring_slots = (float *const *)final_->ring_slots, wf.ring_counter = (int32_t *)final_->ring_counter;
+                wf.ring_n = final_->ring_n;
+            }
             hipLaunchKernelGGL(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
                                (const float *)src, cB, cT, cR, cC, (int)tl.n[r], (int)K, rounds, wo,
-                               last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef);
+                               last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef, wf);
             if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
             r += rounds;
             src = (const T *)wo.o[rounds - 1];
@@ -977,6 +1026,8 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             cR = K;
             cC = 1;
         }
+    } else if (final_) {
+        return ALAN_ERR_UNSUPPORTED;                      // (only the one-wave-per-product kernel carries the parent's contraction)
     } else if (K <= 32 && !per_round) {
         const size_t slot = (KP * (KP + 4) + KP * KP + 2 * KP) * sizeof(T);
         auto tk = chain_tree_kernel<T>;
@@ -1486,21 +1537,39 @@ extern "C" int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_
     return ALAN_ERR_BAD_DESC;
 }
 
-extern "C" int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
-                                                const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T,
-                                                int64_t K, void *out_chain, void *out_vec, void *workspace,
-                                                size_t workspace_bytes, void *stream) {
+extern "C" int alan_chain_logmmexp_terms_final(const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                               const alan_chain_normal_t *normal, const alan_chain_final_t *fin,
+                                               int32_t dtype, int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
+                                               void *workspace, size_t workspace_bytes, void *stream) {
     if (!terms || !strides || n_terms < 1 || n_terms > 3 || !terms[0] || B < 1 || T < 1 || K < 1 ||
         (!out_chain && !out_vec))
         return ALAN_ERR_BAD_DESC;
     if (T >= (1ll << 31) || B > 65535) return ALAN_ERR_UNSUPPORTED;
+    if (fin) {
+        if (fin->n_extra < 0 || fin->n_extra > 3 || !out_vec || (!fin->out && !fin->ring_n)) return ALAN_ERR_BAD_DESC;
+        if (fin->ring_n && (fin->ring_n < 0 || !fin->ring_slots || !fin->ring_counter)) return ALAN_ERR_BAD_DESC;
+        for (int f = 0; f < fin->n_extra; ++f) {
+            if (!fin->extra[f]) return ALAN_ERR_BAD_DESC;
+            if (fin->stride[f] < 0 || fin->stride[f] * K >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+        }
+        // one chain, the one-wave-per-product kernel's sizes (chain_run declines the rest)
+        if (B != 1 || dtype != ALAN_F32 || K <= 12 || K > 32) return ALAN_ERR_UNSUPPORTED;
+    }
     if (dtype == ALAN_F32)
         return chain_run<float>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
-                                workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1, normal);
+                                workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1, normal, fin);
     if (dtype == ALAN_F64)
         return chain_run<double>(terms[0], B, T, K, strides[0], strides[1], strides[2], strides[3], out_chain, out_vec,
                                  workspace, workspace_bytes, (hipStream_t)stream, terms + 1, strides + 4, n_terms - 1, normal);
     return ALAN_ERR_BAD_DESC;
+}
+
+extern "C" int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                                const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T,
+                                                int64_t K, void *out_chain, void *out_vec, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    return alan_chain_logmmexp_terms_final(terms, strides, n_terms, normal, nullptr, dtype, B, T, K, out_chain, out_vec,
+                                           workspace, workspace_bytes, stream);
 }
 
 extern "C" int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,

@@ -75,6 +75,11 @@ class ChainNormal(C.Structure):
                 ("loc_mul", C.c_double), ("log_scale", C.c_int32), ("loc0", C.c_void_p), ("l0_stride", C.c_int64 * 4)]
 
 
+class ChainFinal(C.Structure):
+    _fields_ = [("n_extra", C.c_int32), ("extra", C.c_void_p * 3), ("stride", C.c_int64 * 3), ("add_const", C.c_double),
+                ("out", C.c_void_p), ("ring_slots", C.c_void_p), ("ring_counter", C.c_void_p), ("ring_n", C.c_int32)]
+
+
 class BackwardDesc(C.Structure):
     _fields_ = [("fwd", ReduceDesc), ("grad", Tensor * MAX_FACTORS)]
 
@@ -161,6 +166,11 @@ def lib():
         L.alan_chain_logmmexp_terms_normal.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
                                                        C.POINTER(ChainNormal), C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.alan_chain_logmmexp_terms_final.restype = C.c_int
+        L.alan_chain_logmmexp_terms_final.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                                                      C.POINTER(ChainNormal), C.POINTER(ChainFinal), C.c_int32, C.c_int64,
+                                                      C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                      C.c_void_p]
         L.alan_chain_backward_batched_workspace_bytes.restype = C.c_size_t
         L.alan_chain_backward_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp_backward_batched.restype = C.c_int
@@ -186,7 +196,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_chain_workspace_bytes",
            "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
            "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
-           "alan_chain_logmmexp_terms_normal",
+           "alan_chain_logmmexp_terms_normal", "alan_chain_logmmexp_terms_final",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
            "alan_abi_version", "alan_build_target")
@@ -241,6 +251,7 @@ class _Queue(threading.local):
         self.pending = []        # [(desc, device, keepalive tensors)]
         self.depth = [0, 0]      # nesting of deferring() / may_defer()
         self.fused = None        # a fused plate step waiting for its launch (_Fused), issued BEFORE ``pending``
+        self.chain = None        # a single timeseries chain waiting for its launch (_PendingChain): the final contraction may join it
         self.tail_ok = 0         # nesting of tail_attach(): launches of an evaluation's final contraction
 
 
@@ -270,6 +281,7 @@ def deferring():
         if _Q.depth[0] == 0:
             _Q.pending.clear()          # (only non-empty after an exception)
             _Q.fused = None
+            _Q.chain = None
 
 
 # ---- the chained launch (alan_normal_lse_chained) ------------------------------------------------------------------
@@ -341,7 +353,51 @@ def own_chain_state(device):
 
 
 def fused_pending():
-    return _Q.fused is not None
+    return _Q.fused is not None or _Q.chain is not None
+
+
+CHAIN_FINAL = os.environ.get("ALAN_AMD_CHAIN_FINAL", "1") != "0"
+"""A single timeseries chain (one-wave-per-product kernel: fp32, 12 < K <= 32) is queued like a fused plate step, and the
+evaluation's final contraction -- a log-sum-exp over [K_init] vectors, one of them the chain's result -- runs behind the
+last round of the chain's last launch, which is ONE workgroup: no hand-off between workgroups, one launch fewer
+(alan_chain_logmmexp_terms_final)."""
+
+
+class _PendingChain:
+    def __init__(self, launch, vec, K, device, keepalive):
+        self.launch, self.vec, self.K, self.device, self.keepalive = launch, vec, K, device, keepalive
+
+    def try_final(self, desc, device, keepalive):
+        """The alan_reduce call `desc` as this chain's final contraction, if it is one.  True: launched together."""
+        if device != self.device or desc.mode != MODE_LSE or desc.weight.data or desc.lse_out.data \
+                or desc.out.dtype != F32 or not (1 <= desc.n_factors <= 4):
+            return False
+        big = [i for i in range(desc.ndim) if desc.size[i] > 1]
+        if len(big) != 1 or desc.role[big[0]] != REDUCE or desc.size[big[0]] != self.K:
+            return False
+        k = big[0]
+        fin, mine = ChainFinal(), 0
+        for f in range(desc.n_factors):
+            fac = desc.factor[f]
+            if fac.dtype != F32 or fac.scale != 1.0:
+                return False
+            if fac.data == self.vec.data_ptr() and fac.stride[k] == 1:
+                mine += 1
+                continue
+            if fin.n_extra == 3 or fac.stride[k] < 0:
+                return False
+            fin.extra[fin.n_extra], fin.stride[fin.n_extra] = fac.data, fac.stride[k]
+            fin.n_extra += 1
+        if mine != 1:
+            return False
+        fin.add_const, fin.out = desc.add_const, desc.out.data
+        fin.ring_slots, fin.ring_counter, fin.ring_n = desc.ring_slots, desc.ring_counter, desc.ring_n
+        _Q.chain = None
+        self.keepalive = (self.keepalive, keepalive)
+        if not self.launch(fin):                          # (the library declined: the chain alone, the caller goes on)
+            self.launch(None)
+            return False
+        return True
 
 
 @contextlib.contextmanager
@@ -404,6 +460,9 @@ def may_defer():
 
 def flush():
     """Issue every queued launch now (in order)."""
+    if _Q.chain is not None:
+        c, _Q.chain = _Q.chain, None
+        c.launch(None)
     if _Q.fused is not None:
         f = _Q.fused
         # producers queued behind the fused launch read nothing it writes: they ride in its prelude while there is room
@@ -451,6 +510,9 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
         _Q.pending.append((desc, device, keepalive))
         if len(_Q.pending) >= 16:
             flush()
+        return True
+    if _Q.chain is not None and _Q.tail_ok and _TIMER[0] is None and not t.is_grad_enabled() and \
+            _Q.chain.try_final(desc, device, keepalive):
         return True
     if _Q.fused is not None and _Q.tail_ok and not lin_grad and _TIMER[0] is None and not t.is_grad_enabled() and \
             L.alan_reduce_workspace_bytes(C.byref(desc)) == 0 and _try_tail(desc, device, keepalive):
@@ -624,9 +686,21 @@ def chain_logmmexp_terms(terms, normal=None):
             nd.loc0 = l0.data_ptr()
             for q in range(4):
                 nd.l0_stride[q] = l0.stride(q)
-    rc = L.alan_chain_logmmexp_terms_normal(ptrs, strides, len(terms), C.byref(nd) if nd is not None else None, code,
-                                            B, T, K, None, vec.data_ptr(), tree.data_ptr(), nbytes, current_stream(device))
-    check(rc, "alan_chain_logmmexp_terms_normal")
+    def launch(fin):
+        rc = L.alan_chain_logmmexp_terms_final(ptrs, strides, len(terms), C.byref(nd) if nd is not None else None,
+                                               C.byref(fin) if fin is not None else None, code, B, T, K, None,
+                                               vec.data_ptr(), tree.data_ptr(), nbytes, current_stream(device))
+        if rc == ERR_UNSUPPORTED and fin is not None:
+            return False
+        check(rc, "alan_chain_logmmexp_terms_final")
+        return True
+
+    if CHAIN_FINAL and _Q.depth[0] and _Q.chain is None and B == 1 and 12 < K <= 32 and terms[0].dtype == t.float32 \
+            and _TIMER[0] is None and not t.is_grad_enabled():
+        # queued: its result only ever feeds the parent's contraction (logpq._chain_of_terms), which may join its launch
+        _Q.chain = _PendingChain(launch, vec, K, device, (terms, normal, tree, ptrs, strides, nd))
+        return vec
+    launch(None)
     return vec
 
 

@@ -265,7 +265,8 @@ class Sample:
         from . import logpq as LP
         from . import split as SP
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS, N.CHAIN_LAUNCHES, N.CHAIN_TAIL)
+                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS, N.CHAIN_LAUNCHES, N.CHAIN_TAIL,
+                N.CHAIN_FINAL)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)

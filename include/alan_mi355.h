@@ -344,6 +344,25 @@ typedef struct {
 int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
                                      const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                      void *out_chain, void *out_vec, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the PARENT's contraction of the chain's result run by the chain's last launch (one workgroup) behind its
+ * last round -- the evaluation's final reduce_Ks when the timeseries plate sits under the top level (Sample.py:69-86,
+ * reduce_Ks.py:249-251 + utils.py:218-220 on [K_init] vectors): one launch fewer per evaluation.
+ *     out = log(sum_k exp(x_k - max_k x_k) + eps) + max_k x_k + add_const,   x_k = out_vec[k] + sum_f extra_f[k * stride_f]
+ * written to *out, or through a result ring (ring_*, as alan_reduce_desc_t).  One chain (B = 1), fp32, 12 < K <= 32 (the
+ * one-wave-per-product kernel); ALAN_ERR_UNSUPPORTED otherwise (nothing launched: issue the chain and alan_reduce). */
+typedef struct {
+    int32_t n_extra;                  /* 0 .. 3 further [K] factors */
+    const void *extra[3];
+    int64_t stride[3];                /* element strides (0 = a scalar broadcast) */
+    double add_const;
+    void *out;
+    void *ring_slots, *ring_counter;
+    int32_t ring_n;
+} alan_chain_final_t;
+int alan_chain_logmmexp_terms_final(const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                    const alan_chain_normal_t *normal, const alan_chain_final_t *fin, int32_t dtype,
+                                    int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                          int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,

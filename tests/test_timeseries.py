@@ -79,6 +79,30 @@ def test_timeseries_T1000_K30_runs_and_matches_oracle_chain():
     assert abs(gpu - cpu) <= 1e-4 * abs(cpu) + 1e-3, (gpu, cpu)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,K", [(1000, 30), (37, 16), (64, 32)])
+def test_final_contraction_inside_the_chains_last_launch_is_the_same_elbo(T, K, monkeypatch):
+    """native.CHAIN_FINAL: the evaluation's last log-sum-exp (over K_init, of the chain's result plus the initial state's
+    factor) run by the chain's last launch behind its last round -- against the separate launch, eagerly and as a replayed
+    graph (through the result ring), and it is actually taken."""
+    from alan_amd import native as N
+    prob, _ = kalman_problem(T)
+    prob.to("cuda")
+    t.manual_seed(7)
+    sample = prob.sample(K, reparam=False)
+    monkeypatch.setattr(N, "CHAIN_FINAL", False)
+    separate = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    monkeypatch.setattr(N, "CHAIN_FINAL", True)
+    taken = []
+    real = N._PendingChain.try_final
+    monkeypatch.setattr(N._PendingChain, "try_final", lambda self, *a: (lambda r: (taken.append(r), r)[1])(real(self, *a)))
+    eager = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert taken and taken[-1] is True, taken
+    replayed = [float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) for _ in range(4)]
+    for got in (eager, *replayed):
+        assert abs(got - separate) <= 2e-6 * abs(separate) + 1e-5, (got, separate)
+
+
 def _ts_posterior_check(device, K, N):
     """Timeseries posterior: marginals (chain backward) and importance samples (sample_Ks_timeseries) vs
     each other and vs the closed-form Kalman smoother mean (tests/timeseries.py:52-56 of the reference)."""
