@@ -269,7 +269,7 @@ static int classify(const alan_reduce_desc_t &d, uint32_t &keep, uint32_t &red, 
         d.mode != ALAN_MODE_NORMAL && d.mode != ALAN_MODE_BERNOULLI && d.mode != ALAN_MODE_NORMAL_LOGSCALE &&
         d.mode != ALAN_MODE_PRODUCER_GRAD && d.mode != ALAN_MODE_DOT && d.mode != ALAN_MODE_AFFINE)
         return ALAN_ERR_BAD_DESC;
-    if (d.mode == ALAN_MODE_DOT && (d.n_factors < 2 || d.n_factors > 4)) return ALAN_ERR_BAD_DESC;
+    if (d.mode == ALAN_MODE_DOT && (d.n_factors < 2 || d.n_factors > 5)) return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_AFFINE && d.n_factors != 3) return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_NORMAL_LOGSCALE && d.n_factors != 3) return ALAN_ERR_BAD_DESC;
     if (d.mode == ALAN_MODE_NORMAL && d.n_factors != 3 && d.n_factors != 6) return ALAN_ERR_BAD_DESC;

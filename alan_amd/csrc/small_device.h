@@ -72,7 +72,9 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
         // (a third factor multiplies in, through exp when its scale field says it holds a logarithm)
         const T third = nf > 2 ? (scale[2] == 2.f ? Num<T>::exp_acc(val[2]) : val[2]) : T(1);
         // (a fourth factor is ADDED, weighted by its scale field: the other contribution to the same gradient)
-        s += ok ? val[0] * val[1] * third + (nf > 3 ? (T)scale[3] * val[3] : T(0)) : T(0);
+        // and a fifth joins the first: (f0 + f4) f1 g(f2) -- a gradient that arrives in two pieces
+        const T lead = val[0] + (nf > 4 ? val[4] : T(0));
+        s += ok ? lead * val[1] * third + ((nf > 3 && scale[3] != 0.f) ? (T)scale[3] * val[3] : T(0)) : T(0);
     } else if (MODE == ALAN_MODE_AFFINE) {
         const T sc = scale[2] == 2.f ? Num<T>::exp_acc(val[2]) : val[2];
         s += ok ? val[0] + val[1] * sc : T(0);

@@ -183,14 +183,22 @@ class ReparamPT(PT):
     """A reparameterised Normal sample x = loc + eps * scale, with a key of the parameter tensors that made it (address,
     layout, version: dist._tkey).  A log-prob of x under that very distribution then knows log q(x) = -eps^2 / 2 -
     log scale - const: its total gradient reaches the scale only (dist._OwnSampleLogProb)."""
-    __slots__ = ("src",)
+    __slots__ = ("src", "x2")
 
-    def __init__(self, x, dims, src):
+    def __init__(self, x, dims, src, x2=None):
         PT.__init__(self, x, dims)
         self.src = src
+        # a second autograd output of the node that drew the sample, aliasing the same memory: the consumer that takes it
+        # (the variable's own log P term, logpq.logPQ_group) sends its gradient to the node separately, so autograd has no
+        # two contributions to add with a kernel of its own (dist._ReparamNormalBatch)
+        self.x2 = x2
 
     def detach(self):
         return PT(self.x.detach(), self.dims)
+
+    def alias(self):
+        """The sample for the ONE consumer that may take the second output (else the sample itself)."""
+        return PT(self.x2, self.dims) if self.x2 is not None else self
 
 
 class PendingPT(ReparamPT):
@@ -203,6 +211,7 @@ class PendingPT(ReparamPT):
         self.dims = tuple(dims)
         self.ids = tuple(id(d) for d in self.dims)
         self.src = src
+        self.x2 = None
 
     @property
     def x(self):
@@ -211,7 +220,7 @@ class PendingPT(ReparamPT):
         return self._val
 
     def settled(self):
-        return ReparamPT(self.x, self.dims, self.src) if self.src is not None else PT(self.x, self.dims)
+        return ReparamPT(self.x, self.dims, self.src, self.x2) if self.src is not None else PT(self.x, self.dims)
 
 
 class ShiftPT(PT):

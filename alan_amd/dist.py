@@ -340,22 +340,37 @@ small library launches (the sums of G and of G * eps over the broadcast dims, al
 together) instead of the five or six torch kernels autograd derives from exp, addcmul and the broadcasts."""
 
 
-def _sum_to(G, other, shape, log_third=None, plus=None):
+def _sum_to(G, other, shape, log_third=None, plus=None, G2=None):
     """sum of G (or of G * other, or of G * other * exp(log_third) [+ c * plus[0] with plus = (tensor broadcastable to G,
-    c)]) over the dims along which a parameter of shape ``shape`` was broadcast to G's."""
+    c)]) over the dims along which a parameter of shape ``shape`` was broadcast to G's.  ``G2`` (fp32 on the GPU, with
+    log_third where other is given): G is G + G2, added inside the launch."""
     pad = G.ndim - len(shape)
     keep = [i for i in range(G.ndim) if i >= pad and shape[i - pad] != 1]
-    if plus is not None:
+    if G2 is not None and other is None:
+        from . import engine as E
+        from . import native as N
+        axes = tuple(range(G.ndim))
+        with N.may_defer():
+            out = E._produce(N.MODE_SUM, [(G, axes), (G2, axes)], tuple(keep))
+        return out.reshape(shape)
+    if plus is not None or G2 is not None:
         assert other is not None and log_third is not None
-        if G.is_cuda and G.dtype == t.float32 and other.dtype == t.float32 and plus[0].dtype == t.float32:
+        if G.is_cuda and G.dtype == t.float32 and other.dtype == t.float32 and (plus is None or plus[0].dtype == t.float32):
             from . import engine as E
             from . import native as N
             axes = tuple(range(G.ndim))
+            facs = [(G, axes), (other.expand_as(G), axes), (log_third.expand_as(G), axes),
+                    ((plus[0] if plus is not None else G).expand_as(G), axes)]
+            scales = [1.0, 1.0, 2.0, float(plus[1]) if plus is not None else 0.0]
+            if G2 is not None:
+                facs.append((G2, axes))
+                scales.append(1.0)
             with N.may_defer():
-                out = E._produce(N.MODE_DOT, [(G, axes), (other.expand_as(G), axes), (log_third.expand_as(G), axes),
-                                              (plus[0].expand_as(G), axes)], tuple(keep), scales=[1.0, 1.0, 2.0, float(plus[1])])
+                out = E._produce(N.MODE_DOT, facs, tuple(keep), scales=scales)
             return out.reshape(shape)
-        v = G * other * log_third.exp() + plus[1] * plus[0]
+        v = (G if G2 is None else G + G2) * other * log_third.exp()
+        if plus is not None:
+            v = v + plus[1] * plus[0]
         red = [i for i in range(G.ndim) if i not in keep]
         return (v.sum(red) if red else v).reshape(shape)
     if G.is_cuda and G.dtype == t.float32 and (other is None or other.dtype == t.float32) and \
@@ -464,8 +479,10 @@ class _DrawBatch:
             if rp:
                 meta = tuple((mine[k][2], eps[k], mine[k][7]) for k in rp)
                 res = _ReparamNormalBatch.apply(meta, *[x for k in rp for x in (mine[k][0], mine[k][1])])
-                for k, x in zip(rp, res):
-                    outs[k] = x
+                for i, k in enumerate(rp):
+                    outs[k] = res[i]
+                    if SAMPLE_ALIAS:
+                        mine[k][5].x2 = res[len(rp) + i]
             rest = [k for k in range(len(mine)) if not mine[k][6]]
             if rest:
                 with t.no_grad():
@@ -509,7 +526,8 @@ class _ReparamNormalBatch(t.autograd.Function):
                 m[2]["node"] = True
         ctx.shapes = [(tuple(l.shape), tuple(s_.shape)) for l, s_, _, _ in jobs]
         ctx.save_for_backward(*[j[1] for j in jobs])
-        return tuple(outs)
+        # every sample twice: the second output aliases the first (dims.ReparamPT.x2) -- two consumers, two gradient slots
+        return tuple(outs) + tuple(o.view_as(o) for o in outs)
 
     @staticmethod
     @t.autograd.function.once_differentiable
@@ -517,15 +535,23 @@ class _ReparamNormalBatch(t.autograd.Function):
         from . import native as N
         grads = [None]
         with N.deferring():
-            for i, ((is_log, eps, holder), G) in enumerate(zip(ctx.meta, Gs)):
+            n = len(ctx.meta)
+            for i, ((is_log, eps, holder), G) in enumerate(zip(ctx.meta, Gs[:n])):
                 gl = gs = None
+                G2 = Gs[n + i]                            # (the gradient that arrived through the sample's second output)
+                if G is None:
+                    G, G2 = G2, None
                 own = holder.pop("own", None) if holder is not None else None
                 if G is None and own is not None:         # (nobody but its own log q used the sample)
                     G = t.zeros(eps.shape, dtype=eps.dtype, device=eps.device)
                 if G is not None:
                     G = G.contiguous()
+                    if G2 is not None:
+                        G2 = G2.contiguous()
+                        if not (G.is_cuda and G.dtype == G2.dtype == t.float32 and is_log):
+                            G, G2 = G + G2, None          # (the launches below take the pair only in this form)
                     if ctx.needs_input_grad[1 + 2 * i]:
-                        gl = _sum_to(G, None, ctx.shapes[i][0])
+                        gl = _sum_to(G, None, ctx.shapes[i][0], G2=G2)
                     if ctx.needs_input_grad[2 + 2 * i]:
                         plus = None
                         if own is not None:
@@ -533,7 +559,8 @@ class _ReparamNormalBatch(t.autograd.Function):
                             # event dims: d raw gets coef * its sum over the same broadcast dims, in the same launch
                             Gq, coef = own
                             plus = (Gq.reshape(tuple(Gq.shape) + (1,) * (G.ndim - Gq.ndim)), coef)
-                        gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None, plus=plus)
+                        gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None, plus=plus,
+                                     G2=G2)
                 grads += [gl, gs]
         return tuple(grads)
 
@@ -576,6 +603,12 @@ class _OwnSampleLogProb(t.autograd.Function):
             return None, None, None, (g if a == -1.0 else g * (-a))
         return None, None, None, g * (-a) / scale
 
+
+SAMPLE_ALIAS = os.environ.get("ALAN_AMD_SAMPLE_ALIAS", "1") != "0"
+"""The node that draws a batch of samples returns every sample twice -- the second output aliases the first -- and the
+variable's own log P term takes the second (logpq.logPQ_group): the two gradients a sample receives (from its prior term
+and from whatever it parameterises) reach the node in separate slots and are added inside its backward's launches
+(two-factor SUM, five-factor DOT) instead of by an add kernel of autograd's: three launches fewer per VI iteration."""
 
 OWN_LOGQ_FOLD = os.environ.get("ALAN_AMD_OWN_FOLD", "1") != "0"
 """The log-scale gradient that a variable's own log q contributes (-1 per unit of upstream gradient, _OwnSampleLogProb) is

@@ -307,6 +307,15 @@ def _logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, sco
     return lp
 
 
+def _for_own_log_p(x):
+    """The sample as its own log P term sees it: the second output of the node that drew it, where there is one and
+    gradients are recorded (dims.ReparamPT.alias: the gradient then reaches that node in a slot of its own)."""
+    from .dims import ReparamPT
+    if t.is_grad_enabled() and isinstance(x, ReparamPT) and x.x2 is not None:
+        return x.alias()
+    return x
+
+
 def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarname2Kdim,
                 varname2groupvarname, sampler, dimcache=None):
     """Factors of one latent group on its K dim:  sum_v log P(v) , -(reduce_logQ(sum_v log Q(v)) + log K)."""
@@ -332,7 +341,7 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
         if pq is not None:                      # log P - log Q - log K in one launch
             return [pq], (Kdim,), (), ()
         with N.may_defer():
-            lp = tP.log_prob_pt(sample[var], dim_order=order)
+            lp = tP.log_prob_pt(_for_own_log_p(sample[var]), dim_order=order)
             neg_q = tQ.log_prob_pt(sample[var], dim_order=order, affine=(-1.0, -math.log(K), own))
         if not set(neg_q.ids) <= own:           # log Q carries a parent K: reduce it first (Sampler.py:118-134)
             lq = sampler.reduce_logQ(neg_q, active_platedims, Kdim)
@@ -355,7 +364,7 @@ def logPQ_group(name, prog_P, prog_Q, sample, scope, active_platedims, groupvarn
                 pqs.append(pq)
                 continue
             with N.may_defer():                    # a factor of the plate's contraction and nothing else
-                lp = tP.log_prob_pt(x, dim_order=order)
+                lp = tP.log_prob_pt(_for_own_log_p(x), dim_order=order)
             Kinit_p = Kinit_q = None
             if (set(x.ids) | set(tQ.all_arg_ids)) <= own:
                 # log Q on the group's own dims: reduce_logQ leaves it alone and is separable over such terms, so

@@ -95,12 +95,14 @@ typedef enum {
                               is sum over ONE ALAN_DOT dim of their product.  At most 3 terms; fp32 only
                               (ALAN_ERR_UNSUPPORTED otherwise: evaluate the logits and use ALAN_MODE_BERNOULLI).
                               out = out.scale * sum_R [ logsigmoid(l) - (1 - value) * l ] + add_const */
-    ALAN_MODE_DOT = 8,     /* out = sum_R [ factor_0 * factor_1 [* g(factor_2)] [+ factor_3.scale * factor_3] ] (+ add_const):
-                              2 factors, or 3 with g as in ALAN_MODE_AFFINE (the gradient of a reparameterised draw with
+    ALAN_MODE_DOT = 8,     /* out = sum_R [ (factor_0 [+ factor_4]) * factor_1 [* g(factor_2)] [+ factor_3.scale * factor_3] ]
+                              (+ add_const): 2 factors, or 3 with g as in ALAN_MODE_AFFINE (the gradient of a reparameterised draw with
                               respect to its log-scale: sum G * eps * exp(raw)), or 4 with one more SUMMAND (that
                               gradient's other contribution -- the -1 per unit of log q's upstream gradient that
                               TorchDimDist.py:127-162 gives the log-scale of a variable's own draw -- so that one launch
-                              writes the parameter's whole gradient).  A term of such logits whose
+                              writes the parameter's whole gradient), or 5: the upstream gradient given as the sum of two
+                              tensors (a sample used by two consumers: factor_3.scale = 0 when there is no summand).
+                              A term of such logits whose
                               operands lack some dim of the likelihood's index space, evaluated once (what the lambda's
                               `phi @ bus_company_name` is); small ones join alan_reduce_batch launches */
     ALAN_MODE_AFFINE = 10, /* out = sum_R [ factor_0 + factor_1 * g(factor_2) ] (+ add_const), g = exp where factor_2.scale == 2

@@ -792,6 +792,14 @@ def test_chained_launch_equals_the_separate_launches(K, split, mode, tail, monke
         assert st.tolist() == [0, 0, 0, 0]
 
 
+def _leaves(tree):
+    for v in tree.values():
+        if isinstance(v, dict):
+            yield from _leaves(v)
+        else:
+            yield v
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown")])
 def test_own_log_q_gradient_folded_into_the_draw_node_is_the_same_gradient(fixture, model, monkeypatch):
@@ -817,6 +825,20 @@ def test_own_log_q_gradient_folded_into_the_draw_node_is_the_same_gradient(fixtu
     (e1, g1, n1), (e0, g0, n0) = res[True], res[False]
     assert n1 >= 2 and n0 == 0, (n1, n0)
     assert abs(e1 - e0) <= 1e-6 * abs(e0)
+    # dist.SAMPLE_ALIAS off (a sample's two gradient contributions added by autograd's own kernel) gives them too
+    monkeypatch.setattr(D, "OWN_LOGQ_FOLD", True)
+    monkeypatch.setattr(D, "SAMPLE_ALIAS", False)
+    prob = models.BUILDERS[model](fx).to("cuda").float()
+    t.manual_seed(21)
+    sample = prob.sample(int(fx["K"]), reparam=True)
+    assert all(getattr(v, "x2", None) is None for v in _leaves(sample.reparam_sample_pt if hasattr(sample, "reparam_sample_pt") else {}))
+    elbo = sample.elbo_vi(alan.no_checkpoint)
+    elbo.backward()
+    g2 = {n: p.grad.detach().clone() for n, p in prob.named_parameters() if p.grad is not None}
+    assert abs(float(elbo) - e0) <= 1e-6 * abs(e0) and g2.keys() == g0.keys()
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-6
+        t.testing.assert_close(g2[n], g1[n], rtol=2e-5, atol=2e-6 * scale, msg=lambda m: f"{n} (alias off): {m}")
     assert g1.keys() == g0.keys() and len(g0) >= 2
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
