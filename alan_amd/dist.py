@@ -1295,7 +1295,7 @@ def _producer_terms(value, terms):
 
 def call_model_lambda(fn, named_args, dimcache=None):
     vals = [v for _, v in named_args]
-    if len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_floating_point() and _is_plain_exp(fn):
+    if len(vals) == 1 and type(vals[0]) in (PT, ReparamPT) and vals[0].x.is_floating_point() and _is_plain_exp(fn):
         # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
         # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
         return ExpPT(vals[0].x, vals[0].dims)
