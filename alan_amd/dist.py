@@ -736,23 +736,25 @@ class TorchDimDist:
                 return ReparamPT(x, (*extra, *self.all_arg_dims), src)
         if self.dist is td.Normal and set(self.kwargs) == {"loc", "scale"} and not sample_shape \
                 and not (reparam and t.is_grad_enabled()) \
-                and self.kwargs["loc"].x.dtype == self.kwargs["scale"].x.dtype \
-                and self.kwargs["loc"].x.device == self.kwargs["scale"].x.device:
+                and self.kwargs["loc"].x.dtype == _peek(self.kwargs["scale"]).dtype \
+                and self.kwargs["loc"].x.device == _peek(self.kwargs["scale"]).device:
             # gradient-free Normal draw, written directly in the caller's dim order (plates outermost, K innermost) from
             # noise drawn in rsample's order -- the same particles, no re-layout copy afterwards
             loc, scale = self.kwargs["loc"], self.kwargs["scale"]
             with t.no_grad():
                 la = pt_align(loc, ids, self.sample_batch_ndim - self.arg_batch_ndim["loc"])
-                sa = pt_align(scale, ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
+                # (a learned log-scale -- OptParam(transformation=exp) -- stays unevaluated for the batched draw: the exp
+                # happens in its launch, and the log-prob producers then take the raw parameter too)
+                lazy = _DRAW_BATCH[0] is not None and la.is_cuda and la.dtype == t.float32 and isinstance(scale, ExpPT) \
+                    and not scale.materialised
+                sa = pt_align(PT(scale.raw, scale.dims) if lazy else scale, ids,
+                              self.sample_batch_ndim - self.arg_batch_ndim["scale"])
                 n = len(ids)
                 rest = t.broadcast_shapes(la.shape[n:], sa.shape[n:])
                 drawn = [*extra, *self.all_arg_dims]
                 pos = {id(d_): k for k, d_ in enumerate(drawn)}
                 perm = [pos[i] for i in ids] + list(range(n, n + len(rest)))
                 if _DRAW_BATCH[0] is not None and la.is_cuda and la.dtype == t.float32:
-                    lazy = isinstance(scale, ExpPT) and not scale.materialised
-                    if lazy:                              # (the exp of a learned log-scale happens in the launch)
-                        sa = pt_align(PT(scale.raw, scale.dims), ids, self.sample_batch_ndim - self.arg_batch_ndim["scale"])
                     return _DRAW_BATCH[0].add(la, sa, lazy, [*[d_.size for d_ in drawn], *rest],
                                               None if perm == list(range(len(perm))) else perm, sample_dims, None, False)
                 eps = t.empty([*[d_.size for d_ in drawn], *rest], dtype=la.dtype, device=la.device).normal_().permute(perm)
