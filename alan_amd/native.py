@@ -183,6 +183,16 @@ def lib():
                                         C.c_void_p, *([C.c_int64] * 4), C.c_void_p, C.c_void_p]
         L.alan_chain_filter.restype = C.c_int
         L.alan_chain_filter.argtypes = [C.c_void_p, *([C.c_int64] * 7), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.alan_exchange_create.restype = C.c_int
+        L.alan_exchange_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.alan_exchange_connect.restype = C.c_int
+        L.alan_exchange_connect.argtypes = [C.c_void_p, C.c_char_p]
+        L.alan_exchange_sum.restype = C.c_int
+        L.alan_exchange_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.alan_exchange_status.restype = C.c_int
+        L.alan_exchange_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.alan_exchange_destroy.restype = C.c_int
+        L.alan_exchange_destroy.argtypes = [C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -199,7 +209,59 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_chain_logmmexp_terms_normal", "alan_chain_logmmexp_terms_final",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
+           "alan_exchange_create", "alan_exchange_connect", "alan_exchange_sum", "alan_exchange_status",
+           "alan_exchange_destroy",
            "alan_abi_version", "alan_build_target")
+
+EXCHANGE_MAX_RANKS = 8
+EXCHANGE_HANDLE_BYTES = 64
+
+
+class Exchange:
+    """This rank's end of the one-shot sum of per-rank partials (include/alan_mi355.h: alan_exchange_*).  `carry` takes
+    this rank's handle bytes and returns every rank's, rank-major (the caller's transport between the processes)."""
+
+    def __init__(self, world, rank, capacity, carry):
+        L = lib()
+        if not 1 <= world <= EXCHANGE_MAX_RANKS:
+            raise NativeError(f"alan_amd: a one-shot exchange takes up to {EXCHANGE_MAX_RANKS} ranks, not {world}")
+        buf = C.create_string_buffer(EXCHANGE_HANDLE_BYTES)
+        h = C.c_void_p()
+        rc = L.alan_exchange_create(world, rank, capacity, buf, C.byref(h))
+        if rc != 0:
+            raise NativeError(f"alan_exchange_create failed ({rc})")
+        self._h, self.world, self.rank, self.capacity = h, world, rank, capacity
+        handles = carry(buf.raw)
+        if len(handles) != world or any(len(x) != EXCHANGE_HANDLE_BYTES for x in handles):
+            raise NativeError("alan_amd: the exchange's handles did not come back one per rank")
+        rc = L.alan_exchange_connect(h, b"".join(handles))
+        if rc != 0:
+            raise NativeError(f"alan_exchange_connect failed ({rc}): are all ranks on one node, HSA_ENABLE_IPC_MODE_LEGACY=0?")
+
+    def sum(self, x):
+        """Sum over ranks of the fp32 device tensor x (contiguous), as a new tensor; enqueued on the current stream."""
+        if not (x.is_cuda and x.dtype == t.float32 and x.is_contiguous() and 1 <= x.numel() <= self.capacity):
+            raise NativeError("alan_amd: the one-shot exchange takes a contiguous fp32 device tensor within its capacity")
+        out = t.empty_like(x)
+        rc = lib().alan_exchange_sum(self._h, x.data_ptr(), out.data_ptr(), x.numel(),
+                                     t.cuda.current_stream(x.device).cuda_stream)
+        if rc != 0:
+            raise NativeError(f"alan_exchange_sum failed ({rc})")
+        return out
+
+    def status(self):
+        """(exchanges completed on this rank, number of the first exchange that timed out or 0); synchronises."""
+        t.cuda.synchronize()
+        done, bad = C.c_uint32(), C.c_uint32()
+        rc = lib().alan_exchange_status(self._h, C.byref(done), C.byref(bad))
+        if rc != 0:
+            raise NativeError(f"alan_exchange_status failed ({rc})")
+        return done.value, bad.value
+
+    def close(self):
+        if self._h is not None:
+            lib().alan_exchange_destroy(self._h)
+            self._h = None
 
 
 def dtype_code(dtype):

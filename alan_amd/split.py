@@ -11,6 +11,8 @@ log-sum-exp, because independent plate elements multiply (logpq.py:149-153).
 """
 import warnings
 
+import os
+
 import torch as t
 import torch.distributed as dist
 
@@ -170,6 +172,8 @@ class _AllReduceSum(t.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         ctx.world = dist.get_world_size(group)
+        if one_shot_takes(x, ctx.world):
+            return exchange_for(group).sum(x.contiguous())   # (one launch of the library; nothing of RCCL's in a capture)
         x = x.contiguous().clone()
         dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
         ALL_REDUCES.append((group, x.numel(), x.dtype))      # (what a captured sharded evaluation's graph may hold)
@@ -180,6 +184,52 @@ class _AllReduceSum(t.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g * ctx.world, None
+
+
+ONE_SHOT_EXCHANGE = os.environ.get("ALAN_AMD_ONE_SHOT", "0") == "1"
+"""The ranks' partials summed by the library's one-shot exchange (alan_exchange_sum: every rank writes its partial into
+every peer's inbox over xGMI and adds what arrived, one launch) instead of RCCL's all_reduce.  Off by default: written
+for the ranks of ONE node and tested with processes sharing one GPU -- the arithmetic and the protocol, not the fabric
+(no multi-GPU node in reach of this repository's tests); RCCL stays the transport until it has been timed on one."""
+
+ONE_SHOT_CAPACITY = int(os.environ.get("ALAN_AMD_ONE_SHOT_CAPACITY", str(1 << 16)))      # fp32 elements per partial
+
+_EXCHANGES = {}
+
+
+def one_shot_takes(x, world):
+    from . import native as N
+    return ONE_SHOT_EXCHANGE and x.is_cuda and x.dtype == t.float32 and 1 <= x.numel() <= ONE_SHOT_CAPACITY \
+        and 2 <= world <= N.EXCHANGE_MAX_RANKS
+
+
+def exchange_for(group=None):
+    """The group's exchange; the first call (every rank makes it together, outside any stream capture) allocates the
+    inboxes and carries their IPC handles between the ranks with the group's own all_gather_object."""
+    from . import native as N
+    key = id(group) if group is not None else None
+    ex = _EXCHANGES.get(key)
+    if ex is None:
+        if t.cuda.is_current_stream_capturing():
+            raise Exception("alan_amd: the one-shot exchange has to be set up before a stream capture: evaluate the "
+                            "sharded ELBO once eagerly first")
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def carry(mine):
+            got = [None] * world
+            dist.all_gather_object(got, mine, group=group)
+            return got
+        ex = N.Exchange(world, rank, ONE_SHOT_CAPACITY, carry)
+        dist.barrier(group=group)                         # (every rank has opened every inbox: deliveries may start)
+        _EXCHANGES[key] = ex
+    return ex
+
+
+def close_exchanges():
+    """Frees the inboxes (call it on every rank, after a barrier: a peer may still be writing otherwise)."""
+    for ex in _EXCHANGES.values():
+        ex.close()
+    _EXCHANGES.clear()
 
 
 GATHER_PARTIALS = False

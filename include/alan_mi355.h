@@ -390,6 +390,34 @@ int alan_chain_sample(const void *ms, int64_t T, int64_t K, int64_t sC, int64_t 
 int alan_chain_filter(const void *ms, int64_t C, int64_t T, int64_t K, int64_t sC, int64_t sT, int64_t sRow,
                       int64_t sCol, const void *init, int64_t N, void *alpha, void *stream);
 
+/* One-shot sum of the ranks' partial log-marginals (the collective of a sharded Split: logpq.py:149-153 evaluated by
+ * `world` ranks, one per GPU of a node, each over its own chunks of the plate).  Every rank writes its partial into a
+ * slot of every peer's inbox over xGMI, raises a flag there, waits (for a bounded time) for the peers' flags in its own
+ * inbox and adds the slots in rank order: ONE launch of `world` workgroups per exchange, the same bits on every rank,
+ * in place of RCCL's all-reduce.  The exchange's running number lives on the device, so a launch captured into a HIP
+ * graph advances it on every replay; every rank must issue the same sequence of exchanges.
+ *   alan_exchange_create   allocates this rank's inbox on the current device (the ONE place this library owns device
+ *                          memory: an inbox must be a whole allocation to be exported) and writes its HIP IPC handle
+ *                          (ALAN_EXCHANGE_HANDLE_BYTES) to handle_out; capacity = the largest n, in fp32 elements.
+ *                          Uncached device memory; the environment variable ALAN_EXCHANGE_ALLOC=plain asks for hipMalloc.
+ *   alan_exchange_connect  handles = the world handles, rank-major (the caller carries them between the processes, e.g.
+ *                          with torch.distributed.all_gather_object); opens the peers' inboxes.  Once.
+ *   alan_exchange_sum      out[0..n) = sum over ranks q = 0..world-1, in that order, of rank q's src[0..n); fp32, device
+ *                          pointers, enqueued on `stream`.  A peer that has not delivered within ALAN_EXCHANGE_SPIN_MS
+ *                          (environment, default 2000) ends the wait: out is filled with NaN and the exchange is marked
+ *                          failed (alan_exchange_status) -- no launch spins for ever.  Issue the first exchange only
+ *                          after every rank has connected (a host barrier).
+ *   alan_exchange_status   synchronous read-back: exchanges completed on this rank, and the number of the first one
+ *                          that timed out (0 = none).
+ *   alan_exchange_destroy  closes the peers' inboxes and frees this rank's (after the peers have stopped writing). */
+#define ALAN_EXCHANGE_MAX_RANKS 8
+#define ALAN_EXCHANGE_HANDLE_BYTES 64
+int alan_exchange_create(int32_t world, int32_t rank, int32_t capacity, unsigned char *handle_out, void **exchange);
+int alan_exchange_connect(void *exchange, const unsigned char *handles);
+int alan_exchange_sum(void *exchange, const void *src, void *out, int64_t n, void *stream);
+int alan_exchange_status(void *exchange, uint32_t *completed, uint32_t *failed_at);
+int alan_exchange_destroy(void *exchange);
+
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);
 const char *alan_build_target(void);

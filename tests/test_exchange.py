@@ -1,0 +1,70 @@
+"""The one-shot exchange (alan_exchange_*: the ranks' [K_parents...] partials of a sharded Split summed by one launch
+per rank, logpq.py:149-153 across ranks) with 2 and 3 processes sharing the one GPU over HIP IPC handles."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch as t
+import torch.multiprocessing as mp
+
+import exchange_worker
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, what):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "res")
+        mp.spawn(exchange_worker.run, args=(world, _free_port(), out, what), nprocs=world, join=True)
+        return [t.load(f"{out}.{r}") for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_shot_exchange_sums_in_rank_order_on_every_rank(world):
+    """Eight exchanges of different sizes (1 .. the capacity), then one captured launch replayed five times: every rank
+    ends with sum_q x_q added in rank order -- bit for bit --, nothing timed out, and the device-side running number
+    counts exactly the launches that ran (a captured launch does not run until it is replayed)."""
+    for r in _run(world, "direct"):
+        assert r["bad"] == 0, r
+        assert r["bitwise"] and r["worst"] == 0.0, r
+        assert r["replays"] == [True] * 5, r
+        assert r["done"] == 8 + 1 + 5, r
+
+
+@pytest.mark.gpu
+def test_sharded_split_through_the_one_shot_exchange():
+    """movielens K=10 (fp32), Split over the user plate sharded over two ranks: the ELBO with the partials summed by the
+    exchange == the same through gloo's all_reduce (two summands: the same bits) == this rank evaluating every chunk
+    alone; replayed as a HIP graph too; RWS gradients averaged over ranks == the unsharded ones."""
+    res = _run(2, "split")
+    for r in res:
+        assert r["bad"] == 0, r
+        assert r["one_shot"] == r["through_gloo"], r
+        assert all(g == r["one_shot"] for g in r["graphed"]), r
+        assert abs(r["one_shot"] - r["alone"]) <= 2e-6 * abs(r["alone"]), r
+        assert r["grad_err"] < 1e-3, r
+    assert res[0]["one_shot"] == res[1]["one_shot"]
+
+
+def test_exchange_refuses_bad_arguments_without_a_gpu():
+    """The entry points validate before touching the device (they are exported and bound: test_native_abi)."""
+    import ctypes as C
+    from alan_amd import native as N
+    L = N.lib()
+    h = C.c_void_p()
+    buf = C.create_string_buffer(N.EXCHANGE_HANDLE_BYTES)
+    assert L.alan_exchange_create(0, 0, 16, buf, C.byref(h)) == -1
+    assert L.alan_exchange_create(N.EXCHANGE_MAX_RANKS + 1, 0, 16, buf, C.byref(h)) == -1
+    assert L.alan_exchange_create(2, 2, 16, buf, C.byref(h)) == -1
+    assert L.alan_exchange_create(2, 0, 0, buf, C.byref(h)) == -1
+    assert L.alan_exchange_sum(None, None, None, 1, None) == -1
+    assert L.alan_exchange_connect(None, None) == -1
+    assert L.alan_exchange_destroy(None) == -1
