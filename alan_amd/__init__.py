@@ -14,9 +14,11 @@ Where a drop-in user sees something other than the reference (each with a switch
     fp64 log-sum-exp on the BASELINE configurations).  ``engine.FP64_SMALL_FACTORS = "exact"``.
   * ``Split(plate, size)`` evaluates a rank's chunks as one slice while every tensor that needs stays under
     ``split.MERGE_MAX_BYTES``; ``Split(..., merge=False)`` is the reference's per-chunk loop.
-  * ``Problem.sample`` draws the noise of all its Normal variables with ONE generator call (same distribution, other
-    particles than torch's variable-by-variable ``rsample`` under the same seed).  ``dist.BATCH_NOISE = False`` keeps
-    torch's particles; ``dist.BATCH_DRAWS = False`` issues every draw where the model meets it.
+  * ``Problem.sample`` draws the noise of all its Normal variables together, generated inside the launch that uses it
+    (Philox4x32-10 keyed by torch's generator: same distribution, reproducible under ``torch.manual_seed``, other
+    particles than torch's variable-by-variable ``rsample`` under the same seed).  ``dist.DEVICE_NOISE = False``: the
+    noise is torch's ``normal_`` (one call per batch); ``dist.BATCH_NOISE = False`` keeps torch's particles;
+    ``dist.BATCH_DRAWS = False`` issues every draw where the model meets it.
 """
 from .model import Plate, Group, Data
 from .timeseries import Timeseries

@@ -51,6 +51,16 @@ struct SmallDesc {
     int32_t *ring_counter;
     int32_t ring_n;
     int32_t presum_n, presum_stride;   // role ALAN_PRESUM: factor 0 is the sum of presum_n slices presum_stride apart (0: off)
+    int32_t noise_on;                  // alan_noise_t: factor 1 is generated (ALAN_MODE_AFFINE / ALAN_MODE_DOT)
+    uint64_t noise_off;
+};
+
+// What the problems of ONE launch share of alan_noise_t (a kernel argument of its own: eight SmallDescs fill the 4 KB)
+struct NoiseLaunch {
+    uint64_t seed;
+    const unsigned long long *cell;
+    unsigned long long *receipt, *advance;
+    uint32_t advance_by, pad_;
 };
 
 // Kernel argument of the linear-logits Bernoulli producer (ALAN_MODE_BERNOULLI_LINEAR): fp32, 32-bit offsets, at
@@ -83,6 +93,7 @@ struct SmallMultiT {
     uint32_t first_block[NP + 1];
     SmallDesc d[NP];
     LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
+    NoiseLaunch noise;
 };
 typedef SmallMultiT<SMALL_MULTI> SmallMulti;
 
@@ -142,6 +153,16 @@ struct EvPair {
     void *ring_slots = nullptr, *ring_counter = nullptr;
     int ring_n = 0;
 };
+inline NoiseLaunch noise_launch(const alan_noise_t *n, bool advance) {
+    NoiseLaunch r;
+    std::memset(&r, 0, sizeof(r));
+    if (n && n->on) {
+        r.seed = n->seed, r.cell = (const unsigned long long *)n->cell, r.receipt = (unsigned long long *)n->receipt;
+        r.advance = advance ? (unsigned long long *)n->advance : nullptr;
+        r.advance_by = n->advance_by;
+    }
+    return r;
+}
 int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, GroupLaunch &gl,
                float out_scale = 1.f);
 
@@ -155,7 +176,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
 int build_small(const Canon &c, const GroupDesc &gd, int mode, int compute_dtype, SmallDesc &sd);
 // `lin`: the LinDesc of the (at most one) problem whose mode[] entry is ALAN_MODE_BERNOULLI_LINEAR; its sd[] slot is unused
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
-                       const LinDesc *lin = nullptr);
+                       const LinDesc *lin = nullptr, const alan_noise_t *noise = nullptr, bool advance = false);
 // (its kernel argument alone; returns the number of workgroups the problems take together)
 template <int NP>
 inline uint32_t fill_small_multi(SmallMultiT<NP> &m, const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n,

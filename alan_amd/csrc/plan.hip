@@ -643,18 +643,37 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     bool have_lin = false;
     int mode[SMALL_MULTI], m = 0, lone = -1;
     std::memset(sd, 0, sizeof(sd));
+    if (n > 64) return ALAN_ERR_UNSUPPORTED;
+    // generated noise (alan_noise_t): every such problem must be of the small kind (found out before anything is launched),
+    // all of them name the same generator, and the last launch that holds one advances its counter
+    const alan_noise_t *nz = nullptr;
+    int last_noise = -1;
+    bool grp_noise = false, grp_last = false;
+    for (int i = 0; i < n; ++i) {
+        const alan_noise_t &z = descs[i]->noise;
+        if (!z.on) continue;
+        SmallDesc ts;
+        GroupLaunch tg;
+        int tm;
+        if (descs[i]->mode != ALAN_MODE_AFFINE && descs[i]->mode != ALAN_MODE_DOT) return ALAN_ERR_BAD_DESC;
+        if (!prepare_small(*descs[i], ts, tg, tm)) return ALAN_ERR_UNSUPPORTED;
+        if (nz && (nz->seed != z.seed || nz->cell != z.cell || nz->receipt != z.receipt || nz->advance != z.advance ||
+                   nz->advance_by != z.advance_by))
+            return ALAN_ERR_BAD_DESC;
+        nz = &z, last_noise = i;
+    }
     auto flush_small = [&]() -> int {
         int rc = ALAN_OK;
-        if (m >= 2)
-            rc = launch_small_multi(sd, gl, mode, m, stream, have_lin ? &lin : nullptr);
+        if (m >= 2 || (m == 1 && grp_noise))
+            rc = launch_small_multi(sd, gl, mode, m, stream, have_lin ? &lin : nullptr, grp_noise ? nz : nullptr, grp_last);
         else if (m == 1)
             rc = alan_reduce(descs[lone], nullptr, 0, stream_);
         m = 0;
         have_lin = false;
+        grp_noise = grp_last = false;
         return rc;
     };
     bool other[64];
-    if (n > 64) return ALAN_ERR_UNSUPPORTED;
     for (int i = 0; i < n; ++i) {
         if (descs[i]->mode == ALAN_MODE_BERNOULLI_LINEAR) {
             // one per multi launch (its argument has its own slot there); a second one goes out alone, below
@@ -677,6 +696,11 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
             }
         } else {
             other[i] = !prepare_small(*descs[i], sd[m], gl[m], mode[m]);
+            if (!other[i] && descs[i]->noise.on) {
+                sd[m].noise_on = 1, sd[m].noise_off = descs[i]->noise.offset;
+                grp_noise = true;
+                if (i == last_noise) grp_last = true;
+            }
         }
         if (other[i]) continue;
         lone = i;
@@ -806,7 +830,15 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
         return lin_prepare(*d, ld, gl);
     }
     uint32_t keep, red, plate;
-    return classify(*d, keep, red, plate);
+    const int rc = classify(*d, keep, red, plate);
+    if (rc == ALAN_OK && d->noise.on) {                  // generated noise: the small kernel or nothing
+        SmallDesc sd;
+        GroupLaunch gl;
+        int mode;
+        if (d->mode != ALAN_MODE_AFFINE && d->mode != ALAN_MODE_DOT) return ALAN_ERR_BAD_DESC;
+        return prepare_small(*d, sd, gl, mode) ? ALAN_OK : ALAN_ERR_UNSUPPORTED;
+    }
+    return rc;
 }
 
 extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
@@ -881,6 +913,15 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     uint32_t keep, red, plate;
     int rc = classify(*d, keep, red, plate);
     if (rc != ALAN_OK) return rc;
+    if (d->noise.on) {                                   // generated noise: the small kernel or nothing
+        SmallDesc sd;
+        GroupLaunch gl;
+        int mode;
+        if (d->mode != ALAN_MODE_AFFINE && d->mode != ALAN_MODE_DOT) return ALAN_ERR_BAD_DESC;
+        if (d->ring_n || !prepare_small(*d, sd, gl, mode)) return ALAN_ERR_UNSUPPORTED;
+        sd.noise_on = 1, sd.noise_off = d->noise.offset;
+        return launch_small_multi(&sd, &gl, &mode, 1, stream, nullptr, &d->noise, true);
+    }
     EvPair ev;
     ev.start = (hipEvent_t)d->ev_start;
     ev.stop = (hipEvent_t)d->ev_stop;
@@ -993,5 +1034,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 10; }
+extern "C" int alan_abi_version(void) { return 11; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

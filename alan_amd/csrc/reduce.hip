@@ -327,11 +327,12 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
 }
 
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
-                       const LinDesc *lin) {
+                       const LinDesc *lin, const alan_noise_t *noise, bool advance) {
     if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;
     SmallMulti m;
     const uint32_t blocks = fill_small_multi(m, sd, gl, mode, n, lin);
     if (blocks == 0) return ALAN_OK;
+    m.noise = noise_launch(noise, advance);
     hipLaunchKernelGGL(reduce_small_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }

@@ -20,6 +20,48 @@ __device__ __forceinline__ void small_store(float *p, float v) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Generated noise (alan_noise_t): Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's own CUDA /
+// HIP sampling kernels use) keyed by the seed, counter = the element's index / 4; its four 32-bit words make four
+// standard normals by Box-Muller (u in (0, 1]: x 2^-32 + 2^-33, as curand's uniform), element i takes the (i & 3)th.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        // (one 32 x 32 -> 64 multiply per product: v_mad_u64_u32, quarter rate like each of a mul_hi / mul_lo pair)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c0 = hi1 ^ c1 ^ k0, c1 = lo1, c2 = hi0 ^ c3 ^ k1, c3 = lo0;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    r[0] = c0, r[1] = c1, r[2] = c2, r[3] = c3;
+}
+
+__device__ __forceinline__ float noise_at(const uint64_t seed, const uint64_t i) {
+    uint32_t r[4];
+    const uint64_t c = i >> 2;
+    philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0x414c414eu, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int lane = (int)(i & 3u);
+    const uint32_t a = lane & 2 ? r[2] : r[0], b = lane & 2 ? r[3] : r[1];
+    const float u1 = (float)a * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+    const float u2 = (float)b * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1)
+    // (v_sin_f32 / v_cos_f32 take their argument in turns)
+    return rad * (lane & 1 ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
+}
+
+// Behind a launch's problems: its first workgroup leaves the receipt and hands the generator on -- {counter + advance_by,
+// seed} written to the slot whose ADDRESS the word `advance` holds: never the slot this launch reads (its other
+// workgroups may not have read it yet), so nothing has to wait for anything.
+__device__ __forceinline__ void noise_finish(const NoiseLaunch &n, const uint64_t cell_value, const uint64_t seed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (n.receipt) n.receipt[0] = cell_value, n.receipt[1] = seed;
+    if (n.advance) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(*n.advance);
+        dst[0] = cell_value + n.advance_by, dst[1] = seed;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // One element of the reduce index: the mode's term from the loaded factor values (shared by both kernels).
 template <typename T, int MODE>
 __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T wv, const float (&scale)[MAXF],
@@ -131,8 +173,12 @@ __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
 // NW: waves of the workgroup (BLOCK: all of them on one output); UNR elements of the reduce index per thread and round, PF
 // slices of a partial-sum factor (role PRESUM) per element and round -- UNR x PF loads in flight.
 template <int MODE, bool BLOCK, bool WT = false, int NW = 4, int UNR = 4, int PF = 8>
-__device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id) {
+__device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id,
+                                           const uint64_t noise_seed = 0, const uint64_t noise_cell = 0) {
     typedef float T;
+    constexpr bool NOISY = MODE == ALAN_MODE_AFFINE || MODE == ALAN_MODE_DOT;
+    const bool noise = NOISY && d.noise_on != 0;                       // (uniform)
+    const uint64_t noise_base = d.noise_off + noise_cell;
     const uint32_t G = BLOCK ? 64u * NW : (1u << logG);
     uint32_t grp, gl;
     if (BLOCK) {
@@ -187,6 +233,9 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
             // unused factor slots alias factor 0 with zero strides: the load is harmless and never used
 #pragma unroll
             for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];
+            if (NOISY) {
+                if (noise) val[u][1] = noise_at(noise_seed, noise_base + (uint64_t)(int64_t)off[1]);
+            }
             wv[u] = MODE == ALAN_MODE_WEXPSUM ? d.w[woff] : 0.f;
             off0[u] = off[0];
         }
@@ -388,11 +437,12 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
 }
 
 template <int MODE, bool WT = false>
-__device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool block, uint32_t bid) {
+__device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool block, uint32_t bid,
+                                             const uint64_t noise_seed = 0, const uint64_t noise_cell = 0) {
     if (block)
-        small_body<MODE, true, WT>(d, 8, bid);
+        small_body<MODE, true, WT>(d, 8, bid, noise_seed, noise_cell);
     else
-        small_body<MODE, false, WT>(d, logG, bid);
+        small_body<MODE, false, WT>(d, logG, bid, noise_seed, noise_cell);
 }
 
 // Virtual workgroup `vb` of a SmallMulti that sits in the kernel-argument segment at byte offset `arg_off` (its
@@ -410,6 +460,8 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
     const SmallDesc &d = *reinterpret_cast<const SmallDesc *>(base + offsetof(SmallMulti, d) + (size_t)p * sizeof(SmallDesc));
     const bool block = m.block[p] != 0;
     const int logG = m.logG[p];
+    const NoiseLaunch &nz = *reinterpret_cast<const NoiseLaunch *>(base + offsetof(SmallMulti, noise));
+    const uint64_t cellv = nz.cell ? nz.cell[0] : 0ull, nseed = nz.cell ? nz.cell[1] : nz.seed;     // (the cell: {counter, seed})
     switch (m.mode[p]) {
         case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE, WT>(d, logG, block, bid); break;
         case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM, WT>(d, logG, block, bid); break;
@@ -418,8 +470,8 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI, WT>(d, logG, block, bid); break;
         case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD, WT>(d, logG, block, bid); break;
         case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM, WT>(d, logG, block, bid); break;   // (per-factor backward launches)
-        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_AFFINE: small_either<ALAN_MODE_AFFINE, WT>(d, logG, block, bid); break;
+        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT, WT>(d, logG, block, bid, nseed, cellv); break;
+        case ALAN_MODE_AFFINE: small_either<ALAN_MODE_AFFINE, WT>(d, logG, block, bid, nseed, cellv); break;
         case ALAN_MODE_BERNOULLI_LINEAR: {
             const LinDesc &ld = *reinterpret_cast<const LinDesc *>(base + offsetof(SmallMulti, lin));
             if (block)
@@ -430,6 +482,7 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         }
         default: break;
     }
+    if (nz.receipt || nz.advance) noise_finish(nz, cellv, nseed);
 }
 
 }  // namespace alan

@@ -340,12 +340,36 @@ small library launches (the sums of G and of G * eps over the broadcast dims, al
 together) instead of the five or six torch kernels autograd derives from exp, addcmul and the broadcasts."""
 
 
-def _sum_to(G, other, shape, log_third=None, plus=None, G2=None):
+def _sum_to(G, other, shape, log_third=None, plus=None, G2=None, noise=None):
     """sum of G (or of G * other, or of G * other * exp(log_third) [+ c * plus[0] with plus = (tensor broadcastable to G,
     c)]) over the dims along which a parameter of shape ``shape`` was broadcast to G's.  ``G2`` (fp32 on the GPU, with
-    log_third where other is given): G is G + G2, added inside the launch."""
+    log_third where other is given): G is G + G2, added inside the launch.  ``noise``: ``other`` is the placeholder of
+    noise the launch generates (_NoiseSpec.backward_args)."""
     pad = G.ndim - len(shape)
     keep = [i for i in range(G.ndim) if i >= pad and shape[i - pad] != 1]
+    if noise is not None:
+        from . import engine as E
+        from . import native as N
+        axes = tuple(range(G.ndim))
+        facs = [(G, axes), (other.expand_as(G), axes)]
+        scales = [1.0, 1.0]
+        if log_third is not None or plus is not None or G2 is not None:
+            facs.append(((log_third if log_third is not None else G).expand_as(G), axes))
+            scales.append(2.0 if log_third is not None else 1.0)
+            assert log_third is not None
+        if plus is not None or G2 is not None:
+            facs.append(((plus[0] if plus is not None else G).expand_as(G), axes))
+            scales.append(float(plus[1]) if plus is not None else 0.0)
+        if G2 is not None:
+            facs.append((G2, axes))
+            scales.append(1.0)
+        with N.may_defer():
+            out = E._produce(N.MODE_DOT, facs, tuple(keep), scales=scales, noise=noise)
+        if out is not None:
+            return out.reshape(shape)
+        # (the library does not take this reduction with generated noise -- more than two summed dims that do not merge:
+        # the noise is written out by a launch that does, x = 0 + eps * 1 as the forward drew it, and read from memory)
+        other = _materialise_noise(other, noise)
     if G2 is not None and other is None:
         from . import engine as E
         from . import native as N
@@ -437,8 +461,9 @@ BATCH_DRAWS = os.environ.get("ALAN_AMD_BATCH_DRAWS", "1") != "0"
 collected and issued together -- the affine maps x = loc + eps * exp(raw) of all of them as ONE library launch
 (alan_reduce_batch of ALAN_MODE_AFFINE problems, written straight in the sample's layout) behind the noise, and, under
 autograd, one node whose backward issues every variable's two reductions together (d loc = sum G, d raw = sum G * eps *
-exp(raw): no torch multiply, no exp).  A movielens VI iteration: 2 + 3 launches for the draws where there were 9, 2 for
-their backward where there were 6.  False: a draw is issued where the model meets it."""
+exp(raw): no torch multiply, no exp).  A movielens VI iteration: 2 launches for the draws (their noise generated inside:
+DEVICE_NOISE) where there were 9, 2 for their backward where there were 6.  False: a draw is issued where the model
+meets it."""
 
 BATCH_NOISE = os.environ.get("ALAN_AMD_BATCH_NOISE", "1") != "0"
 """The noise of a batch of draws from ONE normal_ call over one buffer (one kernel instead of one per variable).  The
@@ -464,12 +489,19 @@ class _DrawBatch:
             return
         for dev, dt in {(j[0].device, j[0].dtype) for j in jobs}:
             mine = [j for j in jobs if j[0].device == dev and j[0].dtype == dt]
+            specs = [None] * len(mine)
             with t.no_grad():
                 if BATCH_NOISE:
-                    flat = t.empty(sum(j[3].numel() for j in mine), dtype=dt, device=dev).normal_()
+                    total = sum(j[3].numel() for j in mine)
+                    src = _noise_source(dev, dt, total, any(j[6] for j in mine)) if DEVICE_NOISE else None
+                    flat = t.empty(total, dtype=dt, device=dev)
+                    if src is None:
+                        flat.normal_()
                     eps, o = [], 0
-                    for j in mine:
+                    for k, j in enumerate(mine):
                         eps.append(flat[o:o + j[3].numel()].view(j[3]))
+                        if src is not None:                # (flat stays unwritten: a placeholder whose offsets number the noise)
+                            specs[k] = _NoiseSpec(src, o)
                         o += j[3].numel()
                 else:
                     eps = [t.empty(j[3], dtype=dt, device=dev).normal_() for j in mine]
@@ -477,7 +509,7 @@ class _DrawBatch:
             rp = [k for k, j in enumerate(mine) if j[6]]
             outs = [None] * len(mine)
             if rp:
-                meta = tuple((mine[k][2], eps[k], mine[k][7]) for k in rp)
+                meta = tuple((mine[k][2], eps[k], mine[k][7], specs[k]) for k in rp)
                 res = _ReparamNormalBatch.apply(meta, *[x for k in rp for x in (mine[k][0], mine[k][1])])
                 for i, k in enumerate(rp):
                     outs[k] = res[i]
@@ -486,7 +518,7 @@ class _DrawBatch:
             rest = [k for k in range(len(mine)) if not mine[k][6]]
             if rest:
                 with t.no_grad():
-                    res = _affine_batch([(mine[k][0], mine[k][1], mine[k][2], eps[k]) for k in rest])
+                    res = _affine_batch([(mine[k][0], mine[k][1], mine[k][2], eps[k], specs[k]) for k in rest])
                 for k, x in zip(rest, res):
                     outs[k] = x
             for j, x in zip(mine, outs):
@@ -498,16 +530,98 @@ def _affine_batch(jobs):
     GPU all of them as one multi-problem launch (ALAN_MODE_AFFINE)."""
     from . import engine as E
     from . import native as N
-    if not all(e.is_cuda and e.dtype == t.float32 and l.dtype == s_.dtype == t.float32 for l, s_, _, e in jobs):
-        return [t.addcmul(l, e, s_.exp() if lg else s_) for l, s_, lg, e in jobs]
+    if not all(e.is_cuda and e.dtype == t.float32 and l.dtype == s_.dtype == t.float32 for l, s_, _, e, _ in jobs):
+        assert all(z is None for *_, z in jobs)
+        return [t.addcmul(l, e, s_.exp() if lg else s_) for l, s_, lg, e, _ in jobs]
     outs = []
     with N.deferring(), N.may_defer():
-        for l, s_, lg, e in jobs:
+        for i, (l, s_, lg, e, z) in enumerate(jobs):
             axes = tuple(range(e.ndim))
-            outs.append(E._produce(N.MODE_AFFINE, [(l.expand_as(e), axes), (e, axes), (s_.expand_as(e), axes)], axes,
-                                   scales=[1.0, 1.0, 2.0 if lg else 1.0]))
+            args = [(l.expand_as(e), axes), (e, axes), (s_.expand_as(e), axes)]
+            # (the last job with generated noise advances a captured graph's counter: the library finds it by itself)
+            x = E._produce(N.MODE_AFFINE, args, axes, scales=[1.0, 1.0, 2.0 if lg else 1.0],
+                           noise=z.forward_args() if z is not None else None)
+            if x is None:                                 # (not a problem the library generates noise for: torch's, in memory)
+                z.declined = True
+                e.normal_()
+                x = E._produce(N.MODE_AFFINE, args, axes, scales=[1.0, 1.0, 2.0 if lg else 1.0])
+            outs.append(x)
     N.flush()                                             # (inside someone else's deferring() the exit above issues nothing)
     return outs
+
+
+DEVICE_NOISE = os.environ.get("ALAN_AMD_DEVICE_NOISE", "1") != "0"
+"""The standard-normal noise of a batch of draws generated INSIDE the launch that uses it (alan_noise_t: Philox4x32-10 +
+Box-Muller keyed by torch's generator -- its seed, its offset, which the draw advances as torch's own kernels would) and,
+for a reparameterised sample, again inside the launch of its gradient: no noise kernel and no noise in memory.  In a
+graph captured by GraphedStep / GraphedEval the counter lives on the device (native.GraphNoise): no generator-state fills
+in front of a replay either.  Same distribution as torch's normal_, different particles for a given seed (as BATCH_NOISE).
+False: the noise is torch's, drawn into memory."""
+
+
+class _NoiseSource:
+    """Where one batch of draws gets its noise: (seed, offset) by value from torch's generator, or a captured graph's
+    device-side state."""
+    __slots__ = ("seed", "offset", "cell", "receipt", "advance", "advance_by")
+
+
+def _noise_source(dev, dtype, total, reparam):
+    from . import native as N
+    if dtype != t.float32 or dev.type != "cuda" or total < 1:
+        return None
+    inc = 4 * ((total + 3) // 4)
+    src = _NoiseSource()
+    src.advance_by = inc
+    if t.cuda.is_current_stream_capturing():
+        st = N.graph_noise(dev)
+        if st is None:                                    # (someone else's capture: torch's generator knows how to be captured)
+            return None
+        slot = st.next_launch()
+        if slot is None:
+            return None
+        src.seed, src.offset, (src.cell, src.advance) = 0, 0, slot
+        src.receipt = t.empty(2, dtype=t.int64, device=dev) if reparam else None
+        st.per_replay += inc
+        return src
+    gen = t.cuda.default_generators[dev.index if dev.index is not None else t.cuda.current_device()]
+    src.seed, src.offset, src.cell, src.receipt, src.advance = gen.initial_seed(), gen.get_offset(), None, None, None
+    gen.set_offset(src.offset + inc)
+    return src
+
+
+class _NoiseSpec:
+    """One variable's share of a batch's noise: the elements of its placeholder, numbered from ``base``."""
+    __slots__ = ("src", "base", "declined")
+
+    def __init__(self, src, base):
+        self.src, self.base, self.declined = src, base, False
+
+    def forward_args(self):
+        s = self.src
+        return (s.seed, s.offset + self.base, s.cell, s.receipt, s.advance, s.advance_by)
+
+    def backward_args(self):
+        s = self.src
+        if self.declined:
+            return None
+        if s.cell is not None:                            # (replayed: the forward's receipt says which numbers it used)
+            return (0, self.base, s.receipt, None, None, 0)
+        return (s.seed, s.offset + self.base, None, None, None, 0)
+
+
+def _materialise_noise(placeholder, noise):
+    """The noise ``noise`` names, written into its placeholder's memory (a launch x = 0 + eps * 1)."""
+    from . import engine as E
+    from . import native as N
+    axes = tuple(range(placeholder.ndim))
+    zero = t.zeros((), dtype=placeholder.dtype, device=placeholder.device)
+    one = t.ones((), dtype=placeholder.dtype, device=placeholder.device)
+    out = E._produce(N.MODE_AFFINE, [(zero.expand_as(placeholder), axes), (placeholder, axes),
+                                     (one.expand_as(placeholder), axes)], axes, scales=[1.0, 1.0, 1.0], noise=noise)
+    if out is None:
+        raise N.NativeError("alan_amd: the library declined to regenerate a draw's noise (it generated it in the forward)")
+    N.flush()
+    return out
 
 
 class _ReparamNormalBatch(t.autograd.Function):
@@ -518,13 +632,13 @@ class _ReparamNormalBatch(t.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *params):
-        jobs = [(params[2 * i], params[2 * i + 1], meta[i][0], meta[i][1]) for i in range(len(meta))]
+        jobs = [(params[2 * i], params[2 * i + 1], meta[i][0], meta[i][1], meta[i][3]) for i in range(len(meta))]
         outs = _affine_batch(jobs)
         ctx.meta = meta
         for m in meta:                                     # (this node will add log q's share of d raw itself: OWN_LOGQ_FOLD)
             if m[2] is not None and m[0]:
                 m[2]["node"] = True
-        ctx.shapes = [(tuple(l.shape), tuple(s_.shape)) for l, s_, _, _ in jobs]
+        ctx.shapes = [(tuple(l.shape), tuple(s_.shape)) for l, s_, _, _, _ in jobs]
         ctx.save_for_backward(*[j[1] for j in jobs])
         # every sample twice: the second output aliases the first (dims.ReparamPT.x2) -- two consumers, two gradient slots
         return tuple(outs) + tuple(o.view_as(o) for o in outs)
@@ -536,7 +650,7 @@ class _ReparamNormalBatch(t.autograd.Function):
         grads = [None]
         with N.deferring():
             n = len(ctx.meta)
-            for i, ((is_log, eps, holder), G) in enumerate(zip(ctx.meta, Gs[:n])):
+            for i, ((is_log, eps, holder, spec), G) in enumerate(zip(ctx.meta, Gs[:n])):
                 gl = gs = None
                 G2 = Gs[n + i]                            # (the gradient that arrived through the sample's second output)
                 if G is None:
@@ -560,7 +674,7 @@ class _ReparamNormalBatch(t.autograd.Function):
                             Gq, coef = own
                             plus = (Gq.reshape(tuple(Gq.shape) + (1,) * (G.ndim - Gq.ndim)), coef)
                         gs = _sum_to(G, eps, ctx.shapes[i][1], log_third=ctx.saved_tensors[i] if is_log else None, plus=plus,
-                                     G2=G2)
+                                     G2=G2, noise=spec.backward_args() if spec is not None else None)
                 grads += [gl, gs]
         return tuple(grads)
 

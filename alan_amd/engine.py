@@ -136,7 +136,7 @@ def _empty(shape, dtype, device):
 
 
 def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=None, add_const=0.0,
-            scales=None, out_scale=1.0, ring=None):
+            scales=None, out_scale=1.0, ring=None, noise=None):
     space = list(sizes)
     if len(space) > N.MAX_DIMS:
         raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
@@ -172,7 +172,16 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
         algo += weight[0].numel() * weight[0].element_size()
     if ring is not None:
         desc.ring_slots, desc.ring_counter, desc.ring_n = ring.table.data_ptr(), ring.counter.data_ptr(), ring.n
-    return N.run_reduce(desc, device, algo, keepalive=([x for x, _ in factors], out, weight, lse_out))
+    if noise is not None:
+        # factor 1 is generated inside the launch (alan_noise_t); noise = (seed, offset, cell, receipt, advance, advance_by),
+        # the three in the middle int64 device tensors or None
+        seed, offset, cell, receipt, advance, advance_by = noise
+        z = desc.noise
+        z.on, z.seed, z.offset, z.advance_by = 1, seed, offset, advance_by
+        z.cell = cell.data_ptr() if cell is not None else None
+        z.receipt = receipt.data_ptr() if receipt is not None else None
+        z.advance = advance.data_ptr() if advance is not None else None
+    return N.run_reduce(desc, device, algo, keepalive=([x for x, _ in factors], out, weight, lse_out, noise))
 
 
 def _result_dtype(tensors):
@@ -419,9 +428,11 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0, ring=None, pres
 
 
 # --------------------------------------------------------------------------- fused factor producer
-def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None):
+def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None, noise=None):
     """One producer launch: ``args`` are (tensor, leading first-class dims) pairs whose trailing positional
-    dims are right-aligned; every dim not in ``out_dims`` is summed out; out = affine[0] * sum + affine[1]."""
+    dims are right-aligned; every dim not in ``out_dims`` is summed out; out = affine[0] * sum + affine[1].
+    ``noise`` (modes AFFINE / DOT): the second argument is standard-normal noise generated inside the launch (_launch);
+    None is returned -- nothing launched -- when the library does not take such a problem."""
     tok = _Tokens()
     npos = max(x.ndim - len(d) for x, d in args)
     factors = []
@@ -434,8 +445,10 @@ def _produce(mode, args, out_dims, affine=(1.0, 0.0), scales=None):
     roles = {d: (N.KEEP if d in odims else N.REDUCE) for d in sizes}
     dtype = _result_dtype([x for x, _ in factors])
     out = _empty([sizes[d] for d in odims], dtype, args[0][0].device)
-    _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]),
-            scales=scales)
+    ok = _launch(mode, factors, sizes, roles, out, odims, out_scale=float(affine[0]), add_const=float(affine[1]),
+                 scales=scales, noise=noise)
+    if noise is not None and not ok:
+        return None
     return out
 
 

@@ -49,6 +49,11 @@ class Tensor(C.Structure):
     ]
 
 
+class Noise(C.Structure):
+    _fields_ = [("on", C.c_int32), ("advance_by", C.c_uint32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("cell", C.c_void_p), ("receipt", C.c_void_p), ("advance", C.c_void_p)]
+
+
 class ReduceDesc(C.Structure):
     _fields_ = [
         ("mode", C.c_int32),
@@ -66,6 +71,7 @@ class ReduceDesc(C.Structure):
         ("ring_slots", C.c_void_p),
         ("ring_counter", C.c_void_p),
         ("ring_n", C.c_int32),
+        ("noise", Noise),
     ]
 
 
@@ -414,6 +420,73 @@ def own_chain_state(device):
         _CHAIN_STATE_FOR_CAPTURE[0] = saved
 
 
+class GraphNoise:
+    """The generator state of ONE captured graph whose launches generate their noise (alan_noise_t.cell): a ring of
+    {counter, seed} slots on the device, one per captured launch that draws; each such launch reads its own slot and
+    writes the next one's (the last writes the first's: the ring is closed when the capture has ended), so every replay
+    draws fresh noise with no kernel in front of it and nothing inside it waiting.  Kept in step with torch's generator
+    from the host: before a replay the first slot is rewritten if the generator was re-seeded or used by anyone else since
+    the last one (a 16-byte copy, otherwise nothing), and the generator's offset is moved past what the replay will
+    consume -- the replays draw what the same iterations launched one by one would."""
+    MAX_LAUNCHES = 64
+
+    def __init__(self, device):
+        self.device = device
+        self.state = t.zeros(3 * self.MAX_LAUNCHES, dtype=t.int64, device=device)     # slots [MAX][2], then the ring's addresses
+        self.n = 0                   # captured launches that draw
+        self.per_replay = 0          # counter increments of one replay (summed while capturing)
+        self._expect = None
+
+    def next_launch(self):
+        """(cell, advance) of the next captured launch that draws, or None when the ring is full."""
+        if self.n >= self.MAX_LAUNCHES:
+            return None
+        j, self.n = self.n, self.n + 1
+        return self.state[2 * j:2 * j + 2], self.state[2 * self.MAX_LAUNCHES + j:2 * self.MAX_LAUNCHES + j + 1]
+
+    def close(self):
+        """After the capture: launch j hands on to slot j + 1, the last one to slot 0."""
+        if self.n:
+            base = self.state.data_ptr()
+            ring = [base + 16 * ((j + 1) % self.n) for j in range(self.n)]
+            self.state[2 * self.MAX_LAUNCHES:2 * self.MAX_LAUNCHES + self.n].copy_(t.tensor(ring, dtype=t.int64))
+
+    def before_replay(self):
+        if not self.per_replay:
+            return
+        gen = t.cuda.default_generators[self.device.index if self.device.index is not None else t.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        if (seed, off) != self._expect:
+            self.state[0:2].copy_(t.tensor([off, seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=t.int64))
+        gen.set_offset(off + self.per_replay)
+        self._expect = (seed, off + self.per_replay)
+
+
+_GRAPH_NOISE = [None]
+
+
+def graph_noise(device):
+    """The state of the graph being captured (own_graph_noise), or None."""
+    st = _GRAPH_NOISE[0]
+    if st is None or st.device.type != device.type:
+        return None
+    cur = t.cuda.current_device()
+    same = (st.device.index if st.device.index is not None else cur) == (device.index if device.index is not None else cur)
+    return st if same else None
+
+
+@contextlib.contextmanager
+def own_graph_noise(device):
+    """Around the capture of one graph that draws samples: its launches take their noise from a state of its own."""
+    saved, _GRAPH_NOISE[0] = _GRAPH_NOISE[0], GraphNoise(device)
+    mine = _GRAPH_NOISE[0]
+    try:
+        yield mine
+    finally:
+        _GRAPH_NOISE[0] = saved
+    mine.close()                                         # (the capture has ended -- the context managers nest that way)
+
+
 def fused_pending():
     return _Q.fused is not None or _Q.chain is not None
 
@@ -561,8 +634,11 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     L = lib()
     presum = any(desc.role[i] == PRESUM for i in range(desc.ndim))
     lin_grad = desc.mode == MODE_BERNOULLI_LINEAR_GRAD
-    if (desc.mode == MODE_BERNOULLI_LINEAR or presum or lin_grad) and L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
+    if (desc.mode == MODE_BERNOULLI_LINEAR or presum or lin_grad or desc.noise.on) and \
+            L.alan_reduce_check(C.byref(desc)) == ERR_UNSUPPORTED:
         return False
+    if desc.noise.on and _Q.pending and any(d.noise.on and _noise_key(d) != _noise_key(desc) for d, _, _ in _Q.pending):
+        flush()                                     # (one generator per alan_reduce_batch call)
     if (DEFER_SMALL_LAUNCHES and not presum and not lin_grad and _Q.depth[0] and _Q.depth[1] and _TIMER[0] is None and not t.is_grad_enabled()
             and not desc.ring_n
             and L.alan_reduce_workspace_bytes(C.byref(desc)) == 0
@@ -580,7 +656,7 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
             L.alan_reduce_workspace_bytes(C.byref(desc)) == 0 and _try_tail(desc, device, keepalive):
         return True
     flush()
-    if _TIMER[0] is not None:
+    if _TIMER[0] is not None and not desc.noise.on:     # (a launch that generates noise carries no timing events)
         _TIMER[0].attach(desc, algo_bytes)
     nbytes = L.alan_reduce_workspace_bytes(C.byref(desc))
     ws = t.empty(nbytes, dtype=t.uint8, device=device) if nbytes else None
@@ -593,6 +669,11 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
 
 
 ERR_UNSUPPORTED = -2
+
+
+def _noise_key(desc):
+    z = desc.noise
+    return (z.seed, z.cell, z.receipt, z.advance, z.advance_by)
 
 
 def run_reduce_backward(desc, device):

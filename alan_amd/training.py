@@ -176,8 +176,10 @@ class GraphedStep:
         # Capture on the SAME stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it
         # was first used on and autograd runs it there; a different capture stream would put the gradient
         # accumulation on a parallel branch of the graph (PyTorch warns "AccumulateGrad node's stream does not match").
-        with t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
-                          capture_error_mode="thread_local"):
+        from . import native as N
+        with N.own_graph_noise(problem.device) as self.noise, \
+                t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
+                             capture_error_mode="thread_local"):
             self.elbo = self._iteration()
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedStep", allow_memset_nodes)
 
@@ -195,6 +197,7 @@ class GraphedStep:
     def __call__(self):
         """Replay one iteration; returns a COPY of the ELBO (the graph's own output buffer is overwritten by the next
         replay, so ``[step() for _ in range(n)]`` holds n different values)."""
+        self.noise.before_replay()
         self.graph.replay()
         return self.elbo.clone()
 
@@ -202,8 +205,9 @@ class GraphedStep:
 class GraphedEval:
     """``ev = GraphedEval(problem, K); elbo = ev()``: ``problem.sample(K).elbo_nograd()`` with FRESH particles on every
     call -- the quantity the reference's runner times per iteration (examples/basic_runner.py:86-97) -- captured once
-    as a HIP graph: sampling kernels (the generator's Philox state is registered with the graph), log-prob producers
-    and the contraction all replay on the device."""
+    as a HIP graph: the draws (their noise generated inside the launches from a counter that lives on the device:
+    native.GraphNoise, kept in step with torch's generator), log-prob producers and the contraction all replay on the
+    device."""
 
     def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3, ring=True):
         if problem.device.type != "cuda":
@@ -228,7 +232,8 @@ class GraphedEval:
             if self.ring is not None:
                 self.ring.taken = 0
             self.graph = t.cuda.CUDAGraph(keep_graph=True)
-            with t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            with N.own_graph_noise(problem.device) as self.noise, \
+                    t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.elbo = self._iteration()
         finally:
             own.__exit__(None, None, None)
@@ -248,6 +253,7 @@ class GraphedEval:
     def __call__(self):
         """Replay; returns this replay's own ELBO tensor (a result-ring slot, or a copy of the graph's output buffer:
         see GraphedStep.__call__)."""
+        self.noise.before_replay()
         if self.ring is None:
             self.graph.replay()
             return self.elbo.clone()

@@ -129,6 +129,36 @@ typedef struct {
     int64_t stride[ALAN_MAX_DIMS];    /* element stride per dim of the space; 0 = broadcast */
 } alan_tensor_t;
 
+/* Standard-normal noise generated inside the launch instead of read from memory (ALAN_MODE_AFFINE / ALAN_MODE_DOT only:
+ * the draws x = loc + eps * scale of Problem.sample, TorchDimDist.py:88-125, and the reparameterised gradient's
+ * sum G * eps * scale).  With on != 0, factor 1 of the problem is VIRTUAL: its strides place every element at an offset
+ * as usual, nothing is loaded, and the element at offset o is
+ *     eps(o) = Box-Muller(Philox4x32-10(key = seed, counter = (i >> 2, 0x414c414e, 0)))[i & 3],  i = offset + counter + o
+ * -- a pure function of (seed, i): the backward of a draw regenerates the noise the forward used from the same numbers.
+ * factor[1].data must still point at valid device memory (it is not read through).
+ *   cell     optional device uint64[2] = {counter, seed}: generator state that lives on the device, so that a launch
+ *            replayed from a HIP graph draws fresh noise every replay (and can be re-seeded between replays).  Given:
+ *            counter and seed are read from it and the `seed` field is ignored.  NULL: counter = 0, seed = `seed`.
+ *            The launch only reads it;
+ *   receipt  optional device uint64[2]: receives the counter and the seed this launch used (what a later launch of the
+ *            same replay -- the backward -- passes as its cell);
+ *   advance  optional device uint64 holding the ADDRESS of a uint64[2]: that slot receives {counter + advance_by, seed}
+ *            -- the cell of the NEXT launch that draws (of the first one of the next replay, for the last).  It must not
+ *            be this launch's own cell: workgroups of the launch may still be reading that (which is why the state is
+ *            handed on from slot to slot instead of advanced in place -- nothing waits for anything).  The address is
+ *            read on the device, so the caller can close the ring of slots after a capture has ended.  In
+ *            alan_reduce_batch every problem with noise must name the same seed / cell / receipt / advance; the batch's
+ *            last launch that holds such a problem does the handing on.
+ * ALAN_ERR_UNSUPPORTED (nothing enqueued; alan_reduce_check says so beforehand) when the problem does not take the
+ * small single-launch kernel: the caller then draws the noise itself. */
+typedef struct {
+    int32_t on;
+    uint32_t advance_by;
+    uint64_t seed, offset;
+    const void *cell;
+    void *receipt, *advance;
+} alan_noise_t;
+
 typedef struct {
     int32_t mode;                         /* alan_mode_t */
     int32_t ndim;                         /* <= ALAN_MAX_DIMS */
@@ -152,6 +182,7 @@ typedef struct {
      * single-workgroup launch. */
     void *ring_slots, *ring_counter;
     int32_t ring_n;
+    alan_noise_t noise;                   /* on = 0: off */
 } alan_reduce_desc_t;
 
 /* Bytes of scratch alan_reduce() needs for this descriptor (0 is possible). */

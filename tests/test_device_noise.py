@@ -1,0 +1,204 @@
+"""Noise generated inside the launches that use it (alan_noise_t, dist.DEVICE_NOISE): the draws x = loc + eps * scale of
+Problem.sample (TorchDimDist.py:88-125) and the reparameterised gradient's sum G * eps * scale."""
+import math
+
+import numpy as np
+import pytest
+import torch as t
+
+import alan_amd as alan
+import models
+
+M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11) on arrays of counters [n, 4] and one key (k0, k1)."""
+    c = [ctr[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(M0) * c[0], np.uint64(M1) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + np.uint64(W0)) & mask, (k1 + np.uint64(W1)) & mask
+    return np.stack(c, 1).astype(np.uint32)
+
+
+def reference_noise(seed, first, n):
+    """Elements first .. first + n - 1 of the stream alan_noise_t defines (include/alan_mi355.h)."""
+    i = np.arange(first, first + n, dtype=np.uint64)
+    c = i >> np.uint64(2)
+    ctr = np.stack([c & np.uint64(0xFFFFFFFF), c >> np.uint64(32), np.full_like(c, 0x414C414E), np.zeros_like(c)], 1)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).astype(np.float64)
+    lane = (i & np.uint64(3)).astype(np.int64)
+    a = np.where(lane & 2, r[:, 2], r[:, 0])
+    b = np.where(lane & 2, r[:, 3], r[:, 1])
+    u1 = (a.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float64)
+    u2 = (b.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float64)
+    rad = np.sqrt(-2.0 * np.log(u1))
+    return rad * np.where(lane & 1, np.sin(2 * np.pi * u2), np.cos(2 * np.pi * u2))
+
+
+def test_philox_restatement_against_the_published_known_answers():
+    """Random123's kat_vectors for philox4x32 with 10 rounds."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(x) for x in got) == want
+
+
+def _draw(shape, seed, offset, perm=None):
+    """eps through the library alone: x = 0 + eps * 1."""
+    from alan_amd import engine as E
+    from alan_amd import native as N
+    flat = t.empty(math.prod(shape), device="cuda")
+    e = flat.view(shape)
+    if perm is not None:
+        e = e.permute(perm)
+    axes = tuple(range(e.ndim))
+    zero, one = t.zeros((), device="cuda"), t.ones((), device="cuda")
+    out = E._produce(N.MODE_AFFINE, [(zero.expand_as(e), axes), (e, axes), (one.expand_as(e), axes)], axes,
+                     scales=[1.0, 1.0, 1.0], noise=(seed, offset, None, None, None, 0))
+    N.flush()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,offset", [(0, 0), (1234, 4), (2 ** 63 + 12345, 2 ** 33 + 8), (7, 3)])
+def test_generated_noise_is_the_documented_stream(seed, offset):
+    n = 10007
+    got = _draw((n,), seed, offset).cpu().double().numpy()
+    want = reference_noise(seed, offset, n)
+    assert np.abs(got - want).max() < 3e-5          # (v_log / v_sqrt / v_sin / v_cos: ~1e-6 each, radius up to 6.8)
+
+
+@pytest.mark.gpu
+def test_generated_noise_follows_the_placeholders_strides():
+    """A permuted placeholder: element [i, j] of the view is element j * 5 + i of the stream."""
+    got = _draw((7, 5), 99, 16, perm=(1, 0)).cpu().double().numpy()             # view shape [5, 7]
+    want = reference_noise(99, 16, 35).reshape(7, 5).T
+    assert np.abs(got - want).max() < 3e-5
+
+
+@pytest.mark.gpu
+def test_generated_noise_is_standard_normal():
+    from scipy import stats
+    x = _draw((1 << 20,), 2024, 0).cpu().double().numpy()
+    assert abs(x.mean()) < 4e-3 and abs(x.var() - 1) < 6e-3
+    assert abs(stats.skew(x)) < 1e-2 and abs(stats.kurtosis(x)) < 2e-2
+    assert stats.kstest(x, "norm").pvalue > 1e-3
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 4e-3 and abs(np.corrcoef(x[:-2], x[2:])[0, 1]) < 4e-3
+
+
+def _movielens():
+    g = t.Generator().manual_seed(5)
+    x = t.randn(60, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(60, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 60, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    return prob
+
+
+@pytest.mark.gpu
+def test_draws_follow_torchs_generator_and_do_not_touch_memory(monkeypatch):
+    """Same seed, same draws; the generator's offset moves as the draws consume it; no torch noise kernel runs."""
+    from alan_amd import dist as D
+    assert D.DEVICE_NOISE
+    prob = _movielens()
+    called = []
+    real = t.Tensor.normal_
+    monkeypatch.setattr(t.Tensor, "normal_", lambda self, *a, **k: (called.append(1), real(self, *a, **k))[1])
+    gen = t.cuda.default_generators[0]
+    t.manual_seed(11)
+    o0 = gen.get_offset()
+    a = prob.sample(7, reparam=False)
+    o1 = gen.get_offset()
+    b = prob.sample(7, reparam=False)
+    t.manual_seed(11)
+    c = prob.sample(7, reparam=False)
+    assert not called and o1 > o0 and (o1 - o0) % 4 == 0
+    ea, eb, ec = (float(s.elbo_nograd(graph=False)) for s in (a, b, c))
+    assert ea == ec and ea != eb
+
+
+@pytest.mark.gpu
+def test_reparameterised_gradient_regenerates_the_forwards_noise():
+    """d/d loc and d/d raw of sum(w * x), x = loc + eps * exp(raw) drawn by a batch: eps is never in memory -- the backward
+    makes it again; checked against eps recovered from the sample itself."""
+    from alan_amd import dist as D
+    t.manual_seed(3)
+    loc = t.randn(6, device="cuda", requires_grad=True)
+    raw = (0.3 * t.randn(6, device="cuda")).requires_grad_()
+    w = t.randn(50, 9, 6, device="cuda")
+    batch = D._DrawBatch()
+    shape = t.Size((50, 9, 6))
+    la, sa = loc.expand(shape), raw.expand(shape)
+    pt = batch.add(la, sa, True, shape, None, (), None, True, holder=None)
+    batch.flush()
+    x = pt._val
+    (x * w).sum().backward()
+    eps = ((x.detach() - loc.detach()) / raw.detach().exp())
+    want_loc = w.sum((0, 1))
+    want_raw = (w * eps * raw.detach().exp()).sum((0, 1))
+    assert t.allclose(loc.grad, want_loc, rtol=1e-5, atol=1e-5)
+    assert t.allclose(raw.grad, want_raw, rtol=2e-4, atol=2e-4)
+    assert abs(float(eps.mean())) < 0.1 and abs(float(eps.std()) - 1) < 0.1
+
+
+@pytest.mark.gpu
+def test_replayed_graph_draws_what_the_iterations_launched_one_by_one_would():
+    """GraphedEval: the counter lives on the device (no generator fills in front of a replay); replays after a re-seed
+    repeat, and equal the same evaluations launched one by one under that seed."""
+    prob = _movielens()
+    ev = alan.GraphedEval(prob, 8)
+    assert ev.noise.per_replay > 0
+    t.manual_seed(21)
+    first = [float(ev()) for _ in range(4)]
+    t.manual_seed(21)
+    again = [float(ev()) for _ in range(4)]
+    t.manual_seed(21)
+    with t.no_grad():
+        eager = [float(prob.sample(8, reparam=False).elbo_nograd(graph=False)) for _ in range(4)]
+    assert first == again and len(set(first)) == 4
+    for a, b in zip(first, eager):
+        assert abs(a - b) <= 2e-6 * abs(b)
+    # somebody else used the generator between two replays: the graph moves on from where the generator is now
+    t.manual_seed(21)
+    one = float(ev())
+    t.randn(10, device="cuda")
+    two = float(ev())
+    assert one == first[0] and two != first[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vi", "rws"])
+def test_graphed_step_with_generated_noise_trains(method):
+    prob = _movielens()
+    opt = t.optim.Adam(prob.parameters(), lr=0.01, capturable=True)
+    step = alan.GraphedStep(prob, 10, opt, method=method)
+    assert step.noise.per_replay > 0
+    t.manual_seed(1)
+    a = [float(step()) for _ in range(40)]
+    assert all(math.isfinite(v) for v in a) and len(set(a)) == 40
+    if method == "vi":
+        assert sum(a[-10:]) / 10 > sum(a[:10]) / 10
+
+
+@pytest.mark.gpu
+def test_a_kernel_timer_around_draws_with_generated_noise():
+    """bench.py times the plate step's backward with profiling.KernelTimer around whole VI iterations: the draws go out one
+    by one then (nothing is queued under a timer), without timing events of their own."""
+    from alan_amd.profiling import KernelTimer
+    prob = _movielens()
+    with KernelTimer() as kt:
+        for _ in range(2):
+            for q in prob.parameters():
+                q.grad = None
+            prob.sample(6, reparam=True).elbo_vi(alan.no_checkpoint).backward()
+        t.cuda.synchronize()
+    assert all(q.grad is None or bool(t.isfinite(q.grad).all()) for q in prob.parameters())
+    assert kt.results() is not None

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 10
+    assert L.alan_abi_version() == 11
     assert L.alan_build_target() == b"gfx950"
 
 
@@ -33,8 +33,31 @@ def test_struct_layout_matches_header():
     # alan_tensor_t: ptr(8) + int32 + float + 8*int64 ; alan_reduce_desc_t per the header
     assert ctypes.sizeof(N.Tensor) == 8 + 4 + 4 + 8 * N.MAX_DIMS
     expect = 4 + 4 + 8 * N.MAX_DIMS + 4 * N.MAX_DIMS + 4 + 4 + ctypes.sizeof(N.Tensor) * (N.MAX_FACTORS + 3) + 8 + 16 + (8 + 8 + 4 + 4)
+    expect += 4 + 4 + 8 + 8 + 3 * 8                      # alan_noise_t
+    assert ctypes.sizeof(N.Noise) == 48
     assert ctypes.sizeof(N.ReduceDesc) == expect
     assert ctypes.sizeof(N.BackwardDesc) == expect + ctypes.sizeof(N.Tensor) * N.MAX_FACTORS
+
+
+def test_generated_noise_is_only_for_the_draws_modes():
+    """alan_noise_t on a log-sum-exp: a bad descriptor, said before anything touches a GPU."""
+    L = N.lib()
+    d = N.ReduceDesc()
+    d.mode, d.ndim, d.n_factors = N.MODE_LSE, 1, 2
+    d.size[0], d.role[0] = 8, N.REDUCE
+    dummy = ctypes.c_void_p(0x1000)
+    for x in (d.factor[0], d.factor[1], d.out):
+        x.data, x.dtype, x.scale = dummy, N.F32, 1.0
+    d.factor[0].stride[0] = d.factor[1].stride[0] = 1
+    assert L.alan_reduce_check(ctypes.byref(d)) == 0
+    d.noise.on = 1
+    assert L.alan_reduce_check(ctypes.byref(d)) == -1
+    d.mode, d.n_factors, d.role[0] = N.MODE_AFFINE, 3, N.KEEP
+    d.factor[2].data, d.factor[2].dtype, d.factor[2].scale = dummy, N.F32, 1.0
+    d.factor[2].stride[0] = d.out.stride[0] = 1
+    assert L.alan_reduce_check(ctypes.byref(d)) == 0
+    d.out.dtype = d.factor[0].dtype = d.factor[1].dtype = d.factor[2].dtype = N.F64      # (fp64: not the small kernel)
+    assert L.alan_reduce_check(ctypes.byref(d)) == N.ERR_UNSUPPORTED
 
 
 def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
