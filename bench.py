@@ -105,6 +105,20 @@ def build_timeseries_problem(device, T=1000, seed=0):
     return prob.to(device)
 
 
+def build_timeseries_train_problem(device, T=1000, seed=0):
+    """The same model with a learned approximate posterior: a Normal per timestep (OptParam location and log-scale of
+    shape [T], Param.py:18-25) -- what a VI / RWS iteration on it trains."""
+    from alan_amd import Normal, Timeseries, Plate, BoundPlate, Problem, Data, OptParam
+    g = t.Generator().manual_seed(seed)
+    y = t.randn(T, generator=g).refine_names("T")
+    P = Plate(init=Normal(0, 1.0),
+              T=Plate(ts=Timeseries("init", Normal(lambda prev: 0.9 * prev, 0.1)), obs=Normal("ts", 1.0)))
+    Q = Plate(init=Normal(OptParam(0.0), OptParam(0.0, transformation=t.exp)),
+              T=Plate(ts=Normal(OptParam(0.0), OptParam(0.0, transformation=t.exp)), obs=Data()))
+    prob = Problem(BoundPlate(P, {"T": T}), BoundPlate(Q, {"T": T}), {"obs": y})
+    return prob.to(device)
+
+
 def draw(prob, K, seed=1):
     t.manual_seed(seed)
     if t.cuda.is_available():
@@ -689,6 +703,26 @@ def main():
         except Exception as e:
             chain["error"] = f"{type(e).__name__}: {e}"
         out["timeseries_chain_T1000"] = chain
+        # ---- a training iteration of the same timeseries model (learned Normal posterior per timestep), one replayed graph
+        ts_tr = {}
+        try:
+            for mode in ("vi", "rws"):
+                p_ts = build_timeseries_train_problem("cuda")
+                opt = t.optim.Adam(list(p_ts.parameters()), lr=1e-2, capturable=True, fused=True, maximize=(mode == "rws"))
+                step = alan.GraphedStep(p_ts, 30, opt, method=mode)
+                for _ in range(5):
+                    step()
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    v_ts = step()
+                t.cuda.synchronize()
+                ts_tr[mode] = {"ms_per_iter": (time.perf_counter() - t0) / 30 * 1e3, "last_elbo": float(v_ts)}
+                del step, opt, p_ts
+            ts_tr["config"] = "Kalman T=1000, K=30, OptParam location and log-scale per timestep, Adam (fused, capturable)"
+        except Exception as e:
+            ts_tr["error"] = f"{type(e).__name__}: {e}"
+        out["timeseries_training_iteration"] = ts_tr
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
