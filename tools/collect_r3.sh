@@ -37,6 +37,13 @@ timeout -k 10 150 python3 tools/chain_parts.py 30 > $O/chain_parts_K30.txt 2>&1 
 timeout -k 10 150 python3 tools/chain_parts.py 100 > $O/chain_parts_K100.txt 2>&1 || echo "chain parts K=100 failed"
 timeout -k 10 300 python3 tools/chain_check.py > $O/chain_check.txt 2>&1 || echo "chain check failed"
 for b in 0 1; do ALAN_AMD_BATCH_DRAWS=$b timeout -k 10 200 python3 tools/train_step_bench.py 2>/dev/null | grep "graph replay" | sed "s/^/BATCH_DRAWS=$b /"; done > $O/batched_draws_ab.txt 2>&1 || echo "train A/B failed"
+# ---- last part of round 3: the one-shot exchange between processes sharing this GPU, the dispatcher's ramp, training
+# iterations of the timeseries model
+timeout -k 10 120 python3 tools/exchange_probe.py 2 > $O/exchange_probe.txt 2>&1 || echo "exchange probe failed"
+[ -x tools/_build/dispatch_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/dispatch_probe.hip -o tools/_build/dispatch_probe > /dev/null 2>&1
+timeout -k 10 60 ./tools/_build/dispatch_probe > $O/dispatch_probe.txt 2>&1 || echo "dispatch probe failed"
+timeout -k 10 200 python3 tools/ts_train_probe.py 30 30 > $O/ts_train.txt 2>&1 || echo "ts train probe failed"
+for b in 0 1; do ALAN_AMD_DEVICE_NOISE=$b timeout -k 10 200 python3 tools/train_step_bench.py 2>/dev/null | grep "graph replay" | sed "s/^/DEVICE_NOISE=$b /"; done > $O/device_noise_ab.txt 2>&1 || echo "noise A/B failed"
 # keep what the summariser reads, drop the bulky traces
 find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
 find $O -path "*case_*" -name "*kernel_trace.csv" -delete

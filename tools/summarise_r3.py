@@ -160,9 +160,14 @@ for src, dst, head in (("chain_bwd_trace_K30.txt", "r3_chain_backward_launches_K
                        ("chain_parts_K30.txt", "r3_chained_launch_parts_K30.txt", "# python3 tools/chain_parts.py 30: the chained launch (alan_normal_lse_chained) replayed with subsets of its parts\n"),
                        ("chain_parts_K100.txt", "r3_chained_launch_parts_K100.txt", "# python3 tools/chain_parts.py 100\n"),
                        ("chain_check.txt", "r3_chained_launch_ab.txt", "# python3 tools/chain_check.py: movielens evaluations as separate launches / sync-free chained / chained with hand-offs / one launch\n"),
-                       ("batched_draws_ab.txt", "r3_batched_draws_ab.txt", "# tools/train_step_bench.py with dist.BATCH_DRAWS off / on (one process each, same box)\n")):
+                       ("batched_draws_ab.txt", "r3_batched_draws_ab.txt", "# tools/train_step_bench.py with dist.BATCH_DRAWS off / on (one process each, same box)\n"),
+                       ("device_noise_ab.txt", "r3_device_noise_ab.txt", "# tools/train_step_bench.py with dist.DEVICE_NOISE off / on (one process each, same box)\n"),
+                       ("exchange_probe.txt", "r3_exchange_probe.txt", "# python3 tools/exchange_probe.py 2: alan_exchange_sum between two processes SHARING this GPU (40 KB partials, 500 exchanges launched one by one): protocol and arithmetic, not the xGMI fabric\n"),
+                       ("dispatch_probe.txt", "r3_dispatch_probe.txt", "# tools/dispatch_probe.hip: how long the dispatcher takes to start the 2048 waves of a launch, by workgroup size and register budget\n"),
+                       ("ts_train.txt", "r3_timeseries_training_iteration.txt", "# python3 tools/ts_train_probe.py 30 30: VI / RWS iteration of the Kalman timeseries model (T=1000, K=30) as one replayed graph\n")):
     p = os.path.join(RAW, src)
     if os.path.exists(p):
-        body = "".join(l for l in open(p) if "amdgpu.ids" not in l and "UserWarning" not in l and "refine_names" not in l)
+        body = "".join(l for l in open(p) if "amdgpu.ids" not in l and "UserWarning" not in l and "refine_names" not in l
+                       and "[Gloo]" not in l and "socket.cpp" not in l)
         open(os.path.join(OUT, dst), "w").write(head + body)
 print("profiles/ written:", sorted(x for x in os.listdir(OUT) if x.startswith("r3_")))
