@@ -134,9 +134,15 @@ class GraphedStep:
     ``maximize=True`` (the loss is ``-elbo`` for both methods)."""
 
     def __init__(self, problem, K, optimizer, method="vi", computation_strategy=no_checkpoint, warmup=3,
-                 capture_stream=None, allow_memset_nodes=False, _unsafe=False):
+                 capture_stream=None, allow_memset_nodes=False, _unsafe=False, unroll=1):
         """``capture_stream``: diagnostics (tools/graph_race_probe.py) -- capture on another stream than the warm-up
-        one.  ``allow_memset_nodes``: only warn about memset nodes in the captured graph (see ``memset_nodes``)."""
+        one.  ``allow_memset_nodes``: only warn about memset nodes in the captured graph (see ``memset_nodes``).
+        ``unroll``: that many consecutive iterations per captured graph -- a replay then runs them all and returns their
+        ELBOs as a vector (a graph launch leaves the GPU idle for several microseconds whatever it holds: tools/replay_trace.sh;
+        with the draws' generator state on the device every inner iteration has its own particles)."""
+        if unroll < 1:
+            raise Exception("unroll must be at least 1")
+        self.unroll = unroll
         if method not in ("vi", "rws"):
             raise Exception("method must be 'vi' or 'rws'")
         if problem.device.type != "cuda":
@@ -180,7 +186,10 @@ class GraphedStep:
         with N.own_graph_noise(problem.device) as self.noise, \
                 t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
                              capture_error_mode="thread_local"):
-            self.elbo = self._iteration()
+            if unroll == 1:
+                self.elbo = self._iteration()
+            else:
+                self.elbo = t.stack([self._iteration() for _ in range(unroll)])
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedStep", allow_memset_nodes)
 
     def _iteration(self):
@@ -209,14 +218,18 @@ class GraphedEval:
     native.GraphNoise, kept in step with torch's generator), log-prob producers and the contraction all replay on the
     device."""
 
-    def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3, ring=True):
+    def __init__(self, problem, K, computation_strategy=no_checkpoint, warmup=3, ring=True, unroll=1):
+        """``unroll``: that many evaluations (each with its own fresh particles) per captured graph; a call then returns
+        their ELBOs as a vector (GraphedStep.__init__ says why)."""
         if problem.device.type != "cuda":
             raise Exception("GraphedEval needs the Problem on the GPU")
+        if unroll < 1:
+            raise Exception("unroll must be at least 1")
         from . import engine as E
         from . import sample as S
-        self.problem, self.K, self.strategy = problem, K, computation_strategy
+        self.problem, self.K, self.strategy, self.unroll = problem, K, computation_strategy, unroll
         # the evaluation's last launch delivers through a result ring (engine.ResultRing): no copy after a replay
-        self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING) else None
+        self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING and unroll == 1) else None
         E._RING[0] = self.ring
         from . import native as N
         own = N.own_chain_state(problem.device)
@@ -234,7 +247,10 @@ class GraphedEval:
             self.graph = t.cuda.CUDAGraph(keep_graph=True)
             with N.own_graph_noise(problem.device) as self.noise, \
                     t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                self.elbo = self._iteration()
+                if unroll == 1:
+                    self.elbo = self._iteration()
+                else:
+                    self.elbo = t.stack([self._iteration().float() for _ in range(unroll)])
         finally:
             own.__exit__(None, None, None)
             E._RING[0] = None
@@ -242,7 +258,7 @@ class GraphedEval:
         if self.ring is not None:
             how = self.ring.settle(self.elbo)
             if how == "recapture":
-                self.__init__(problem, K, computation_strategy, warmup, ring=False)
+                self.__init__(problem, K, computation_strategy, warmup, ring=False, unroll=unroll)
             elif how == "copy":
                 self.ring = None
 

@@ -564,6 +564,21 @@ def main():
                                             "graph_last_elbo": float(v_se)})
         except Exception as e:
             out["sample_plus_elbo"]["graph_error"] = f"{type(e).__name__}: {e}"
+        try:                                      # eight such iterations per captured graph (each with its own fresh particles)
+            ev8 = alan.GraphedEval(prob, K, strat, unroll=8)
+            for _ in range(3):
+                ev8()
+            t.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(25):
+                v8 = ev8()
+            t.cuda.synchronize()
+            dt_8 = (time.perf_counter() - t0) / (25 * 8)
+            out["sample_plus_elbo"].update({"graph_unroll8_ms_per_iter": dt_8 * 1e3, "graph_unroll8_iters_per_s": 1 / dt_8,
+                                            "graph_unroll8_distinct_elbos": len(set(v8.tolist()))})
+            del ev8
+        except Exception as e:
+            out["sample_plus_elbo"]["graph_unroll8_error"] = f"{type(e).__name__}: {e}"
         # row a10 (the path's backward) in production use: a whole training iteration -- sample -> elbo_vi | elbo_rws ->
         # backward -> Adam, the loop of examples/basic_runner.py:81-112 -- captured once and replayed
         try:
@@ -582,6 +597,21 @@ def main():
                     v_tr = step()
                 t.cuda.synchronize()
                 tr[mode] = {"ms_per_iter": (time.perf_counter() - t0) / 50 * 1e3, "last_elbo": float(v_tr)}
+                del step, opt, p_tr
+                # four consecutive iterations per captured graph (GraphedStep(unroll=4))
+                p_tr = build_problem("cuda")
+                params = list(p_tr.parameters()) if mode == "vi" else list(p_tr.Q.parameters())
+                opt = t.optim.Adam(params, lr=1e-2, capturable=True, fused=True, maximize=(mode == "rws"))
+                step = alan.GraphedStep(p_tr, K, opt, method=mode, unroll=4)
+                for _ in range(2):
+                    step()
+                t.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(13):
+                    v_tr = step()
+                t.cuda.synchronize()
+                tr[mode]["unroll4_ms_per_iter"] = (time.perf_counter() - t0) / (13 * 4) * 1e3
+                tr[mode]["unroll4_last_elbos"] = v_tr.tolist()
                 del step, opt, p_tr
             # the fused plate step's backward alone (elbo_vi, eager, HIP events on its launch)
             p_tr = build_problem("cuda")

@@ -202,3 +202,33 @@ def test_a_kernel_timer_around_draws_with_generated_noise():
         t.cuda.synchronize()
     assert all(q.grad is None or bool(t.isfinite(q.grad).all()) for q in prob.parameters())
     assert kt.results() is not None
+
+
+@pytest.mark.gpu
+def test_unrolled_graphs_run_their_iterations_in_order_with_fresh_particles():
+    """GraphedEval(unroll=4): one replay = four evaluations, each with its own draws -- the same twelve values as twelve
+    replays of the plain graph under the same seed.  GraphedStep(unroll=3): two replays = six iterations of the one-by-one
+    graph (same parameters afterwards)."""
+    prob = _movielens()
+    ev1, ev4 = alan.GraphedEval(prob, 8), alan.GraphedEval(prob, 8, unroll=4)
+    t.manual_seed(5)
+    one = [float(ev1()) for _ in range(12)]
+    t.manual_seed(5)
+    four = [v for _ in range(3) for v in ev4().tolist()]
+    assert len(set(one)) == 12
+    for a, b in zip(one, four):
+        assert abs(a - b) <= 2e-6 * abs(a)
+    results = []
+    for unroll in (1, 3):
+        t.manual_seed(0)
+        p = _movielens()
+        opt = t.optim.Adam(p.parameters(), lr=0.01, capturable=True)
+        step = alan.GraphedStep(p, 6, opt, method="vi", unroll=unroll)
+        t.manual_seed(9)
+        vals = [float(step()) for _ in range(6)] if unroll == 1 else [v for _ in range(2) for v in step().tolist()]
+        results.append((vals, [q.detach().clone() for q in p.parameters()]))
+    (v1, p1), (v3, p3) = results
+    for a, b in zip(v1, v3):
+        assert abs(a - b) <= 1e-4 * abs(a)
+    for a, b in zip(p1, p3):
+        assert t.allclose(a, b, rtol=1e-3, atol=1e-4)
