@@ -648,7 +648,7 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
         if (smem > 64 * 1024)
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
                 return ALAN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(n_out, B), dim3(threads), smem, stream, src, cB, cT, cR, cC, n_src, (int)K, dst,
+        ALAN_LAUNCH(kern, dim3(n_out, B), dim3(threads), smem, stream, src, cB, cT, cR, cC, n_src, (int)K, dst,
                            vec_out, ad);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
@@ -662,7 +662,7 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
             if (ssm > 64 * 1024)
                 if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ssm) != hipSuccess)
                     return ALAN_ERR_LAUNCH;
-            hipLaunchKernelGGL(kern, dim3(n_out, B, (uint32_t)kt), dim3(threads), ssm, stream, src, cB, cT, cR, cC, n_src,
+            ALAN_LAUNCH(kern, dim3(n_out, B, (uint32_t)kt), dim3(threads), ssm, stream, src, cB, cT, cR, cC, n_src,
                                (int)K, dst, vec_out);
             return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
         };
@@ -1015,7 +1015,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
                 wf.ring_slots = (float *const *)final_->ring_slots, wf.ring_counter = (int32_t *)final_->ring_counter;
                 wf.ring_n = final_->ring_n;
             }
-            hipLaunchKernelGGL(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
+            ALAN_LAUNCH(wk, dim3((uint32_t)nseg, (uint32_t)B), dim3(64 * nw), lsmem, stream,
                                (const float *)src, cB, cT, cR, cC, (int)tl.n[r], (int)K, rounds, wo,
                                last ? (float *)out_vec : (float *)nullptr, r == 0 ? adf : nonef, wf);
             if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
@@ -1040,7 +1040,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             int nn[3] = {0, 0, 0};
             for (int q = 0; q < rounds; ++q) o[q] = (T *)((char *)ws + tl.off[r + 1 + q]), nn[q] = (int)tl.n[r + 1 + q];
             const bool last = r + rounds == tl.L;
-            hipLaunchKernelGGL(tk, dim3((uint32_t)nseg, (uint32_t)B), dim3(TREE_THREADS), 8 * slot, stream, src, cB, cT,
+            ALAN_LAUNCH(tk, dim3((uint32_t)nseg, (uint32_t)B), dim3(TREE_THREADS), 8 * slot, stream, src, cB, cT,
                                cR, cC, (int)tl.n[r], (int)K, rounds, o[0], o[1], o[2], nn[0], nn[1], nn[2],
                                last ? (T *)out_vec : (T *)nullptr, r == 0 ? ad0 : none);
             if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
@@ -1061,7 +1061,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
                                                    r == 1 ? ad0 : none);
             if (rc == ALAN_ERR_LAUNCH) return rc;
             if (rc == ALAN_ERR_UNSUPPORTED) {
-                hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
+                ALAN_LAUNCH(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB,
                                    cT, cR, cC, (int)tl.n[r - 1], 2, (int)K, dst, r == tl.L ? (T *)out_vec : (T *)nullptr,
                                    r == 1 ? ad0 : none);
                 if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
@@ -1481,18 +1481,18 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
         if constexpr (sizeof(T) == 4) {
             if (mfma) {
                 if (K > 48)
-                    hipLaunchKernelGGL(chain_pair_backward_mfma_kernel<1024>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(1024),
+                    ALAN_LAUNCH(chain_pair_backward_mfma_kernel<1024>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(1024),
                                        smem_m, stream, src, cB, cT, cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K),
                                        (int64_t)K, (int64_t)1, (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
                 else
-                    hipLaunchKernelGGL(chain_pair_backward_mfma_kernel<256>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(256),
+                    ALAN_LAUNCH(chain_pair_backward_mfma_kernel<256>, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(256),
                                        smem_m, stream, src, cB, cT, cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K),
                                        (int64_t)K, (int64_t)1, (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
                 if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
                 continue;
             }
         }
-        hipLaunchKernelGGL(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
+        ALAN_LAUNCH(kern, dim3((uint32_t)tl.n[r], (uint32_t)B), dim3(CHAIN_THREADS), smem, stream, src, cB, cT,
                            cR, cC, (int)tl.n[r - 1], (int)K, G, root, (int64_t)(K * K), (int64_t)K, (int64_t)1,
                            (const T *)out_vec, (const T *)grad_vec, (const T *)grad_chain, dsrc);
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;

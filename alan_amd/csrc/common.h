@@ -4,6 +4,9 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <functional>
+#include <tuple>
+#include <vector>
 #include "alan_mi355.h"
 
 namespace alan {
@@ -15,6 +18,35 @@ inline int env_knob(const char *name) {
     const char *e = getenv(name);
     return e ? atoi(e) : ENV_UNSET;
 }
+
+// Every kernel launch of the library goes through alan_launch: normally straight to hipLaunchKernelGGL (or its event-
+// carrying form), but while a call list is being recorded (calls.hip: alan_calls_add_*) the launch is NOT issued -- it is
+// kept, kernel and grid and a copy of every argument, to be issued by alan_calls_replay: all the host-side planning
+// of a call happens once.
+struct LaunchRecorder {
+    std::vector<std::function<void(hipStream_t)>> launches;
+};
+extern thread_local LaunchRecorder *g_launch_recorder;
+
+template <typename... KArgs, typename... Args>
+inline void alan_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t e0,
+                        hipEvent_t e1, const Args &...args) {
+    if (g_launch_recorder) {
+        std::tuple<std::decay_t<KArgs>...> held(args...);
+        g_launch_recorder->launches.emplace_back([kernel, grid, block, lds, held](hipStream_t st) {
+            std::apply([&](const auto &...a) { hipLaunchKernelGGL(kernel, grid, block, lds, st, a...); }, held);
+        });
+        return;
+    }
+    if (e0 || e1)
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0, e1, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
+#define ALAN_LAUNCH(kernel, grid, block, lds, stream, ...) \
+    ::alan::alan_launch(kernel, grid, block, lds, stream, nullptr, nullptr, __VA_ARGS__)
+#define ALAN_LAUNCH_EXT(kernel, grid, block, lds, stream, e0, e1, flags, ...) \
+    ::alan::alan_launch(kernel, grid, block, lds, stream, e0, e1, __VA_ARGS__)
 
 constexpr int MAXD = ALAN_MAX_DIMS;
 constexpr int MAXF = ALAN_MAX_FACTORS;

@@ -384,13 +384,13 @@ template <int EH>
 static void launch_normal_mfma(int nst, dim3 grid, hipStream_t stream, const EvPair &ev, const NormalDesc &d) {
     const uint32_t lds = d.l_chunk * 2u * EH * sizeof(float);        // the loc rows of a workgroup
     if (nst == 1 && d.ts_nk)
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1, true>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        ALAN_LAUNCH_EXT((normal_mfma_kernel<EH, 1, true>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
     else if (nst == 1)
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 1, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        ALAN_LAUNCH_EXT((normal_mfma_kernel<EH, 1, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
     else if (nst == 2)
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 2, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        ALAN_LAUNCH_EXT((normal_mfma_kernel<EH, 2, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
     else
-        hipExtLaunchKernelGGL((normal_mfma_kernel<EH, 4, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
+        ALAN_LAUNCH_EXT((normal_mfma_kernel<EH, 4, false>), grid, dim3(256), lds, stream, ev.start, ev.stop, 0, d);
 }
 
 // d is filled except for l_chunk.  Declines (false) outside E <= 32, NS <= 128.
@@ -549,10 +549,10 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
 #define ALAN_NORMAL_CASE(EM)                                                                                     \
     case EM:                                                                                                     \
         if (R == 2)                                                                                              \
-            hipExtLaunchKernelGGL((normal_outer_kernel<EM, 2>), grid, block, (uint32_t)lds, stream, ev.start,     \
+            ALAN_LAUNCH_EXT((normal_outer_kernel<EM, 2>), grid, block, (uint32_t)lds, stream, ev.start,     \
                                   ev.stop, 0, d);                                                                \
         else                                                                                                     \
-            hipExtLaunchKernelGGL((normal_outer_kernel<EM, 1>), grid, block, (uint32_t)lds, stream, ev.start,     \
+            ALAN_LAUNCH_EXT((normal_outer_kernel<EM, 1>), grid, block, (uint32_t)lds, stream, ev.start,     \
                                   ev.stop, 0, d);                                                                \
         break
     switch (d.Ep) {
@@ -565,7 +565,7 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
         ALAN_NORMAL_CASE(28);
         ALAN_NORMAL_CASE(32);
         ALAN_NORMAL_CASE(48);
-        default: hipExtLaunchKernelGGL((normal_outer_kernel<64, 1>), grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
+        default: ALAN_LAUNCH_EXT((normal_outer_kernel<64, 1>), grid, block, (uint32_t)lds, stream, ev.start, ev.stop, 0, d);
     }
 #undef ALAN_NORMAL_CASE
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;

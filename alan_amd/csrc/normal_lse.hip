@@ -674,7 +674,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     d.out = (float *)a->out, d.o_sl = a->o_sl, d.o_ss = a->o_ss, d.add_const = (float)a->add_const;
     if (d.counters && (int64_t)p.grid.x > a->n_counters) return ALAN_ERR_BAD_DESC;
     auto launch = [&](auto kern) {
-        hipExtLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
+        ALAN_LAUNCH_EXT(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
     // flat row tiling (see the kernels): the plate elements' k rows as one run
@@ -696,7 +696,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
             if (lds_x > 64 * 1024 &&
                 hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x) != hipSuccess)
                 return ALAN_ERR_LAUNCH;
-            hipExtLaunchKernelGGL(kern, grid3, dim3(256), lds_x, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, x);
+            ALAN_LAUNCH_EXT(kern, grid3, dim3(256), lds_x, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, x);
             return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
         };
 #define X3_PICK(EQV)                                                                                                   \

@@ -533,7 +533,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds) !=
                 hipSuccess)
                 return ALAN_ERR_LAUNCH;
-        hipExtLaunchKernelGGL(kern, grid, dim3(256), p.lds, stream, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, d);
+        ALAN_LAUNCH_EXT(kern, grid, dim3(256), p.lds, stream, (hipEvent_t)a.ev_start, (hipEvent_t)a.ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
 #define NLB_CASE(EHV)                                                                        \
@@ -562,7 +562,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
     if (d.pscl) s1 = ColSeg{d.pscl, (float *)b->grad_scale, (int32_t)p.rows_scl, (int32_t)(a.NS * a.E)};
     if (s0.C || s1.C) {
         const uint32_t gx = (uint32_t)((std::max(s0.C, s1.C) + 15) / 16);
-        hipLaunchKernelGGL(nlb_colsum_kernel, dim3(gx, 2), dim3(256), 0, stream, s0, s1);
+        ALAN_LAUNCH(nlb_colsum_kernel, dim3(gx, 2), dim3(256), 0, stream, s0, s1);
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     }
     if (split && (d.dval || d.dsm)) {
@@ -572,7 +572,7 @@ extern "C" int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *b
         if (d.dval) v0 = ColSeg{d.dval, (float *)b->grad_value, p.gy, (int32_t)cv};
         if (d.dsm) v1 = ColSeg{d.dsm, (float *)b->grad_small, p.gy, (int32_t)cs};
         const uint32_t gx = (uint32_t)std::min<int64_t>(2048, (std::max<int64_t>(v0.C, v1.C) + 255) / 256);
-        hipLaunchKernelGGL(nlb_addrows_kernel, dim3(gx, 2), dim3(256), 0, stream, v0, v1);
+        ALAN_LAUNCH(nlb_addrows_kernel, dim3(gx, 2), dim3(256), 0, stream, v0, v1);
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     }
     return ALAN_OK;

@@ -132,7 +132,7 @@ int chain_launch_eq(const ChainPlan &p, hipStream_t stream) {
         if (p.xp.lds > 64 * 1024 &&
             hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.xp.lds) != hipSuccess)
             return ALAN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.xp.lds, stream, p.k);
+        ALAN_LAUNCH(kern, dim3(p.grid), dim3(256), p.xp.lds, stream, p.k);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
     const bool flat = p.xp.flat;

@@ -371,13 +371,13 @@ int launch_pair(const PairDesc &pd_, dim3 grid, size_t lds_bytes, void *workspac
         pd.ws = (float *)workspace;
     }
     if (pd.bern)
-        hipExtLaunchKernelGGL(pair_lse_kernel<true>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
+        ALAN_LAUNCH_EXT(pair_lse_kernel<true>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
     else
-        hipExtLaunchKernelGGL(pair_lse_kernel<false>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
+        ALAN_LAUNCH_EXT(pair_lse_kernel<false>, grid, dim3(256), lds_bytes, stream, ev.start, ev.stop, 0, pd);
     if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     if (pd.split) {
         const uint32_t n = grid.y * (uint32_t)pd.NI * (uint32_t)pd.NJ;
-        hipLaunchKernelGGL(pair_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pd, (int)grid.y);
+        ALAN_LAUNCH(pair_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pd, (int)grid.y);
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     }
     return ALAN_OK;

@@ -1034,5 +1034,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 11; }
+extern "C" int alan_abi_version(void) { return 12; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

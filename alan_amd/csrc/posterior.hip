@@ -153,7 +153,7 @@ extern "C" int alan_chain_messages(const void *ms, int64_t C, int64_t T, int64_t
         if (smem > 64 * 1024)
             if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
                 return (int)ALAN_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3((uint32_t)C), dim3(PST_THREADS), smem, (hipStream_t)stream, (const float *)ms, sC, sT,
+        ALAN_LAUNCH(kern, dim3((uint32_t)C), dim3(PST_THREADS), smem, (hipStream_t)stream, (const float *)ms, sC, sT,
                            sRow, sCol, (int)T, (int)K, (float *)beta);
         return hipGetLastError() == hipSuccess ? (int)ALAN_OK : (int)ALAN_ERR_LAUNCH;
     };
@@ -168,7 +168,7 @@ extern "C" int alan_chain_sample(const void *ms, int64_t T, int64_t K, int64_t s
     if (T >= (1ll << 31) || N * B >= (1ll << 40)) return ALAN_ERR_UNSUPPORTED;
     const int64_t blocks = (N * B + PST_THREADS - 1) / PST_THREADS;
     if (blocks >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(chain_sample_kernel, dim3((uint32_t)blocks), dim3(PST_THREADS), 0, (hipStream_t)stream,
+    ALAN_LAUNCH(chain_sample_kernel, dim3((uint32_t)blocks), dim3(PST_THREADS), 0, (hipStream_t)stream,
                        (const float *)ms, sC, sT, sRow, sCol, (const float *)beta, (int)T, (int)K, (const int64_t *)init,
                        iN, iB, (const float *)uniforms, N, B, cN, cB, (int64_t *)out);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
@@ -178,7 +178,7 @@ extern "C" int alan_chain_filter(const void *ms, int64_t C, int64_t T, int64_t K
                                  int64_t sCol, const void *init, int64_t N, void *alpha, void *stream) {
     if (!ms || !init || !alpha || C < 1 || T < 1 || K < 1 || N < 1) return ALAN_ERR_BAD_DESC;
     if (K > 4096 || C >= (1ll << 31) || N > 65535) return ALAN_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(chain_filter_kernel, dim3((uint32_t)C, (uint32_t)N), dim3(PST_THREADS), 2 * K * sizeof(float),
+    ALAN_LAUNCH(chain_filter_kernel, dim3((uint32_t)C, (uint32_t)N), dim3(PST_THREADS), 2 * K * sizeof(float),
                        (hipStream_t)stream, (const float *)ms, sC, sT, sRow, sCol, (int)T, (int)K, (const int64_t *)init,
                        (int)N, (float *)alpha);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void reduce_small_plate_kernel(const SmallPlat
 
 int launch_small_plate(const SmallPlateDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.grid == 0) return ALAN_OK;
-    hipExtLaunchKernelGGL(reduce_small_plate_kernel, dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, sd, gl.logG);
+    ALAN_LAUNCH_EXT(reduce_small_plate_kernel, dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, sd, gl.logG);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
@@ -307,16 +307,16 @@ __global__ __launch_bounds__(256) void bernoulli_linear_grad_kernel(const LinDes
 
 int launch_lin_grad(const LinDesc &ld, hipStream_t stream, const EvPair &ev) {
     if (ld.n_out == 0) return ALAN_OK;
-    hipExtLaunchKernelGGL(bernoulli_linear_grad_kernel, dim3((ld.n_out + 255) / 256), dim3(256), 0, stream, ev.start, ev.stop, 0, ld);
+    ALAN_LAUNCH_EXT(bernoulli_linear_grad_kernel, dim3((ld.n_out + 255) / 256), dim3(256), 0, stream, ev.start, ev.stop, 0, ld);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
 int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.grid == 0) return ALAN_OK;
     if (gl.block)
-        hipExtLaunchKernelGGL((bernoulli_linear_kernel<true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, ld, 8);
+        ALAN_LAUNCH_EXT((bernoulli_linear_kernel<true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0, ld, 8);
     else
-        hipExtLaunchKernelGGL((bernoulli_linear_kernel<false>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0,
+        ALAN_LAUNCH_EXT((bernoulli_linear_kernel<false>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop, 0,
                               ld, gl.logG);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
@@ -333,17 +333,17 @@ int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mo
     const uint32_t blocks = fill_small_multi(m, sd, gl, mode, n, lin);
     if (blocks == 0) return ALAN_OK;
     m.noise = noise_launch(noise, advance);
-    hipLaunchKernelGGL(reduce_small_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
+    ALAN_LAUNCH(reduce_small_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
 template <int MODE>
 static void launch_small_T(const SmallDesc &sd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.block)
-        hipExtLaunchKernelGGL((reduce_small_kernel<MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop,
+        ALAN_LAUNCH_EXT((reduce_small_kernel<MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start, ev.stop,
                               0, sd, 8);
     else
-        hipExtLaunchKernelGGL((reduce_small_kernel<MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+        ALAN_LAUNCH_EXT((reduce_small_kernel<MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
                               ev.stop, 0, sd, gl.logG);
 }
 
@@ -447,7 +447,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
     if (wide_knob != 0 && gd.n_out == 1 && gl.block && (mode == ALAN_MODE_LSE || mode == ALAN_MODE_SUM) &&
         (int64_t)sd.n_red * (slices + sd.nf - 1) >= 4096) {
         const int per_thread = (int)((sd.n_red + 1023) / 1024);
-        auto wide = [&](auto kern) { hipExtLaunchKernelGGL(kern, dim3(1), dim3(1024), 0, stream, ev.start, ev.stop, 0, sd); };
+        auto wide = [&](auto kern) { ALAN_LAUNCH_EXT(kern, dim3(1), dim3(1024), 0, stream, ev.start, ev.stop, 0, sd); };
         const bool lse = mode == ALAN_MODE_LSE;
         if (slices >= 16 || per_thread <= 1)
             lse ? wide(reduce_wide_kernel<ALAN_MODE_LSE, 1, 40>) : wide(reduce_wide_kernel<ALAN_MODE_SUM, 1, 40>);
@@ -475,10 +475,10 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
 template <typename T, int MODE>
 static int launch_group_T(const GroupDesc &gd, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev) {
     if (gl.block) {
-        hipExtLaunchKernelGGL((reduce_group_kernel<T, MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+        ALAN_LAUNCH_EXT((reduce_group_kernel<T, MODE, true>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
                               ev.stop, 0, gd, 8);
     } else {
-        hipExtLaunchKernelGGL((reduce_group_kernel<T, MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
+        ALAN_LAUNCH_EXT((reduce_group_kernel<T, MODE, false>), dim3(gl.grid), dim3(256), 0, stream, ev.start,
                               ev.stop, 0, gd, gl.logG);
     }
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;

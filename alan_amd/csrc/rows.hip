@@ -460,7 +460,7 @@ int launch_rows(const Canon &c, const RowsPlan &rp, int mode, double add_const, 
     const dim3 grid(rp.n_windows, rp.n_chunks);
     const dim3 block(256);
 #define ALAN_ROWS5(MODE, G, V, R, GN, PFV, SH)                                                                  \
-    hipExtLaunchKernelGGL((rows_kernel<MODE, G, V, R, GN, PFV, SH>), grid, block, rp.lds_bytes, stream, ev.start, \
+    ALAN_LAUNCH_EXT((rows_kernel<MODE, G, V, R, GN, PFV, SH>), grid, block, rp.lds_bytes, stream, ev.start, \
                           ev.stop, 0, d)
 #define ALAN_ROWS4(MODE, G, V, R, GN)                    \
     if (rp.p_chunk > 1) {                                \

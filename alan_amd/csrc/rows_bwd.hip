@@ -238,10 +238,10 @@ extern "C" int alan_reduce_backward(const alan_backward_desc_t *b, void *workspa
     if (d.gF || d.part) {
         const dim3 grid(rp.n_windows, bp.n_chunks), block(256);
         switch (rp.logG) {
-            case 0: hipLaunchKernelGGL(rows_backward_kernel<0>, grid, block, lds_bytes, stream, d); break;
-            case 1: hipLaunchKernelGGL(rows_backward_kernel<1>, grid, block, lds_bytes, stream, d); break;
-            case 2: hipLaunchKernelGGL(rows_backward_kernel<2>, grid, block, lds_bytes, stream, d); break;
-            default: hipLaunchKernelGGL(rows_backward_kernel<3>, grid, block, lds_bytes, stream, d); break;
+            case 0: ALAN_LAUNCH(rows_backward_kernel<0>, grid, block, lds_bytes, stream, d); break;
+            case 1: ALAN_LAUNCH(rows_backward_kernel<1>, grid, block, lds_bytes, stream, d); break;
+            case 2: ALAN_LAUNCH(rows_backward_kernel<2>, grid, block, lds_bytes, stream, d); break;
+            default: ALAN_LAUNCH(rows_backward_kernel<3>, grid, block, lds_bytes, stream, d); break;
         }
         if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
     }

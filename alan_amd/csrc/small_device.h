@@ -54,10 +54,15 @@ __device__ __forceinline__ float noise_at(const uint64_t seed, const uint64_t i)
 // workgroups may not have read it yet), so nothing has to wait for anything.
 __device__ __forceinline__ void noise_finish(const NoiseLaunch &n, const uint64_t cell_value, const uint64_t seed) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (n.receipt) n.receipt[0] = cell_value, n.receipt[1] = seed;
+    if (n.receipt) {
+        __hip_atomic_store(n.receipt, cell_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(n.receipt + 1, seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (n.advance) {
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(*n.advance);
-        dst[0] = cell_value + n.advance_by, dst[1] = seed;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(
+            __hip_atomic_load(n.advance, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store(dst, cell_value + n.advance_by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -461,7 +466,12 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
     const bool block = m.block[p] != 0;
     const int logG = m.logG[p];
     const NoiseLaunch &nz = *reinterpret_cast<const NoiseLaunch *>(base + offsetof(SmallMulti, noise));
-    const uint64_t cellv = nz.cell ? nz.cell[0] : 0ull, nseed = nz.cell ? nz.cell[1] : nz.seed;     // (the cell: {counter, seed})
+    // (the cell: {counter, seed}, written by the previous launch that drew -- read past the scalar and vector L1 caches)
+    uint64_t cellv = 0ull, nseed = nz.seed;
+    if (nz.cell) {
+        cellv = __hip_atomic_load(nz.cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nseed = __hip_atomic_load(nz.cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     switch (m.mode[p]) {
         case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE, WT>(d, logG, block, bid); break;
         case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM, WT>(d, logG, block, bid); break;

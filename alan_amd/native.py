@@ -199,6 +199,26 @@ def lib():
         L.alan_exchange_status.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.alan_exchange_destroy.restype = C.c_int
         L.alan_exchange_destroy.argtypes = [C.c_void_p]
+        L.alan_calls_create.restype = C.c_int
+        L.alan_calls_create.argtypes = [C.POINTER(C.c_void_p)]
+        L.alan_calls_add_reduce.restype = C.c_int
+        L.alan_calls_add_reduce.argtypes = [C.c_void_p, C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t]
+        L.alan_calls_add_reduce_batch.restype = C.c_int
+        L.alan_calls_add_reduce_batch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(ReduceDesc)), C.c_int32]
+        L.alan_calls_add_normal_lse.restype = C.c_int
+        L.alan_calls_add_normal_lse.argtypes = [C.c_void_p, C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t]
+        L.alan_calls_add_chain_terms_final.restype = C.c_int
+        L.alan_calls_add_chain_terms_final.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                                                       C.POINTER(ChainNormal), C.POINTER(ChainFinal), C.c_int32, C.c_int64,
+                                                       C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.alan_noise_handon.restype = C.c_int
+        L.alan_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.alan_calls_add_noise_handon.restype = C.c_int
+        L.alan_calls_add_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.alan_calls_replay.restype = C.c_int
+        L.alan_calls_replay.argtypes = [C.c_void_p, C.c_void_p]
+        L.alan_calls_destroy.restype = C.c_int
+        L.alan_calls_destroy.argtypes = [C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -217,7 +237,45 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
            "alan_exchange_create", "alan_exchange_connect", "alan_exchange_sum", "alan_exchange_status",
            "alan_exchange_destroy",
+           "alan_calls_create", "alan_calls_add_reduce", "alan_calls_add_reduce_batch", "alan_calls_add_normal_lse",
+           "alan_calls_add_chain_terms_final", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
+           "alan_calls_destroy",
            "alan_abi_version", "alan_build_target")
+
+
+class CallList:
+    """The library calls of one evaluation, recorded while it is captured into a HIP graph (sample._GraphedELBO) and
+    issued again by one call (alan_calls_replay) where that is the same work as replaying the graph.  ``spoiled``: a
+    library launch the list cannot hold was made (the graph is replayed then)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().alan_calls_create(C.byref(h)), "alan_calls_create")
+        self._h, self.n, self.spoiled, self.keep = h, 0, False, []
+
+    def add(self, rc):
+        if rc != 0:
+            self.spoiled = True
+        self.n += 1
+
+    def replay(self, stream):
+        check(lib().alan_calls_replay(self._h, stream), "alan_calls_replay")
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().alan_calls_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_REC = [None]            # the CallList being recorded (sample._GraphedELBO sets it around its capture pass)
+
+
+def _spoil():
+    if _REC[0] is not None:
+        _REC[0].spoiled = True
 
 EXCHANGE_MAX_RANKS = 8
 EXCHANGE_HANDLE_BYTES = 64
@@ -444,12 +502,28 @@ class GraphNoise:
         j, self.n = self.n, self.n + 1
         return self.state[2 * j:2 * j + 2], self.state[2 * self.MAX_LAUNCHES + j:2 * self.MAX_LAUNCHES + j + 1]
 
+    def finish_capture(self):
+        """Still inside the capture, behind everything that draws.  A single launch that draws cannot hand its state on
+        to its own slot (its other workgroups may not have read it yet): it hands on to a second slot, and a one-thread
+        launch here copies that back to the first."""
+        if self.n == 1:
+            L = lib()
+            a, b = self.state.data_ptr(), self.state.data_ptr() + 16
+            check(L.alan_noise_handon(b, a, current_stream(self.device)), "alan_noise_handon")
+            if _REC[0] is not None:
+                _REC[0].add(L.alan_calls_add_noise_handon(_REC[0]._h, b, a))
+            self.handon = True
+
     def close(self):
-        """After the capture: launch j hands on to slot j + 1, the last one to slot 0."""
+        """After the capture: launch j hands on to slot j + 1, the last one to slot 0 (a single one: to slot 1, which
+        finish_capture's launch copies back)."""
+        if self.n == 1 and not getattr(self, "handon", False):
+            raise NativeError("alan_amd: GraphNoise.finish_capture() was not called inside the capture")
         if self.n:
             base = self.state.data_ptr()
-            ring = [base + 16 * ((j + 1) % self.n) for j in range(self.n)]
+            ring = [base + 16 * ((j + 1) % max(self.n, 2)) for j in range(self.n)]
             self.state[2 * self.MAX_LAUNCHES:2 * self.MAX_LAUNCHES + self.n].copy_(t.tensor(ring, dtype=t.int64))
+            t.cuda.current_stream().synchronize()       # (whatever stream the replays are issued on: the ring is there)
 
     def before_replay(self):
         if not self.per_replay:
@@ -555,7 +629,10 @@ def _launch_fused():
     if not f.prelude and not f.tail:
         rc = L.alan_normal_lse(C.byref(f.desc), None, 0, stream)
         check(rc, "alan_normal_lse")
+        if _REC[0] is not None:
+            _REC[0].add(L.alan_calls_add_normal_lse(_REC[0]._h, C.byref(f.desc), None, 0))
         return
+    _spoil()                                             # (a chained launch: not a call the list holds)
     st = chain_state(f.device)
     if st is None:                                       # (first seen inside a capture: the separate launches)
         _flush_items(f.prelude)
@@ -618,13 +695,18 @@ def _flush_items(items):
         return
     L = lib()
     device = items[0][1]
+    rec = _REC[0]
     if len(items) == 1:
         rc = L.alan_reduce(C.byref(items[0][0]), None, 0, current_stream(device))
         check(rc, "alan_reduce")
+        if rec is not None:
+            rec.add(L.alan_calls_add_reduce(rec._h, C.byref(items[0][0]), None, 0))
         return
     arr = (C.POINTER(ReduceDesc) * len(items))(*[C.pointer(d) for d, _, _ in items])
     rc = L.alan_reduce_batch(arr, len(items), current_stream(device))
     check(rc, "alan_reduce_batch")
+    if rec is not None:
+        rec.add(L.alan_calls_add_reduce_batch(rec._h, arr, len(items)))
 
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
@@ -665,6 +747,9 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     if rc == ERR_UNSUPPORTED and desc.ring_n:
         return False
     check(rc, "alan_reduce")
+    if _REC[0] is not None:
+        _REC[0].keep.append(ws)
+        _REC[0].add(L.alan_calls_add_reduce(_REC[0]._h, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes))
     return True
 
 
@@ -679,6 +764,7 @@ def _noise_key(desc):
 def run_reduce_backward(desc, device):
     """All gradients of an LSE call in one pass (alan_reduce_backward).  False when the problem does not fit
     the streaming kernel -- the caller then falls back to one WEXPSUM launch per factor."""
+    _spoil()
     L = lib()
     flush()
     nbytes = L.alan_reduce_backward_workspace_bytes(C.byref(desc))
@@ -738,12 +824,16 @@ def run_normal_lse(desc, device, keepalive=()):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse")
+    if _REC[0] is not None:
+        _REC[0].keep.append(ws)
+        _REC[0].add(L.alan_calls_add_normal_lse(_REC[0]._h, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes))
     return True
 
 
 def run_normal_lse_backward(desc, device):
     """Every gradient of the fused plate step in one pass (alan_normal_lse_backward).  False when the library
     declines the shape."""
+    _spoil()
     L = lib()
     flush()
     nbytes = L.alan_normal_lse_backward_workspace_bytes(C.byref(desc))
@@ -767,6 +857,7 @@ CHAIN_MAX_BATCH = 65535      # the batch rides on gridDim.y
 def chain_logmmexp(ms, want_chain=False):
     """ms: [T,K,K] or a batch [B,T,K,K] (device tensor) -> (vec[(B,)K], chain[(B,)K,K] or None, tree).
     ``tree`` holds every round of the reference's pairwise tree (what the backward walks)."""
+    _spoil()
     require_device(ms, "timeseries factor")
     L = lib()
     flush()
@@ -836,6 +927,11 @@ def chain_logmmexp_terms(terms, normal=None):
         if rc == ERR_UNSUPPORTED and fin is not None:
             return False
         check(rc, "alan_chain_logmmexp_terms_final")
+        if _REC[0] is not None:
+            _REC[0].keep.append((terms, normal, tree, vec))
+            _REC[0].add(L.alan_calls_add_chain_terms_final(
+                _REC[0]._h, ptrs, strides, len(terms), C.byref(nd) if nd is not None else None,
+                C.byref(fin) if fin is not None else None, code, B, T, K, vec.data_ptr(), tree.data_ptr(), nbytes))
         return True
 
     if CHAIN_FINAL and _Q.depth[0] and _Q.chain is None and B == 1 and 12 < K <= 32 and terms[0].dtype == t.float32 \
@@ -852,6 +948,7 @@ POSTERIOR_MAX_K = 128
 
 def chain_messages(ms):
     """ms [C,T,K,K] fp32 -> backward messages beta [C,T+1,K] (alan_chain_messages: one launch)."""
+    _spoil()
     require_device(ms, "timeseries factor")
     flush()
     C_, T, K, _ = ms.shape
@@ -876,6 +973,7 @@ def chain_sample(ms, beta, init, N, B, chain_of_n, chain_of_b, generator=None):
 
 def chain_filter(ms, init):
     """ms [C,T,K,K], init int64 [N] -> alpha [C,T,N,K]: the forward recursion from each initial state."""
+    _spoil()
     require_device(ms, "timeseries factor")
     flush()
     C_, T, K, _ = ms.shape
@@ -889,6 +987,7 @@ def chain_filter(ms, init):
 def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):
     """Gradient wrt ms [T,K,K] (or [B,T,K,K]) of logsumexp(chain_logmmexp(ms), -1) given grad_vec, and / or of
     chain_logmmexp(ms) given grad_chain -- autograd through utils.py:478-510, walked down the forward's tree."""
+    _spoil()
     require_device(ms, "timeseries factor")
     L = lib()
     batched = ms.ndim == 4

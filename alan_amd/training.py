@@ -44,6 +44,31 @@ def memset_nodes(graph):
         return None
 
 
+def node_kinds(graph):
+    """(kernel nodes, nodes of any other kind but empty ones) of a captured graph, or None when it cannot be inspected."""
+    try:
+        raw = graph.raw_cuda_graph()
+        hip = C.CDLL("libamdhip64.so")
+        n = C.c_size_t(0)
+        if hip.hipGraphGetNodes(C.c_void_p(raw), None, C.byref(n)) != 0:
+            return None
+        nodes = (C.c_void_p * max(1, n.value))()
+        if hip.hipGraphGetNodes(C.c_void_p(raw), nodes, C.byref(n)) != 0:
+            return None
+        kernels = others = 0
+        for nd in nodes[: n.value]:
+            ty = C.c_int(-1)
+            if hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(ty)) != 0:
+                return None
+            if ty.value == 0:                           # hipGraphNodeTypeKernel
+                kernels += 1
+            elif ty.value != 5:                         # (hipGraphNodeTypeEmpty joins branches: no work)
+                others += 1
+        return kernels, others
+    except Exception:
+        return None
+
+
 class GraphCannotBeInspected(GraphContainsMemsetNodes):
     pass
 
@@ -190,6 +215,7 @@ class GraphedStep:
                 self.elbo = self._iteration()
             else:
                 self.elbo = t.stack([self._iteration() for _ in range(unroll)])
+            self.noise.finish_capture()
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedStep", allow_memset_nodes)
 
     def _iteration(self):
@@ -245,16 +271,24 @@ class GraphedEval:
             if self.ring is not None:
                 self.ring.taken = 0
             self.graph = t.cuda.CUDAGraph(keep_graph=True)
-            with N.own_graph_noise(problem.device) as self.noise, \
-                    t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                if unroll == 1:
-                    self.elbo = self._iteration()
-                else:
-                    self.elbo = t.stack([self._iteration().float() for _ in range(unroll)])
+            rec = N.CallList() if S.DIRECT_REPLAY else None
+            N._REC[0] = rec
+            try:
+                with N.own_graph_noise(problem.device) as self.noise, \
+                        t.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                    if unroll == 1:
+                        self.elbo = self._iteration()
+                    else:
+                        self.elbo = t.stack([self._iteration().float() for _ in range(unroll)])
+                    self.noise.finish_capture()
+            finally:
+                N._REC[0] = None
         finally:
             own.__exit__(None, None, None)
             E._RING[0] = None
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedEval")
+        # (sample.DIRECT_REPLAY: the evaluation's library launches issued again one by one where that is all the graph holds)
+        self.calls = S.calls_if_equivalent(self.graph, rec)
         if self.ring is not None:
             how = self.ring.settle(self.elbo)
             if how == "recapture":
@@ -271,8 +305,14 @@ class GraphedEval:
         see GraphedStep.__call__)."""
         self.noise.before_replay()
         if self.ring is None:
-            self.graph.replay()
+            self.replay()
             return self.elbo.clone()
         slot = self.ring.claim()
-        self.graph.replay()
+        self.replay()
         return slot.detach()
+
+    def replay(self):
+        if self.calls is not None:
+            self.calls.replay(t.cuda.current_stream().cuda_stream)
+        else:
+            self.graph.replay()

@@ -151,6 +151,9 @@ typedef struct {
  *            last launch that holds such a problem does the handing on.
  * ALAN_ERR_UNSUPPORTED (nothing enqueued; alan_reduce_check says so beforehand) when the problem does not take the
  * small single-launch kernel: the caller then draws the noise itself. */
+/* (alan_noise_handon, declared below: copies one slot {counter, seed} to another -- for a replayed sequence that holds a
+ * SINGLE launch with generated noise, whose `advance` slot must not be its own cell: the launch hands on to a second
+ * slot and this one-thread launch, anywhere behind it, copies that back.) */
 typedef struct {
     int32_t on;
     uint32_t advance_by;
@@ -448,6 +451,29 @@ int alan_exchange_connect(void *exchange, const unsigned char *handles);
 int alan_exchange_sum(void *exchange, const void *src, void *out, int64_t n, void *stream);
 int alan_exchange_status(void *exchange, uint32_t *completed, uint32_t *failed_at);
 int alan_exchange_destroy(void *exchange);
+
+/* A recorded sequence of alan_reduce / alan_reduce_batch / alan_normal_lse calls, issued again in order by ONE call on
+ * the given stream: for a caller that evaluates the same contraction again and again (Sample.elbo_nograd on a fixed
+ * sample -- logpq.py:68-155 once per call of the reference's runner loop).  Measured against replaying the same launches
+ * as a captured HIP graph on MI355X: 23 us per movielens K=30 evaluation instead of 27 (a graph launch leaves the GPU
+ * idle for several microseconds between two replays; launches issued one by one do not).  alan_calls_add_* plans the
+ * call exactly as the entry point of the same name would and keeps its kernel launches -- kernel, grid, a copy of every
+ * argument (host memory of the library's own) -- WITHOUT issuing them; alan_calls_replay issues the kept launches in
+ * order and plans nothing.  Every device pointer of the descriptors, workspaces included, must stay valid for as long as
+ * the list is replayed.  Descriptors carrying timing events are refused (ALAN_ERR_UNSUPPORTED). */
+int alan_calls_create(void **calls);
+int alan_calls_add_reduce(void *calls, const alan_reduce_desc_t *desc, void *workspace, size_t workspace_bytes);
+int alan_calls_add_reduce_batch(void *calls, const alan_reduce_desc_t *const *descs, int32_t n);
+int alan_calls_add_normal_lse(void *calls, const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes);
+int alan_noise_handon(const void *from, void *to, void *stream);
+int alan_calls_add_noise_handon(void *calls, const void *from, void *to);
+/* (alan_chain_logmmexp_terms_final without out_chain: delivering the chain is a copy, and a list holds launches only) */
+int alan_calls_add_chain_terms_final(void *calls, const void *const *terms, const int64_t *strides, int32_t n_terms,
+                                     const alan_chain_normal_t *normal, const alan_chain_final_t *fin, int32_t dtype,
+                                     int64_t B, int64_t T, int64_t K, void *out_vec, void *workspace,
+                                     size_t workspace_bytes);
+int alan_calls_replay(void *calls, void *stream);
+int alan_calls_destroy(void *calls);
 
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);

@@ -232,3 +232,24 @@ def test_unrolled_graphs_run_their_iterations_in_order_with_fresh_particles():
         assert abs(a - b) <= 1e-4 * abs(a)
     for a, b in zip(p1, p3):
         assert t.allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_graphed_eval_replays_through_its_recorded_launches():
+    """sample() + elbo on movielens is library launches from the noise to the final log-sum-exp: GraphedEval issues them
+    again one by one (sample.DIRECT_REPLAY) -- the same values as its graph would produce under the same seed."""
+    from alan_amd import sample as S
+    prob = _movielens()
+    ev = alan.GraphedEval(prob, 8)
+    assert ev.calls is not None
+    t.manual_seed(2)
+    direct = [float(ev()) for _ in range(5)]
+    S.DIRECT_REPLAY = False
+    try:
+        ev2 = alan.GraphedEval(prob, 8)
+    finally:
+        S.DIRECT_REPLAY = True
+    assert ev2.calls is None
+    t.manual_seed(2)
+    through_graph = [float(ev2()) for _ in range(5)]
+    assert direct == through_graph and len(set(direct)) == 5

@@ -217,8 +217,8 @@ def test_graphed_vi_step_does_not_depend_on_host_synchronisation():
         t.cuda.synchronize()
         return [p.detach().clone() for p in prob.parameters()]
 
-    for a, b in zip(run(True), run(False)):
-        assert t.equal(a, b)
+    for i, (a, b) in enumerate(zip(run(True), run(False))):
+        assert t.equal(a, b), (i, tuple(a.shape), float((a - b).abs().max()), int((a != b).sum()))
 
 
 @pytest.mark.gpu
@@ -843,3 +843,46 @@ def test_own_log_q_gradient_folded_into_the_draw_node_is_the_same_gradient(fixtu
     for n in g0:
         scale = float(g0[n].abs().max()) + 1e-6
         t.testing.assert_close(g1[n], g0[n], rtol=2e-5, atol=2e-6 * scale, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.gpu
+def test_direct_replay_of_the_recorded_library_calls_is_the_graphs_replay(monkeypatch):
+    """sample.DIRECT_REPLAY: a captured evaluation made of library launches alone is replayed by issuing those launches
+    again (alan_calls_replay) -- same values as the graph's own replay and as the eager evaluation, also after a
+    parameter changed in place; an evaluation holding a torch kernel (a model lambda's arithmetic) keeps its graph."""
+    from alan_amd import sample as S
+    g = t.Generator().manual_seed(5)
+    x = t.randn(300, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(300, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 300, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    t.manual_seed(3)
+    sample = prob.sample(30, reparam=False)
+    eager = float(sample.elbo_nograd(graph=False))
+    direct = [float(sample.elbo_nograd(graph=True)) for _ in range(3)]
+    ge = next(iter(sample.__dict__["_graphs"].values()))
+    assert ge.calls is not None and ge.calls.n == 3
+    for v in direct:
+        assert abs(v - eager) <= 2e-6 * abs(eager)
+    with t.no_grad():
+        for p in prob.parameters():
+            p.add_(0.05)
+    moved = float(sample.elbo_nograd(graph=False))
+    again = float(sample.elbo_nograd(graph=True))
+    assert abs(moved - eager) > 1e-3 * abs(eager) and abs(again - moved) <= 2e-6 * abs(moved)
+    # switched off: the graph itself
+    monkeypatch.setattr(S, "DIRECT_REPLAY", False)
+    t.manual_seed(3)
+    s2 = prob.sample(30, reparam=False)
+    v2 = float(s2.elbo_nograd(graph=True))
+    assert next(iter(s2.__dict__["_graphs"].values())).calls is None
+    assert abs(v2 - float(s2.elbo_nograd(graph=False))) <= 2e-6 * abs(v2)
+    monkeypatch.setattr(S, "DIRECT_REPLAY", True)
+    # bus_breakdown's lambdas run torch kernels inside the evaluation: not a list of library calls
+    fx = load_golden("e2e_bus_breakdown_K3.pt")
+    pb = models.BUILDERS["bus_breakdown"](fx).to("cuda")
+    sb = models.sample_from_fixture(pb, fx, "cuda")
+    vb = float(sb.elbo_nograd(graph=True))
+    gb = next(iter(sb.__dict__["_graphs"].values()))
+    assert abs(vb - float(sb.elbo_nograd(graph=False))) <= 1e-6 * abs(vb)
+    print("bus_breakdown replays through", "its call list" if gb.calls is not None else "its graph")

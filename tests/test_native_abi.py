@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 11
+    assert L.alan_abi_version() == 12
     assert L.alan_build_target() == b"gfx950"
 
 
