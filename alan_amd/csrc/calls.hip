@@ -89,6 +89,14 @@ int alan_calls_add_chain_terms_final(void *calls, const void *const *terms, cons
     });
 }
 
+int alan_calls_add_normal_lse_chained(void *calls, const alan_normal_lse_desc_t *desc,
+                                      const alan_reduce_desc_t *const *prelude, int32_t n_prelude,
+                                      const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state) {
+    if (!calls || !desc) return ALAN_ERR_BAD_DESC;
+    if (desc->ev_start || desc->ev_stop) return ALAN_ERR_UNSUPPORTED;
+    return record(calls, [&] { return alan_normal_lse_chained(desc, prelude, n_prelude, tail, n_tail, state, nullptr); });
+}
+
 int alan_noise_handon(const void *from, void *to, void *stream) {
     if (!from || !to || from == to) return ALAN_ERR_BAD_DESC;
     ALAN_LAUNCH(noise_handon_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long *)from,

@@ -211,6 +211,9 @@ def lib():
         L.alan_calls_add_chain_terms_final.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
                                                        C.POINTER(ChainNormal), C.POINTER(ChainFinal), C.c_int32, C.c_int64,
                                                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.alan_calls_add_normal_lse_chained.restype = C.c_int
+        L.alan_calls_add_normal_lse_chained.argtypes = [C.c_void_p, C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32,
+                                                        C.c_void_p]
         L.alan_noise_handon.restype = C.c_int
         L.alan_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.alan_calls_add_noise_handon.restype = C.c_int
@@ -238,7 +241,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_exchange_create", "alan_exchange_connect", "alan_exchange_sum", "alan_exchange_status",
            "alan_exchange_destroy",
            "alan_calls_create", "alan_calls_add_reduce", "alan_calls_add_reduce_batch", "alan_calls_add_normal_lse",
-           "alan_calls_add_chain_terms_final", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
+           "alan_calls_add_chain_terms_final", "alan_calls_add_normal_lse_chained", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
            "alan_calls_destroy",
            "alan_abi_version", "alan_build_target")
 
@@ -632,9 +635,9 @@ def _launch_fused():
         if _REC[0] is not None:
             _REC[0].add(L.alan_calls_add_normal_lse(_REC[0]._h, C.byref(f.desc), None, 0))
         return
-    _spoil()                                             # (a chained launch: not a call the list holds)
     st = chain_state(f.device)
     if st is None:                                       # (first seen inside a capture: the separate launches)
+        _spoil()
         _flush_items(f.prelude)
         check(L.alan_normal_lse(C.byref(f.desc), None, 0, stream), "alan_normal_lse")
         for d, _, _ in f.tail:
@@ -643,6 +646,9 @@ def _launch_fused():
     PA, n, TA, m = f.arrays()
     rc = L.alan_normal_lse_chained(C.byref(f.desc), PA, n, TA, m, st.data_ptr(), stream)
     check(rc, "alan_normal_lse_chained")
+    if _REC[0] is not None:
+        _REC[0].keep.append(st)
+        _REC[0].add(L.alan_calls_add_normal_lse_chained(_REC[0]._h, C.byref(f.desc), PA, n, TA, m, st.data_ptr()))
 
 
 def _try_tail(desc, device, keepalive):

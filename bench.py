@@ -304,6 +304,17 @@ def rows_roofline(K, M, iters=20, traffic_key=None):
             "workload": f"S-ML plate step on a materialised factor, K={K}, M={M}"}
 
 
+def launch_mode(sample, use_graph):
+    """How the timed evaluations were issued: what the captured evaluation of this sample actually replays through."""
+    if not use_graph:
+        return "eager (one Python-driven launch per kernel)"
+    graphs = list(sample.__dict__.get("_graphs", {}).values())
+    if graphs and all(getattr(g, "calls", None) is not None for g in graphs):
+        return ("one captured ELBO evaluation, replayed by issuing its recorded library launches again from one C call "
+                "(alan_calls_replay; the captured HIP graph owns the memory and is what proves the evaluation holds nothing else)")
+    return "HIP graph replay of one captured ELBO evaluation"
+
+
 def cpu_elbo_of(builder, gpu_sample):
     """The same ELBO (same particles) through the CPU oracle -- the parity check of a bench configuration."""
     from oracle import backend
@@ -401,8 +412,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"movielens M={M_USERS} N={N_FILMS} d_z={D_Z}, K={K}, elbo_nograd on a fixed sample",
-                   "launch": "HIP graph replay of one captured ELBO evaluation" if use_graph
-                   else "eager (one Python-driven launch per kernel)",
+                   "launch": launch_mode(sample, use_graph),
                    "plate_step": "fused (alan_normal_lse: producer + log-sum-exp + plate sum in one launch)"
                    if adist.FUSE_PLATE_STEP else "materialised factor (producer kernel + rows kernel)",
                    "computation_strategy": type(strat).__name__ +
