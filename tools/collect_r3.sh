@@ -44,6 +44,11 @@ timeout -k 10 120 python3 tools/exchange_probe.py 2 > $O/exchange_probe.txt 2>&1
 timeout -k 10 60 ./tools/_build/dispatch_probe > $O/dispatch_probe.txt 2>&1 || echo "dispatch probe failed"
 timeout -k 10 200 python3 tools/ts_train_probe.py 30 30 > $O/ts_train.txt 2>&1 || echo "ts train probe failed"
 for b in 0 1; do ALAN_AMD_DEVICE_NOISE=$b timeout -k 10 200 python3 tools/train_step_bench.py 2>/dev/null | grep "graph replay" | sed "s/^/DEVICE_NOISE=$b /"; done > $O/device_noise_ab.txt 2>&1 || echo "noise A/B failed"
+# ---- replays: the GPU's timeline as a graph replay and through the recorded launch list, the probes behind sample.DIRECT_REPLAY
+ALAN_AMD_DIRECT_REPLAY=0 bash tools/replay_trace.sh ml 30 100 > $O/replay_trace_graph.txt 2>&1 || echo "replay trace (graph) failed"
+bash tools/replay_trace.sh ml 30 100 > $O/replay_trace_direct.txt 2>&1 || echo "replay trace (direct) failed"
+timeout -k 10 200 python3 tools/replay_alternate_probe.py 2000 > $O/replay_alternate.txt 2>&1 || echo "alternate probe failed"
+ALAN_AMD_DIRECT_REPLAY=0 timeout -k 10 200 python3 tools/direct_replay_probe.py 2000 > $O/direct_replay_probe.txt 2>&1 || echo "direct replay probe failed"
 # keep what the summariser reads, drop the bulky traces
 find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete
 find $O -path "*case_*" -name "*kernel_trace.csv" -delete

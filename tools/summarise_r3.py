@@ -164,6 +164,10 @@ for src, dst, head in (("chain_bwd_trace_K30.txt", "r3_chain_backward_launches_K
                        ("device_noise_ab.txt", "r3_device_noise_ab.txt", "# tools/train_step_bench.py with dist.DEVICE_NOISE off / on (one process each, same box)\n"),
                        ("exchange_probe.txt", "r3_exchange_probe.txt", "# python3 tools/exchange_probe.py 2: alan_exchange_sum between two processes SHARING this GPU (40 KB partials, 500 exchanges launched one by one): protocol and arithmetic, not the xGMI fabric\n"),
                        ("dispatch_probe.txt", "r3_dispatch_probe.txt", "# tools/dispatch_probe.hip: how long the dispatcher takes to start the 2048 waves of a launch, by workgroup size and register budget\n"),
+                       ("replay_trace_graph.txt", "r3_replay_timeline_graph.txt", "# ALAN_AMD_DIRECT_REPLAY=0 bash tools/replay_trace.sh ml 30 100: the GPU's timeline of movielens K=30 evaluations replayed as a HIP graph (rocprofv3 kernel trace: gap since the previous kernel ended, duration)\n"),
+                       ("replay_trace_direct.txt", "r3_replay_timeline_direct.txt", "# bash tools/replay_trace.sh ml 30 100: the same evaluations replayed through the recorded launch list (alan_calls_replay)\n"),
+                       ("replay_alternate.txt", "r3_replay_alternate_probe.txt", "# python3 tools/replay_alternate_probe.py 2000: 1 / 2 / 4 graphs of the same evaluation replayed in turn\n"),
+                       ("direct_replay_probe.txt", "r3_direct_replay_probe.txt", "# ALAN_AMD_DIRECT_REPLAY=0 python3 tools/direct_replay_probe.py 2000: an evaluation's three library calls issued again from the host (ctypes) against its HIP-graph replay\n"),
                        ("ts_train.txt", "r3_timeseries_training_iteration.txt", "# python3 tools/ts_train_probe.py 30 30: VI / RWS iteration of the Kalman timeseries model (T=1000, K=30) as one replayed graph\n")):
     p = os.path.join(RAW, src)
     if os.path.exists(p):
