@@ -30,7 +30,7 @@ evals = max(int(r["Calls"]) for r in rows if "normal_lse_x3_kernel" in r["Name"]
 with open(os.path.join(OUT, "r3_bench_default_kernel_stats.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extras` (round 3)\n\n"
             "Full CSV: `r3_bench_default_kernel_stats.csv`.  Kernel names truncated.  The run evaluates the movielens K=30 "
-            f"ELBO {evals} times (warm-up, capture, 5 + 50 graph replays, then 50 eager for the per-kernel HIP events).\n\n"
+            f"ELBO {evals} times (warm-up, capture, 5 + 50 replays of the captured evaluation -- through its recorded launch list, sample.DIRECT_REPLAY --, then 50 eager for the per-kernel HIP events).\n\n"
             "| kernel | calls | per eval | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows:
         calls = int(r["Calls"])
