@@ -58,3 +58,29 @@ def test_sync_debug_mode_warns_with_the_word_the_auto_promotion_looks_for():
             t.cuda.set_sync_debug_mode(mode)
     msgs = [str(w.message) for w in seen if "prototype feature" not in str(w.message)]
     assert any("synchroniz" in m.lower() for m in msgs), msgs
+
+
+@pytest.mark.gpu
+def test_cuda_generator_offset_can_be_read_and_moved_from_the_host():
+    """dist._noise_source / native.GraphNoise: torch.cuda.default_generators[i].initial_seed() / get_offset() /
+    set_offset() -- the draws key their in-launch noise by them and move the offset as torch's own kernels would; a
+    captured graph's raw handle, pool and node list (sample.calls_if_equivalent, training.node_kinds)."""
+    gen = t.cuda.default_generators[t.cuda.current_device()]
+    t.manual_seed(123)
+    assert gen.initial_seed() == 123 and gen.get_offset() == 0
+    t.randn(10, device="cuda")
+    moved = gen.get_offset()
+    assert moved > 0 and moved % 4 == 0
+    gen.set_offset(moved + 64)
+    assert gen.get_offset() == moved + 64
+    from alan_amd.training import node_kinds
+    x = t.zeros(8, device="cuda")
+    s = t.cuda.Stream()
+    with t.cuda.stream(s):
+        x.add_(1.0)
+        t.cuda.synchronize()
+        g = t.cuda.CUDAGraph(keep_graph=True)
+        with t.cuda.graph(g, stream=s):
+            x.add_(1.0)
+            x.mul_(2.0)
+    assert node_kinds(g) == (2, 0) and g.pool() is not None
