@@ -646,12 +646,16 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
     if (n > 64) return ALAN_ERR_UNSUPPORTED;
     // generated noise (alan_noise_t): every such problem must be of the small kind (found out before anything is launched),
     // all of them name the same generator, and the last launch that holds one advances its counter
-    const alan_noise_t *nz = nullptr;
+    const alan_noise_t *nz = nullptr, *carry = nullptr;
     int last_noise = -1;
     bool grp_noise = false, grp_last = false;
     for (int i = 0; i < n; ++i) {
         const alan_noise_t &z = descs[i]->noise;
         if (!z.on) continue;
+        if (z.on == 2) {                 // a hand-on carried by this batch's first small-problem launch (alan_noise_t)
+            carry = &z;
+            continue;
+        }
         SmallDesc ts;
         GroupLaunch tg;
         int tm;
@@ -662,9 +666,25 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
             return ALAN_ERR_BAD_DESC;
         nz = &z, last_noise = i;
     }
+    if (carry) {
+        if (nz) return ALAN_ERR_BAD_DESC;                // (not beside problems that draw: they hand on themselves)
+        bool any_small = false;
+        for (int i = 0; i < n && !any_small; ++i) {
+            SmallDesc ts;
+            GroupLaunch tg;
+            int tm;
+            any_small = descs[i]->mode != ALAN_MODE_BERNOULLI_LINEAR && prepare_small(*descs[i], ts, tg, tm);
+        }
+        if (!any_small) return ALAN_ERR_UNSUPPORTED;     // (nothing launched)
+    }
     auto flush_small = [&]() -> int {
         int rc = ALAN_OK;
-        if (m >= 2 || (m == 1 && grp_noise))
+        if (carry && m >= 1) {
+            alan_noise_t c = *carry;                     // {cell -> *advance}: advance_by = 0, no receipt
+            c.on = 1, c.advance_by = 0, c.receipt = nullptr;
+            rc = launch_small_multi(sd, gl, mode, m, stream, have_lin ? &lin : nullptr, &c, true);
+            carry = nullptr;
+        } else if (m >= 2 || (m == 1 && grp_noise))
             rc = launch_small_multi(sd, gl, mode, m, stream, have_lin ? &lin : nullptr, grp_noise ? nz : nullptr, grp_last);
         else if (m == 1)
             rc = alan_reduce(descs[lone], nullptr, 0, stream_);
@@ -696,7 +716,7 @@ extern "C" int alan_reduce_batch(const alan_reduce_desc_t *const *descs, int32_t
             }
         } else {
             other[i] = !prepare_small(*descs[i], sd[m], gl[m], mode[m]);
-            if (!other[i] && descs[i]->noise.on) {
+            if (!other[i] && descs[i]->noise.on == 1) {
                 sd[m].noise_on = 1, sd[m].noise_off = descs[i]->noise.offset;
                 grp_noise = true;
                 if (i == last_noise) grp_last = true;
@@ -831,11 +851,11 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
     }
     uint32_t keep, red, plate;
     const int rc = classify(*d, keep, red, plate);
-    if (rc == ALAN_OK && d->noise.on) {                  // generated noise: the small kernel or nothing
+    if (rc == ALAN_OK && d->noise.on) {                  // generated noise (or a carried hand-on): the small kernel or nothing
         SmallDesc sd;
         GroupLaunch gl;
         int mode;
-        if (d->mode != ALAN_MODE_AFFINE && d->mode != ALAN_MODE_DOT) return ALAN_ERR_BAD_DESC;
+        if (d->noise.on != 2 && d->mode != ALAN_MODE_AFFINE && d->mode != ALAN_MODE_DOT) return ALAN_ERR_BAD_DESC;
         return prepare_small(*d, sd, gl, mode) ? ALAN_OK : ALAN_ERR_UNSUPPORTED;
     }
     return rc;
@@ -913,6 +933,10 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     uint32_t keep, red, plate;
     int rc = classify(*d, keep, red, plate);
     if (rc != ALAN_OK) return rc;
+    if (d->noise.on == 2) {                              // a carried hand-on: as a batch of one
+        const alan_reduce_desc_t *one = d;
+        return alan_reduce_batch(&one, 1, stream_);
+    }
     if (d->noise.on) {                                   // generated noise: the small kernel or nothing
         SmallDesc sd;
         GroupLaunch gl;

@@ -495,21 +495,39 @@ class GraphNoise:
         self.device = device
         self.state = t.zeros(3 * self.MAX_LAUNCHES, dtype=t.int64, device=device)     # slots [MAX][2], then the ring's addresses
         self.n = 0                   # captured launches that draw
+        self.handon = False          # the single-launch hand-on has been arranged (carried by a batch, or a launch of its own)
         self.per_replay = 0          # counter increments of one replay (summed while capturing)
         self._expect = None
 
     def next_launch(self):
-        """(cell, advance) of the next captured launch that draws, or None when the ring is full."""
-        if self.n >= self.MAX_LAUNCHES:
+        """(cell, advance) of the next captured launch that draws, or None when the ring is full (its last address word
+        belongs to a carried hand-on)."""
+        if self.n >= self.MAX_LAUNCHES - 1:
             return None
         j, self.n = self.n, self.n + 1
         return self.state[2 * j:2 * j + 2], self.state[2 * self.MAX_LAUNCHES + j:2 * self.MAX_LAUNCHES + j + 1]
+
+    def carry(self, items):
+        """A batch of queued launches issued inside the capture, behind the only launch that drew so far: its first
+        small-problem launch also copies slot 1 back to slot 0 (alan_noise_t.on = 2) -- the hand-on without a launch of
+        its own.  (Should more launches draw later on, the last of them writes slot 0 after this copy: the ring is whole
+        either way.)"""
+        L = lib()
+        for d, dev, _ in items:
+            if dev.type != self.device.type:
+                return
+            z = d.noise
+            z.on, z.cell, z.advance = 2, self.state.data_ptr() + 16, self.state.data_ptr() + 8 * (3 * self.MAX_LAUNCHES - 1)
+            if L.alan_reduce_check(C.byref(d)) == 0 and d.mode != MODE_BERNOULLI_LINEAR:
+                self.handon = True
+                return
+            z.on, z.cell, z.advance = 0, None, None
 
     def finish_capture(self):
         """Still inside the capture, behind everything that draws.  A single launch that draws cannot hand its state on
         to its own slot (its other workgroups may not have read it yet): it hands on to a second slot, and a one-thread
         launch here copies that back to the first."""
-        if self.n == 1:
+        if self.n == 1 and not self.handon:
             L = lib()
             a, b = self.state.data_ptr(), self.state.data_ptr() + 16
             check(L.alan_noise_handon(b, a, current_stream(self.device)), "alan_noise_handon")
@@ -520,10 +538,11 @@ class GraphNoise:
     def close(self):
         """After the capture: launch j hands on to slot j + 1, the last one to slot 0 (a single one: to slot 1, which
         finish_capture's launch copies back)."""
-        if self.n == 1 and not getattr(self, "handon", False):
+        if self.n == 1 and not self.handon:
             raise NativeError("alan_amd: GraphNoise.finish_capture() was not called inside the capture")
         if self.n:
             base = self.state.data_ptr()
+            self.state[3 * self.MAX_LAUNCHES - 1:3 * self.MAX_LAUNCHES].copy_(t.tensor([base], dtype=t.int64))   # (carry's target: slot 0)
             ring = [base + 16 * ((j + 1) % max(self.n, 2)) for j in range(self.n)]
             self.state[2 * self.MAX_LAUNCHES:2 * self.MAX_LAUNCHES + self.n].copy_(t.tensor(ring, dtype=t.int64))
             t.cuda.current_stream().synchronize()       # (whatever stream the replays are issued on: the ring is there)
@@ -702,6 +721,9 @@ def _flush_items(items):
     L = lib()
     device = items[0][1]
     rec = _REC[0]
+    st = _GRAPH_NOISE[0]
+    if st is not None and st.n == 1 and not st.handon and not any(d.noise.on for d, _, _ in items):
+        st.carry(items)                                   # (the single launch that drew hands on through this batch's launch)
     if len(items) == 1:
         rc = L.alan_reduce(C.byref(items[0][0]), None, 0, current_stream(device))
         check(rc, "alan_reduce")

@@ -149,6 +149,9 @@ typedef struct {
  *            read on the device, so the caller can close the ring of slots after a capture has ended.  In
  *            alan_reduce_batch every problem with noise must name the same seed / cell / receipt / advance; the batch's
  *            last launch that holds such a problem does the handing on.
+ *   on = 2   on a problem of ANY mode, beside no problem that draws: the problem itself is computed as usual and the
+ *            launch that carries it also copies {counter, seed} from `cell` to the slot `advance` names (seed, offset,
+ *            receipt, advance_by ignored) -- alan_noise_handon without a launch of its own.
  * ALAN_ERR_UNSUPPORTED (nothing enqueued; alan_reduce_check says so beforehand) when the problem does not take the
  * small single-launch kernel: the caller then draws the noise itself. */
 /* (alan_noise_handon, declared below: copies one slot {counter, seed} to another -- for a replayed sequence that holds a

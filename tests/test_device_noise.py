@@ -156,6 +156,11 @@ def test_replayed_graph_draws_what_the_iterations_launched_one_by_one_would():
     prob = _movielens()
     ev = alan.GraphedEval(prob, 8)
     assert ev.noise.per_replay > 0
+    # (one launch draws: it hands its state on through a second slot, copied back by the producers' launch -- no launch of
+    # its own for that, alan_noise_t.on = 2)
+    assert ev.noise.n == 1 and ev.noise.handon
+    from alan_amd.training import node_kinds
+    assert node_kinds(ev.graph) == (4, 0)                # draws, producers (+ hand-on), plate step, final log-sum-exp
     t.manual_seed(21)
     first = [float(ev()) for _ in range(4)]
     t.manual_seed(21)
