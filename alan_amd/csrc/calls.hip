@@ -97,6 +97,11 @@ int alan_calls_add_normal_lse_chained(void *calls, const alan_normal_lse_desc_t 
     return record(calls, [&] { return alan_normal_lse_chained(desc, prelude, n_prelude, tail, n_tail, state, nullptr); });
 }
 
+int alan_calls_add_exchange_sum(void *calls, void *exchange, const void *src, void *out, int64_t n) {
+    if (!calls) return ALAN_ERR_BAD_DESC;
+    return record(calls, [&] { return alan_exchange_sum(exchange, src, out, n, nullptr); });
+}
+
 int alan_noise_handon(const void *from, void *to, void *stream) {
     if (!from || !to || from == to) return ALAN_ERR_BAD_DESC;
     ALAN_LAUNCH(noise_handon_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long *)from,

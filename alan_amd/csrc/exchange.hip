@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
-#include "alan_mi355.h"
+#include "common.h"
 
 namespace alan {
 
@@ -173,7 +173,7 @@ int alan_exchange_sum(void* exchange, const void* src, void* out, int64_t n, voi
     d.state = (unsigned*)((char*)e->base + ib + 128);
     d.src = (const float*)src, d.out = (float*)out;
     d.world = e->world, d.rank = e->rank, d.n = (int)n, d.capacity = e->capacity, d.spin_ticks = e->spin_ticks;
-    hipLaunchKernelGGL(exchange_sum_kernel, dim3(e->world), dim3(EX_THREADS), 0, (hipStream_t)stream, d);
+    ALAN_LAUNCH(exchange_sum_kernel, dim3(e->world), dim3(EX_THREADS), 0, (hipStream_t)stream, d);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 

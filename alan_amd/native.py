@@ -214,6 +214,8 @@ def lib():
         L.alan_calls_add_normal_lse_chained.restype = C.c_int
         L.alan_calls_add_normal_lse_chained.argtypes = [C.c_void_p, C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32,
                                                         C.c_void_p]
+        L.alan_calls_add_exchange_sum.restype = C.c_int
+        L.alan_calls_add_exchange_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.alan_noise_handon.restype = C.c_int
         L.alan_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.alan_calls_add_noise_handon.restype = C.c_int
@@ -241,7 +243,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_exchange_create", "alan_exchange_connect", "alan_exchange_sum", "alan_exchange_status",
            "alan_exchange_destroy",
            "alan_calls_create", "alan_calls_add_reduce", "alan_calls_add_reduce_batch", "alan_calls_add_normal_lse",
-           "alan_calls_add_chain_terms_final", "alan_calls_add_normal_lse_chained", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
+           "alan_calls_add_chain_terms_final", "alan_calls_add_normal_lse_chained", "alan_calls_add_exchange_sum", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
            "alan_calls_destroy",
            "alan_abi_version", "alan_build_target")
 
@@ -314,6 +316,9 @@ class Exchange:
                                      t.cuda.current_stream(x.device).cuda_stream)
         if rc != 0:
             raise NativeError(f"alan_exchange_sum failed ({rc})")
+        if _REC[0] is not None:
+            _REC[0].keep.append((x, out))
+            _REC[0].add(lib().alan_calls_add_exchange_sum(_REC[0]._h, self._h, x.data_ptr(), out.data_ptr(), x.numel()))
         return out
 
     def status(self):

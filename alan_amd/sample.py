@@ -104,7 +104,9 @@ class _GraphedELBO:
                     c = collective_memset_nodes(grp, numel, dtype, device)
                     expected = None if (c is None or expected is None) else expected + c
             check_no_memset_nodes(self.graph, "Sample.elbo_nograd(graph=True)", expected=expected)
-            self.calls = self._direct(rec, side) if (rec is not None and not getattr(strategy, "sharded", lambda: False)()) else None
+            # (a sharded evaluation whose collective is the library's own one-shot exchange is library launches too; one
+            # that went through RCCL keeps its graph)
+            self.calls = self._direct(rec, side) if (rec is not None and ALL_REDUCES[0] == n_collectives) else None
         finally:
             own.__exit__(None, None, None)
             N._TIMER[0] = timer

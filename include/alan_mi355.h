@@ -471,6 +471,7 @@ int alan_calls_add_normal_lse(void *calls, const alan_normal_lse_desc_t *desc, v
 int alan_calls_add_normal_lse_chained(void *calls, const alan_normal_lse_desc_t *desc,
                                       const alan_reduce_desc_t *const *prelude, int32_t n_prelude,
                                       const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state);
+int alan_calls_add_exchange_sum(void *calls, void *exchange, const void *src, void *out, int64_t n);
 int alan_noise_handon(const void *from, void *to, void *stream);
 int alan_calls_add_noise_handon(void *calls, const void *from, void *to);
 /* (alan_chain_logmmexp_terms_final without out_chain: delivering the chain is a copy, and a list holds launches only) */

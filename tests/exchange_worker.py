@@ -84,6 +84,7 @@ def run(rank, world, port, out_path, what="direct"):
             strat = alan.Split("plate_1", 150, shard=True)
             one_shot = float(sample.elbo_nograd(strat, graph=False))
             graphed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(3)]
+            res["direct"] = next(iter(sample.__dict__["_graphs"].values())).calls is not None
             S.ONE_SHOT_EXCHANGE = False
             through_gloo = float(sample.elbo_nograd(strat, graph=False))
             alone = float(sample.elbo_nograd(alan.Split("plate_1", 150), graph=False))

@@ -49,6 +49,7 @@ def test_sharded_split_through_the_one_shot_exchange():
         assert r["bad"] == 0, r
         assert r["one_shot"] == r["through_gloo"], r
         assert all(g == r["one_shot"] for g in r["graphed"]), r
+        assert r["direct"], r          # (the exchange is a library launch: the replays went through the recorded launch list)
         assert abs(r["one_shot"] - r["alone"]) <= 2e-6 * abs(r["alone"]), r
         assert r["grad_err"] < 1e-3, r
     assert res[0]["one_shot"] == res[1]["one_shot"]
