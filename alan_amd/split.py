@@ -220,6 +220,12 @@ def exchange_for(group=None):
             dist.all_gather_object(got, mine, group=group)
             return got
         ex = N.Exchange(world, rank, ONE_SHOT_CAPACITY, carry)
+        # (the library's device code is loaded at its first launch -- hundreds of milliseconds a peer's bounded wait
+        # should not be spent on: one trivial launch here, then the barrier)
+        scratch = t.zeros(4, dtype=t.int64, device=t.device("cuda", t.cuda.current_device()))
+        N.check(N.lib().alan_noise_handon(scratch.data_ptr(), scratch.data_ptr() + 16, N.current_stream(scratch.device)),
+                "alan_noise_handon")
+        t.cuda.synchronize()
         dist.barrier(group=group)                         # (every rank has opened every inbox: deliveries may start)
         _EXCHANGES[key] = ex
     return ex

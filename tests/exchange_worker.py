@@ -22,6 +22,7 @@ def run(rank, world, port, out_path, what="direct"):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["ALAN_AMD_ONE_SHOT"] = "1"
+    os.environ.setdefault("ALAN_EXCHANGE_SPIN_MS", "20000")       # (ranks time-slicing ONE GPU: generous waits)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     res = {"rank": rank}
     try:

@@ -35,6 +35,11 @@ def clock(label, fn, sync_every=200):
 
 strat = alan.checkpoint
 clock("sample.elbo_nograd(graph=True)  [everything]", lambda: sample.elbo_nograd(graph=True))
+side = t.cuda.Stream()
+side.wait_stream(t.cuda.current_stream())
+with t.cuda.stream(side):                           # (not the legacy default stream)
+    clock("  the same on a stream of its own", lambda: sample.elbo_nograd(graph=True))
+t.cuda.current_stream().wait_stream(side)
 clock("  _graph_key(strategy)", lambda: sample._graph_key(strat))
 clock("  _graphed(strategy)  [key + dict]", lambda: sample._graphed(strat))
 clock("  ring.claim()", lambda: ge.ring.claim())
