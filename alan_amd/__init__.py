@@ -37,19 +37,3 @@ from .training import GraphedStep, GraphedEval
 
 samplers = [CategoricalSampler, PermutationSampler]
 
-
-def _prefer_rocblas():
-    """Model lambdas such as movielens' ``z @ x`` become tiny batched GEMMs ([300,30,18] x [300,18,5]) inside the
-    evaluation; torch's default BLAS backend on ROCm (hipBLASLt) runs that one in 9.3 us, rocBLAS in 3.3 us
-    (tools/small_bmm_probe.py) -- 8 % of a K=30 evaluation.  ALAN_AMD_KEEP_BLAS=1 leaves torch's choice alone."""
-    import os
-    import torch
-    if os.environ.get("ALAN_AMD_KEEP_BLAS") == "1" or not torch.cuda.is_available():
-        return
-    try:
-        torch.backends.cuda.preferred_blas_library("hipblas")
-    except Exception:       # an older / differently built torch: nothing to prefer
-        pass
-
-
-_prefer_rocblas()

@@ -1511,16 +1511,8 @@ extern "C" size_t alan_chain_batched_workspace_bytes(int64_t B, int64_t T, int64
     return tree_layout(B, T, K, elt_of(dtype)).bytes;
 }
 
-extern "C" size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
-    return alan_chain_batched_workspace_bytes(1, T, K, dtype);
-}
-
 extern "C" size_t alan_chain_backward_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype) {
     return alan_chain_batched_workspace_bytes(B, T, K, dtype);     // one gradient per tree node
-}
-
-extern "C" size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype) {
-    return alan_chain_batched_workspace_bytes(1, T, K, dtype);
 }
 
 extern "C" int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K, int64_t sB,
@@ -1564,28 +1556,6 @@ extern "C" int alan_chain_logmmexp_terms_final(const void *const *terms, const i
     return ALAN_ERR_BAD_DESC;
 }
 
-extern "C" int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
-                                                const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T,
-                                                int64_t K, void *out_chain, void *out_vec, void *workspace,
-                                                size_t workspace_bytes, void *stream) {
-    return alan_chain_logmmexp_terms_final(terms, strides, n_terms, normal, nullptr, dtype, B, T, K, out_chain, out_vec,
-                                           workspace, workspace_bytes, stream);
-}
-
-extern "C" int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
-                                         int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
-                                         void *workspace, size_t workspace_bytes, void *stream) {
-    return alan_chain_logmmexp_terms_normal(terms, strides, n_terms, nullptr, dtype, B, T, K, out_chain, out_vec, workspace,
-                                            workspace_bytes, stream);
-}
-
-extern "C" int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,
-                                   int64_t sRow, int64_t sCol, void *out_chain, void *out_vec,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
-    return alan_chain_logmmexp_batched(ms, dtype, 1, T, K, 0, sT, sRow, sCol, out_chain, out_vec, workspace,
-                                       workspace_bytes, stream);
-}
-
 extern "C" int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                                     int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
                                                     const void *tree, const void *out_vec, const void *grad_vec,
@@ -1603,10 +1573,3 @@ extern "C" int alan_chain_logmmexp_backward_batched(const void *ms, int32_t dtyp
     return ALAN_ERR_BAD_DESC;
 }
 
-extern "C" int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K, int64_t sT,
-                                            int64_t sRow, int64_t sCol, const void *tree, const void *out_vec,
-                                            const void *grad_vec, const void *grad_chain, void *grad_ms,
-                                            void *workspace, size_t workspace_bytes, void *stream) {
-    return alan_chain_logmmexp_backward_batched(ms, dtype, 1, T, K, 0, sT, sRow, sCol, tree, out_vec, grad_vec,
-                                                grad_chain, grad_ms, workspace, workspace_bytes, stream);
-}

@@ -4,7 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <functional>
+#include <memory>
 #include <tuple>
 #include <vector>
 #include "alan_mi355.h"
@@ -20,11 +20,35 @@ inline int env_knob(const char *name) {
 }
 
 // Every kernel launch of the library goes through alan_launch: normally straight to hipLaunchKernelGGL (or its event-
-// carrying form), but while a call list is being recorded (calls.hip: alan_calls_add_*) the launch is NOT issued -- it is
-// kept, kernel and grid and a copy of every argument, to be issued by alan_calls_replay: all the host-side planning
-// of a call happens once.
+// carrying form), but while a call list is being recorded on this thread (calls.hip: alan_calls_begin .. alan_calls_end)
+// the launch is NOT issued -- it is kept, kernel and grid and a copy of every argument, to be issued by alan_calls_replay
+// (or by the issuing threads of an alan_pipeline): all the host-side planning of a call happens once.  A kept launch goes
+// out through hipModuleLaunchKernel on the hipFunction_t looked up when it was recorded: 2.4 us of host time against 3.4
+// for hipLaunchKernelGGL, which looks the function up on every call (tools/launch_cost_probe.hip).
+struct KeptLaunch {
+    hipFunction_t fn = nullptr;
+    dim3 grid, block;
+    uint32_t lds = 0;
+    void **params = nullptr;
+    virtual ~KeptLaunch() {}
+    inline hipError_t issue(hipStream_t st) const {
+        return hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds, st, params, nullptr);
+    }
+};
+template <typename... KArgs>
+struct KeptLaunchOf : KeptLaunch {
+    std::tuple<std::decay_t<KArgs>...> held;
+    void *ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    template <typename... Args>
+    explicit KeptLaunchOf(const Args &...a) : held(a...) {
+        int i = 0;
+        std::apply([&](auto &...x) { ((ptrs[i++] = (void *)&x), ...); }, held);
+        params = ptrs;
+    }
+};
 struct LaunchRecorder {
-    std::vector<std::function<void(hipStream_t)>> launches;
+    std::vector<std::unique_ptr<KeptLaunch>> launches;
+    bool failed = false;              // a launch that cannot be kept (timing events, no function handle) was made
 };
 extern thread_local LaunchRecorder *g_launch_recorder;
 
@@ -32,10 +56,14 @@ template <typename... KArgs, typename... Args>
 inline void alan_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t e0,
                         hipEvent_t e1, const Args &...args) {
     if (g_launch_recorder) {
-        std::tuple<std::decay_t<KArgs>...> held(args...);
-        g_launch_recorder->launches.emplace_back([kernel, grid, block, lds, held](hipStream_t st) {
-            std::apply([&](const auto &...a) { hipLaunchKernelGGL(kernel, grid, block, lds, st, a...); }, held);
-        });
+        auto k = std::make_unique<KeptLaunchOf<KArgs...>>(args...);
+        if (e0 || e1 || hipGetFuncBySymbol(&k->fn, (const void *)kernel) != hipSuccess) {
+            (void)hipGetLastError();
+            g_launch_recorder->failed = true;
+            return;
+        }
+        k->grid = grid, k->block = block, k->lds = (uint32_t)lds;
+        g_launch_recorder->launches.emplace_back(std::move(k));
         return;
     }
     if (e0 || e1)

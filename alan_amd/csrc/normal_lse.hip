@@ -22,10 +22,6 @@ struct NLDesc {
     const float *val, *loc, *scl;
     float *part;                      // [n_chunks][NL][NS]
     float *lse;                       // optional [M][NL][NS]: the per-plate-element log-sum-exp (the backward's input)
-    float *out;                       // with counters: the last workgroup of a column of the grid adds up the chunks
-    int32_t *counters;                //   [gridDim.x] arrival counters, zero on entry, left zero (nullptr: second stage)
-    int64_t o_sl, o_ss;
-    float add_const;
     int32_t M, NK, NL, NS, E, m_chunk, n_small, log_scale;
     int64_t v_sm, v_sk, v_se, l_sl, l_se, s_ss, s_se;
     const float *small[4];
@@ -77,7 +73,7 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     const int nlg = (d.NL + NLW - 1) / NLW;           // groups of NLW loc rows
     const int q = blockIdx.x * 4 + wave;              // (group of loc rows, group of NST scale tiles) of this wave
     const bool wave_on = q < nlg * nsg;
-    if (!wave_on && !d.counters) return;              // (no barriers unless the chunks are combined in this launch)
+    if (!wave_on) return;
     const int lgp = wave_on ? q / nsg : 0, sg = wave_on ? q - lgp * nsg : 0;
     const int l = lgp * NLW;                          // first loc row of the wave
     // the small factors ride in the LAST step's spare element: half-wave 0 when the events leave both elements of
@@ -431,49 +427,6 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
         if (wave_on && h == 0 && s < NS && l + lw < d.NL) d.part[((int64_t)blockIdx.y * d.NL + l + lw) * NS + s] = accm[u];
     }
     if (RAG && wave_on && lane < 16 && s16 < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s16] = accm[NU - 1];
-    if (!d.counters) return;
-    // ---- the chunks of the plate are combined in this launch: the workgroup that arrives LAST at its column's
-    // counter adds them up, in chunk order (deterministic).  Agent-scope release / acquire as the inter-workgroup
-    // hand-off needs on gfx950 (per-XCD L2s are not coherent): every storing wave drains its stores, the workgroup
-    // barrier, ONE lane's release fence, then the relaxed ticket; the last arriver's acquire fence before its loads.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *flag = reinterpret_cast<int *>(lds + 4 * 32 * 33);
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int prev = __hip_atomic_fetch_add(&d.counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (int)gridDim.y - 1;
-        if (last) {
-            __hip_atomic_store(&d.counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    // this workgroup's outputs: waves -> (loc-row group, sg), lanes -> scale rows; 4 * NU * 32 sums of gridDim.y partials
-    for (int i = tid; i < 4 * NU * 32; i += 256) {
-        const int w = i / (NU * 32), r0 = i - w * (NU * 32), lw = r0 / (NST * 32), r = r0 - lw * (NST * 32);
-        const int qq = blockIdx.x * 4 + w;
-        if (qq >= nlg * nsg) continue;
-        const int ll = (qq / nsg) * NLW + lw, ss = 32 * ((qq - (qq / nsg) * nsg) * NST) + r;
-        if (ss >= NS || ll >= d.NL) continue;
-        const float *pp = d.part + (int64_t)ll * NS + ss;
-        const int64_t cs = (int64_t)d.NL * NS;
-        float tot = 0.f;
-        int c = 0;
-        for (; c + 16 <= (int)gridDim.y; c += 16) {           // 16 loads in flight, added in chunk order
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = pp[(c + u) * cs];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) tot += v[u];
-        }
-        for (; c < (int)gridDim.y; ++c) tot += pp[c * cs];
-        d.out[(int64_t)ll * d.o_sl + (int64_t)ss * d.o_ss] = tot + d.add_const;
-    }
 }
 
 template <int EQ, int NST, int NLW, bool FLAT>
@@ -523,7 +476,7 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16 && rag_knob != 0;
     // the bf16x3 kernel (default): contiguous value rows (its staged loads), the chunks added by a second launch
     static const int f32_knob = env_knob("ALAN_NLSE_F32");                            // ablation knob: 1 = the f32 MFMA kernel
-    p.x3 = a.v_se == 1 && a.v_sk == a.E && !a.counters && f32_knob != 1 && env_stage_ok() &&
+    p.x3 = a.v_se == 1 && a.v_sk == a.E && f32_knob != 1 && env_stage_ok() &&
            a.l_sl >= 0 && a.l_se >= 0 && a.s_ss >= 0 && a.s_se >= 0 &&                   // (its 32-bit lane offsets)
            a.NL * a.l_sl + a.E * a.l_se < (1ll << 31) && a.NS * a.s_ss + a.E * a.s_se < (1ll << 31) &&
            a.v_sm >= 0 && a.v_sm < (1ll << 31) && a.NL <= 65535;
@@ -581,7 +534,7 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
 
 namespace alan {
 
-// What a launch of the bf16x3 kernel needs, for alan_normal_lse and for the chained launch (normal_lse_chain.hip):
+// What a launch of the bf16x3 kernel needs:
 // ALAN_ERR_UNSUPPORTED when the kernel declines the call (the f32 kernel, or the caller's other route, takes it).
 int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o) {
     NLPlan p;
@@ -633,7 +586,7 @@ extern "C" size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *
 }
 
 extern "C" int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *a) {
-    if (!a || a->counters) return 0;
+    if (!a) return 0;
     NLPlan p;
     if (plan_nl(*a, p) != ALAN_OK) return 0;
     return p.n_chunks;
@@ -647,7 +600,6 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     int rc = plan_nl(*a, p);
     if (rc != ALAN_OK) return rc;
     const bool keep = a->keep_partials != 0;
-    if (keep && a->counters) return ALAN_ERR_BAD_DESC;
     if (!keep && (!workspace || workspace_bytes < p.part_bytes)) return ALAN_ERR_WORKSPACE;
     NLDesc d;
     std::memset(&d, 0, sizeof(d));
@@ -669,10 +621,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     // the staged variant needs the tile's 32 rows to be one contiguous run of the value tensor
     const bool stage = a->v_se == 1 && a->v_sk == a->E && env_stage_ok();
     const bool rag = p.rag && stage;
-    const size_t lds = 4 * 32 * 33 * sizeof(float) + 16;          // the waves' value tiles + the combine's flag
-    d.counters = (int32_t *)a->counters;
-    d.out = (float *)a->out, d.o_sl = a->o_sl, d.o_ss = a->o_ss, d.add_const = (float)a->add_const;
-    if (d.counters && (int64_t)p.grid.x > a->n_counters) return ALAN_ERR_BAD_DESC;
+    const size_t lds = 4 * 32 * 33 * sizeof(float);               // the waves' value tiles
     auto launch = [&](auto kern) {
         ALAN_LAUNCH_EXT(kern, p.grid, dim3(256), lds, stream, (hipEvent_t)a->ev_start, (hipEvent_t)a->ev_stop, 0, d);
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
@@ -742,7 +691,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
 #undef NL_CASE
     }
     if (rc != ALAN_OK) return rc;
-    if (d.counters || keep) return ALAN_OK;           // (the chunks were combined by the launch itself / are the caller's to add)
+    if (keep) return ALAN_OK;                         // (the chunks are the caller's to add)
 
     // ---- second stage: out[l, s] = sum_chunk part[chunk, l, s] + add_const
     Canon s2;

@@ -1,6 +1,5 @@
-// The fused plate step on the bf16 matrix instructions (the default kernel of alan_normal_lse) as an inline device body,
-// shared by its plain launch (normal_lse.hip) and the chained launch that also runs the queued producers and the parent's
-// contraction (normal_lse_chain.hip).  gfx950 only.
+// The fused plate step on the bf16 matrix instructions (the default kernel of alan_normal_lse; launched by normal_lse.hip).
+// gfx950 only.
 #pragma once
 #include "common.h"
 
@@ -105,56 +104,10 @@ int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o);
 // the loc rows and add up their partial sums through LDS, so a launch leaves gridDim.z partial results per output (34
 // at K = 30 where the first build left 150) for the consumer to add.  Slice c = plate elements [c M / n_sub,
 // (c + 1) M / n_sub).  The value tile is staged as in the f32 kernel (STAGE): contiguous rows only.
-//
-// CHAIN (normal_lse_chain.hip): the small factors are written by other workgroups of the SAME launch (write-through
-// stores, then an agent-scope add to *pre_done): thread 0 polls that counter in front of the workgroup's barrier -- a
-// bounded spin; past the bound the launch's results are NaN and *pre_fail is set -- and every load of a small factor is
-// an `sc1` load issued behind that barrier; the partial sums leave as write-through stores (the launch's last workgroup
-// reads them).  bx, by, bz: the workgroup's place in the (scale-tile group, loc-row group, slice group) grid.
-struct X3Chain {
-    const int32_t *pre_done;          // arrivals of the prelude's workgroups
-    int32_t *pre_fail;
-    int32_t pre_n;                    // how many there are (0: none to wait for)
-};
-
-// REC (normal_lse_chain.hip): small factors that are functions of the value row the tile already holds are computed IN
-// the tile instead of being read -- the two producers of a hierarchical model's plate (logpq.py:221-235,
-// TorchDimDist.py:127-162):
-//   normal   n_scale * sum_e log N(value[m,k,e]; loc[m,e], scale[m,e]) + n_add      (the -(log Q + log K) of the latent)
-//   linear   b_scale * sum_n [ logsigmoid(l_n) - (1 - y[m,n]) l_n ] + b_add,  l_n = sum_e value[m,k,e] x[m,n,e]
-//            (a Bernoulli likelihood whose logits are the model lambda `z @ x`)
-// Per plate element the wave loads the block [loc(E) | scale(E) | x(N E) | y(N)] with coalesced loads (one tile ahead),
-// turns scale into 1 / (2 sigma^2) and log sigma on the way, and stages it in its own LDS region with each vector in
-// half-major order (events h, h + 2, ... of lane half h consecutive: 16-byte reads); a lane then needs ~4 vector
-// instructions per event for the normal term and one fma per (event, n) for the dots; the halves' sums meet through
-// v_permlane32_swap.  No launch, no [M, K] tensor, no load latency of its own.
-constexpr int X3_REC_NMAX = 8, X3_REC_SLOTS = 5;      // summed elements of the linear term; 64-float load slots per block
-struct X3Recipes {
-    const float *loc, *scl, *x, *y;
-    int32_t l_sm, l_se, s_sm, s_se, x_sm, x_sn, x_se, y_sm, y_sn;
-    int32_t has_normal, n_log_scale, N;              // N = 0: no linear term
-    float n_scale, n_add, b_scale, b_add;
-};
-template <int EQ>
-struct X3RecLayout {
-    static constexpr int EQP = (EQ + 3) & ~3;         // a half's events, padded to whole 16-byte reads
-    static constexpr int VEC = 2 * EQP;
-    static constexpr int YOFF = (3 + X3_REC_NMAX) * VEC;
-    static constexpr int FLOATS = YOFF + X3_REC_NMAX;  // per wave (a multiple of 4)
-};
-
-template <bool CHAIN>
-__device__ __forceinline__ float nl_load_small(const float *p) {
-    return CHAIN ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
-template <int EQ, int NST, int NLW, bool FLAT, bool CHAIN = false, bool REC = false>
+template <int EQ, int NST, int NLW, bool FLAT>
 __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx, const int by, const int bz, const int gx,
-                                                   const int gy, const X3Chain ch = X3Chain(),
-                                                   const X3Recipes &rc = X3Recipes()) {
+                                                   const int gy) {
     static_assert(!FLAT || NLW == 1, "flat row tiling: one loc row per wave");
-    static_assert(!REC || !FLAT, "in-tile small factors: tiles of one plate element");
-    typedef X3RecLayout<EQ> RL;
     constexpr int NSTEP = (3 * EQ + 3) / 4, NV = 4 * NSTEP;
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,9 +128,8 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
     // ---- LDS: B table | partial log-normalisers | per wave: value tile [32][ES], loc rows [NLW][32]
     u32x4v *bt = reinterpret_cast<u32x4v *>(lds);
     float *lgp_l = lds + NST * NSTEP * 64 * 4;
-    float *tile = lgp_l + NST * 4 * 64 + wave * (32 * 33 + NLW * 36 + (REC ? RL::FLOATS : 0));
+    float *tile = lgp_l + NST * 4 * 64 + wave * (32 * 33 + NLW * 36);
     float *locl = tile + 32 * 33;                                   // [NLW][36]: events 0 .. 2 EQ - 1 <= 33
-    float *recl = locl + NLW * 36;                                  // REC: the plate element's staged block (16-byte aligned)
     // ---- everything the wave needs from memory is requested before anything waits.  The loc rows: one coalesced load
     // per row, handed to the lanes through LDS (lane (j, h) wants events 2 q + h: ten reads at immediate offsets)
     float lrow[NLW];
@@ -203,14 +155,12 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         for (int qq = 0; qq < NX; ++qq)
             x[qq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane4 + 256 * qq, 0, 0));
     };
-    // (the small factors of a tile: with CHAIN `sc1` loads of what other workgroups of this launch wrote, issued only
-    // behind the barrier that follows thread 0's poll)
     auto small_tile = [&](int m, int kt_, float (&hs)[4]) {
         const uint32_t kk = (uint32_t)min(32 * kt_ + j, NK - 1);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {                 // (the launcher points unused slots at valid memory, stride 0)
             const float *sp = d.small[f] + (int64_t)m * d.small_sm[f];                       // (scalar)
-            hs[f] = nl_load_small<CHAIN>(sp + kk * (uint32_t)d.small_sk[f]);
+            hs[f] = sp[kk * (uint32_t)d.small_sk[f]];
         }
         asm volatile("" ::: "memory");
     };
@@ -229,7 +179,7 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
             const float *sp = d.small[f] + (int64_t)m0 * d.small_sm[f];                      // (scalar)
-            hs[f] = nl_load_small<CHAIN>(sp + (mm * (uint32_t)d.small_sm[f] + kk * (uint32_t)d.small_sk[f]));
+            hs[f] = sp[mm * (uint32_t)d.small_sm[f] + kk * (uint32_t)d.small_sk[f]];
         }
         pk += 32;
         if (pk >= NK) pk -= NK, ++pm;
@@ -239,25 +189,9 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         load_run(d.val + (int64_t)m0 * d.v_sm + 32 * tt * E, min(32, rows_total - 32 * tt), x);
         small_flat(hs);
     };
-    // REC: slot s of the block = float lane + 64 s of [loc | scale | x | y]; where it comes from (pointer at plate element
-    // 0 and the stride per plate element) and where it goes in the wave's LDS region (-1: nowhere)
-    const float *rgp[X3_REC_SLOTS];
-    int rgs[X3_REC_SLOTS], rlp[X3_REC_SLOTS], rkind[X3_REC_SLOTS];
-    float pv[X3_REC_SLOTS], pvn[X3_REC_SLOTS];
-    int rec_n = 0;
-    auto load_rec = [&](int m, float (&x)[X3_REC_SLOTS]) {
-#pragma unroll
-        for (int sl = 0; sl < X3_REC_SLOTS; ++sl)
-            if (64 * sl < rec_n) x[sl] = rgp[sl][(int64_t)m * rgs[sl]];        // (lanes beyond the block: a valid address, unused)
-    };
     float zc[NX], zn[NX], hc[4], hn[4];
     if (n_tiles > 0) {
-        if (CHAIN) {                                  // (the first tile's small factors: behind the barrier)
-            if (FLAT)
-                load_run(d.val + (int64_t)m0 * d.v_sm, min(32, rows_total), zc);
-            else
-                load_run(d.val + (int64_t)m0 * d.v_sm, min(32, NK), zc);
-        } else if (FLAT) {
+        if (FLAT) {
             load_flat(0, zc, hc);
         } else {
             load_tile(m0, 0, zc, hc);
@@ -324,64 +258,9 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
                     if ((st * (NV - 3 * EQ) + v) % 4 == wave) bw[((st * NSTEP + (v >> 2)) * 64 + lane) * 4 + (v & 3)] = 0u;
         }
     }
-    // REC: the block's per-lane tables and its first loads, behind everything the barrier below waits for (in front of
-    // the first value tile's loads they delayed every wave's critical path by their ~150 instructions)
-    if (REC) {
-        const int N = rc.N, nE = rc.has_normal ? E : 0;
-        rec_n = 2 * nE + N * E + N;
-#pragma unroll
-        for (int sl = 0; sl < X3_REC_SLOTS; ++sl) {
-            const int idx = lane + 64 * sl;
-            const float *gp = d.val;
-            int gs = 0, lp = -1, kind = 0;
-            if (idx < nE) {
-                gp = rc.loc + idx * rc.l_se, gs = rc.l_sm, lp = (idx & 1) * RL::EQP + (idx >> 1);
-            } else if (idx < 2 * nE) {
-                const int e = idx - nE;
-                gp = rc.scl + e * rc.s_se, gs = rc.s_sm, lp = RL::VEC + (e & 1) * RL::EQP + (e >> 1), kind = 1;
-            } else if (idx < 2 * nE + N * E) {
-                const int tq = idx - 2 * nE, n = (int)(((uint32_t)tq * d.rcp_e) >> 16), e = tq - n * E;
-                gp = rc.x + n * rc.x_sn + e * rc.x_se, gs = rc.x_sm, lp = (3 + n) * RL::VEC + (e & 1) * RL::EQP + (e >> 1);
-            } else if (idx < rec_n) {
-                const int n = idx - 2 * nE - N * E;
-                gp = rc.y + n * rc.y_sn, gs = rc.y_sm, lp = RL::YOFF + n;
-            }
-            rgp[sl] = gp, rgs[sl] = gs, rlp[sl] = lp, rkind[sl] = kind;
-            pv[sl] = pvn[sl] = 0.f;
-        }
-        // (padding events and unused vectors read as zero: w = 0 switches a padded event off)
-        for (int i = lane; i < RL::FLOATS; i += 64) recl[i] = 0.f;
-    }
-    if (REC && n_tiles > 0) load_rec(m0, pv);
     NL_STAMP(1);
-    bool pre_ok = true;
-    __shared__ int pre_failed;
-    if (CHAIN && ch.pre_n > 0) {
-        // the prelude's workgroups have the launch's lowest ids -- they were dispatched before this one and wait for nobody
-        if (tid == 0) {
-            uint32_t spins = 0;
-            pre_failed = 0;
-            while (__hip_atomic_load(ch.pre_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ch.pre_n) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) {           // (seconds: never in a healthy launch; the results are then NaN)
-                    __hip_atomic_store(ch.pre_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    pre_failed = 1;
-                    break;
-                }
-            }
-        }
-    }
     __syncthreads();
     NL_STAMP(2);
-    if (CHAIN) {
-        if (ch.pre_n > 0) pre_ok = pre_failed == 0;
-        if (n_tiles > 0) {
-            if (FLAT)
-                small_flat(hc);
-            else
-                small_tile(m0, 0, hc);
-        }
-    }
     float lgn[NST];
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
@@ -414,7 +293,6 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
             int kt_n = kt + 1, m_n = m;
             if (kt_n == nkt) kt_n = 0, ++m_n;
             if (t + 1 < n_tiles) load_tile(m_n, kt_n, zn, hn);
-            if (REC && t + 1 < n_tiles) load_rec(m_n, pvn);
         }
         const int valid = FLAT ? min(32, rows_total - 32 * t) : 32;
         const int bnd = FLAT ? min(rem_a, valid) : 32;
@@ -433,22 +311,6 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         }
 #endif
         float zv[EQ];
-        if (REC) {                                    // this plate element's block into the wave's LDS region
-#pragma unroll
-            for (int sl = 0; sl < X3_REC_SLOTS; ++sl) {
-                if (64 * sl >= rec_n) continue;
-                const float xx = pv[sl];
-                if (rlp[sl] >= 0) {
-                    if (rkind[sl] == 1) {                 // scale -> 1 / (2 sigma^2), log sigma
-                        const bool lsc = rc.n_log_scale != 0;
-                        recl[rlp[sl]] = lsc ? 0.5f * __builtin_amdgcn_exp2f(-2.f * NL_LOG2E * xx) : 0.5f * __builtin_amdgcn_rcpf(xx * xx);
-                        recl[rlp[sl] + RL::VEC] = lsc ? xx : __builtin_amdgcn_logf(xx) * NL_LN2;
-                    } else {
-                        recl[rlp[sl]] = xx;
-                    }
-                }
-            }
-        }
 #pragma unroll
         for (int qq = 0; qq < NX; ++qq) tile[soff[qq]] = zc[qq];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -457,67 +319,6 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         for (int q = 0; q < EQ; ++q) zv[q] = tile[j * ES + min(2 * q + h, E - 1)];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (REC) {
-            // this half's events of a vector: EQP consecutive floats, 16-byte aligned -- three ds_read_b128 per vector
-            auto vec = [&](int v, float (&o)[RL::EQP]) {
-                const f32x4v *p4 = reinterpret_cast<const f32x4v *>(recl + v * RL::VEC + h * RL::EQP);
-#pragma unroll
-                for (int i = 0; i < RL::EQP / 4; ++i) {
-                    const f32x4v x = p4[i];
-                    o[4 * i] = x[0], o[4 * i + 1] = x[1], o[4 * i + 2] = x[2], o[4 * i + 3] = x[3];
-                }
-            };
-            float tot = 0.f;
-            if (rc.has_normal) {
-                float lo[RL::EQP], wv[RL::EQP], lg[RL::EQP];
-                vec(0, lo), vec(1, wv), vec(2, lg);
-                float acc = 0.f, lgs = 0.f;
-#pragma unroll
-                for (int q = 0; q < EQ; ++q) {
-                    const float df = zv[q] - lo[q];
-                    acc = fmaf(df * df, wv[q], acc);
-                    lgs += lg[q];
-                }
-                float part = acc + lgs;
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
-                part = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                tot += rc.n_scale * (-part - (float)E * 0.91893853320467274178f) + rc.n_add;
-            }
-            if (rc.N > 0) {
-                // the dots of every n over this half's events, the halves' sums exchanged; then lane half 0 takes the
-                // even n's softplus and lane half 1 the odd ones (the transcendental instructions are quarter rate)
-                float bsum = 0.f, xl[X3_REC_NMAX];
-#pragma unroll
-                for (int n = 0; n < X3_REC_NMAX; ++n) {
-                    xl[n] = 0.f;
-                    if (n >= rc.N) continue;              // (uniform)
-                    float xv[RL::EQP];
-                    vec(3 + n, xv);
-                    float dot = 0.f;
-#pragma unroll
-                    for (int q = 0; q < EQ; ++q) dot = fmaf(zv[q], xv[q], dot);
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(dot), __float_as_uint(dot), false, false);
-                    xl[n] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                }
-#pragma unroll
-                for (int n2 = 0; n2 < X3_REC_NMAX; n2 += 2) {
-                    if (n2 >= rc.N) continue;             // (uniform)
-                    // one instruction stream for two n: lane half 0 evaluates n2, lane half 1 n2 + 1
-                    const float x = h ? xl[n2 + 1] : xl[n2];
-                    const float y = recl[RL::YOFF + n2 + h];
-                    // logsigmoid(x) - (1 - y) x, as reduce.hip's linear-logits producer evaluates it
-                    const float ee = __builtin_amdgcn_exp2f(-fabsf(x) * NL_LOG2E);
-                    const float ls = fminf(x, 0.f) - __builtin_amdgcn_logf(1.f + ee) * NL_LN2;
-                    bsum += n2 + h < rc.N ? ls - (1.f - y) * x : 0.f;
-                }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(bsum), __float_as_uint(bsum), false, false);
-                bsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                tot += rc.b_scale * bsum + rc.b_add;
-            }
-            hsum += tot;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();              // (the region is rewritten at the top of the next tile)
-        }
         const float nh = -hsum;
         const float slot = k_ok ? (nh > NL_BIG ? NL_BIG : nh) : NL_BIG;       // (a NaN small factor stays a NaN)
         // Units u = (loc row lw, scale tile st) of this value tile, software-pipelined: the matrix instructions of unit
@@ -666,10 +467,6 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) zc[i] = zn[i];
-        if (REC) {
-#pragma unroll
-            for (int sl = 0; sl < X3_REC_SLOTS; ++sl) pv[sl] = pvn[sl];
-        }
 #pragma unroll
         for (int f = 0; f < 4; ++f) hc[f] = hn[f];
     }
@@ -686,13 +483,8 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
             const int lw = u / NST, st = u - lw * NST;
             const int s = 32 * (sg * NST + st) + j;
             float tot = ((red[u * 32 + j] + red[(NU + u) * 32 + j]) + red[(2 * NU + u) * 32 + j]) + red[(3 * NU + u) * 32 + j];
-            if (CHAIN && !pre_ok) tot = __builtin_nanf("");
             if (h == 0 && s < NS && l + lw < d.NL) {
-                float *pp = d.part + ((int64_t)bz * d.NL + l + lw) * NS + s;
-                if (CHAIN)
-                    __hip_atomic_store(pp, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    *pp = tot;
+                d.part[((int64_t)bz * d.NL + l + lw) * NS + s] = tot;
             }
         }
     }

@@ -34,7 +34,6 @@ struct GroupDesc {
 // is most of the duration of a launch that reads a few hundred elements.
 constexpr int SMALL_NK = 4, SMALL_NR = 2;
 constexpr int SMALL_MULTI = 8;     // problems per reduce_small_multi_kernel launch (its kernel argument: 3.3 KB of the 4 KB)
-constexpr int CHAIN_MULTI = 4;     // problems in the prelude of a chained launch (normal_lse_chain.hip: its argument holds more)
 
 struct SmallDesc {
     const float *f[MAXF];

@@ -795,46 +795,6 @@ static int run_presum(const alan_reduce_desc_t &d2, int64_t n, int64_t stride, h
     return try_launch_small(c, gd, gl, mode, d2.out.dtype, stream, ev, n, stride, dry);
 }
 
-namespace alan {
-
-// The single small-kernel launch an alan_reduce problem is, prepared but not launched (the chained launch of the fused
-// plate step runs such problems inside itself, normal_lse_chain.hip): the linear-logits producer (mode comes back
-// ALAN_MODE_BERNOULLI_LINEAR, `ld` filled), a problem with a PRESUM dim, or an ordinary small problem (`sd` filled).
-// ALAN_ERR_UNSUPPORTED when alan_reduce would run it any other way (rows kernel, several launches, fp64, ...).
-int small_problem_prepare(const alan_reduce_desc_t &d, SmallDesc &sd, LinDesc &ld, GroupLaunch &gl, int &mode) {
-    if (d.mode == ALAN_MODE_BERNOULLI_LINEAR) {
-        mode = ALAN_MODE_BERNOULLI_LINEAR;
-        return lin_prepare(d, ld, gl);
-    }
-    alan_reduce_desc_t d2;
-    int64_t n = 0, stride = 0;
-    const int pp = strip_presum(d, d2, n, stride);
-    if (pp == -2) return ALAN_ERR_BAD_DESC;
-    if (pp < 0) return prepare_small(d, sd, gl, mode) ? ALAN_OK : ALAN_ERR_UNSUPPORTED;
-    uint32_t keep, red, plate;
-    int rc = classify(d2, keep, red, plate);
-    if (rc != ALAN_OK) return rc;
-    if (d2.out.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
-    mode = (d2.mode == ALAN_MODE_LSE && red == 0) ? ALAN_MODE_SUM : d2.mode;
-    Canon c;
-    rc = canonicalise(d2, keep, red, d2.out, c);
-    if (rc != ALAN_OK) return rc;
-    GroupDesc gd;
-    rc = plan_group(c, d2.out.dtype, d2.add_const, gd, gl, 1.f);
-    if (rc != ALAN_OK) return rc;
-    rc = build_small(c, gd, mode, d2.out.dtype, sd);
-    if (rc != ALAN_OK) return rc;
-    if (n > 1) {
-        const int64_t st = stride < 0 ? -stride : stride;
-        if (n > (1 << 16) || st * n >= (1ll << 30)) return ALAN_ERR_UNSUPPORTED;       // (int32 offsets)
-        sd.presum_n = (int32_t)n, sd.presum_stride = (int32_t)stride;
-    }
-    if (gd.n_out == 0) gl.grid = 0;
-    return ALAN_OK;
-}
-
-}  // namespace alan
-
 extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
     if (!d) return ALAN_ERR_BAD_DESC;
     {
@@ -1058,5 +1018,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 12; }
+extern "C" int alan_abi_version(void) { return 13; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
 // = 40 loads each, all of a thread's share in two rounds, and the 16 waves' (max, sum) pairs meet through LDS.
 template <int MODE, int UNR, int PF>
 __global__ __launch_bounds__(1024) void reduce_wide_kernel(const SmallDesc d) {
-    small_body<MODE, true, false, 16, UNR, PF>(d, 10, 0);
+    small_body<MODE, true, 16, UNR, PF>(d, 10, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,7 +323,7 @@ int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, con
 
 
 __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMulti m) {
-    small_multi_block<false>(0, blockIdx.x);
+    small_multi_block<>(0, blockIdx.x);
 }
 
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,

@@ -1,6 +1,4 @@
-// Device code of the small-problem kernels (reduce.hip) as inline functions, so that another launch can run such a
-// problem inside itself: the fused plate step's chained launch (normal_lse_chain.hip) executes the queued log-prob
-// producers in its first workgroups and the parent's contraction in its last-arriving one.  gfx950 only.
+// Device code of the small-problem kernels (reduce.hip).  gfx950 only.
 #pragma once
 #include <cstddef>
 
@@ -9,15 +7,7 @@
 
 namespace alan {
 
-// Result stores of a problem another workgroup of the SAME launch reads: write-through (an agent-scope relaxed atomic
-// store is a `global_store_dword ... sc1`), so the reader's `sc1` loads see them without a release fence.
-template <bool WT>
-__device__ __forceinline__ void small_store(float *p, float v) {
-    if (WT)
-        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-        *p = v;
-}
+__device__ __forceinline__ void small_store(float *p, float v) { *p = v; }
 
 // ------------------------------------------------------------------------------------------
 // Generated noise (alan_noise_t): Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's own CUDA /
@@ -177,7 +167,7 @@ __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
 // ------------------------------------------------------------------------------------------
 // NW: waves of the workgroup (BLOCK: all of them on one output); UNR elements of the reduce index per thread and round, PF
 // slices of a partial-sum factor (role PRESUM) per element and round -- UNR x PF loads in flight.
-template <int MODE, bool BLOCK, bool WT = false, int NW = 4, int UNR = 4, int PF = 8>
+template <int MODE, bool BLOCK, int NW = 4, int UNR = 4, int PF = 8>
 __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, const uint32_t block_id,
                                            const uint64_t noise_seed = 0, const uint64_t noise_cell = 0) {
     typedef float T;
@@ -276,10 +266,10 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
         if (d.ring_n) {
             // one workgroup, one value (try_launch_small checked): deliver it to this replay's slot and move on
             const int32_t slot = *d.ring_counter;
-            small_store<WT>(d.ring_slots[slot], v + d.add_const);
+            small_store(d.ring_slots[slot], v + d.add_const);
             *d.ring_counter = slot + 1 == d.ring_n ? 0 : slot + 1;
         } else {
-            small_store<WT>(d.out + obase, v + d.add_const);
+            small_store(d.out + obase, v + d.add_const);
         }
     }
 }
@@ -321,7 +311,7 @@ __device__ __forceinline__ float lin_dot(const float *pa, const float *pb, int l
     return (acc0 + acc1) + (acc2 + acc3);
 }
 
-template <bool BLOCK, bool WT = false>
+template <bool BLOCK>
 __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const uint32_t block_id) {
     const uint32_t G = BLOCK ? 256u : (1u << logG);
     uint32_t grp, gl;
@@ -438,22 +428,22 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
         s += ls - (1.f - y) * xl;
     }
     combine_lanes<float, ALAN_MODE_SUM, BLOCK>(m, s, G);
-    if (active && gl == 0) small_store<WT>(d.out + obase, s * d.out_scale + d.add_const);
+    if (active && gl == 0) small_store(d.out + obase, s * d.out_scale + d.add_const);
 }
 
-template <int MODE, bool WT = false>
+template <int MODE>
 __device__ __forceinline__ void small_either(const SmallDesc &d, int logG, bool block, uint32_t bid,
                                              const uint64_t noise_seed = 0, const uint64_t noise_cell = 0) {
     if (block)
-        small_body<MODE, true, WT>(d, 8, bid, noise_seed, noise_cell);
+        small_body<MODE, true>(d, 8, bid, noise_seed, noise_cell);
     else
-        small_body<MODE, false, WT>(d, logG, bid, noise_seed, noise_cell);
+        small_body<MODE, false>(d, logG, bid, noise_seed, noise_cell);
 }
 
 // Virtual workgroup `vb` of a SmallMulti that sits in the kernel-argument segment at byte offset `arg_off` (its
 // descriptors are read through the segment itself -- scalar loads at a uniform offset: indexing the by-value struct with a
 // run-time p makes the compiler copy all of it to scratch first).  Every thread of the workgroup calls it (barriers inside).
-template <bool WT, int NP = SMALL_MULTI>
+template <int NP = SMALL_MULTI>
 __device__ __forceinline__ void small_multi_block(const size_t arg_off, const uint32_t vb) {
     typedef SmallMultiT<NP> SmallMulti;
     typedef __attribute__((address_space(4))) const char *kernarg_ptr;
@@ -473,21 +463,21 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         nseed = __hip_atomic_load(nz.cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     switch (m.mode[p]) {
-        case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD, WT>(d, logG, block, bid); break;
-        case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM, WT>(d, logG, block, bid); break;   // (per-factor backward launches)
-        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT, WT>(d, logG, block, bid, nseed, cellv); break;
-        case ALAN_MODE_AFFINE: small_either<ALAN_MODE_AFFINE, WT>(d, logG, block, bid, nseed, cellv); break;
+        case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE>(d, logG, block, bid); break;
+        case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM>(d, logG, block, bid); break;
+        case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL>(d, logG, block, bid); break;
+        case ALAN_MODE_NORMAL_LOGSCALE: small_either<ALAN_MODE_NORMAL_LOGSCALE>(d, logG, block, bid); break;
+        case ALAN_MODE_BERNOULLI: small_either<ALAN_MODE_BERNOULLI>(d, logG, block, bid); break;
+        case ALAN_MODE_PRODUCER_GRAD: small_either<ALAN_MODE_PRODUCER_GRAD>(d, logG, block, bid); break;
+        case ALAN_MODE_WEXPSUM: small_either<ALAN_MODE_WEXPSUM>(d, logG, block, bid); break;   // (per-factor backward launches)
+        case ALAN_MODE_DOT: small_either<ALAN_MODE_DOT>(d, logG, block, bid, nseed, cellv); break;
+        case ALAN_MODE_AFFINE: small_either<ALAN_MODE_AFFINE>(d, logG, block, bid, nseed, cellv); break;
         case ALAN_MODE_BERNOULLI_LINEAR: {
             const LinDesc &ld = *reinterpret_cast<const LinDesc *>(base + offsetof(SmallMulti, lin));
             if (block)
-                lin_body<true, WT>(ld, 8, bid);
+                lin_body<true>(ld, 8, bid);
             else
-                lin_body<false, WT>(ld, logG, bid);
+                lin_body<false>(ld, logG, bid);
             break;
         }
         default: break;

@@ -171,9 +171,10 @@ class _FusedNormalLogProb(t.autograd.Function):
 
 
 class _blas:
-    """``with _blas("hipblaslt"):`` -- torch's BLAS preference for the enclosed GEMMs.  alan_amd prefers rocBLAS
-    globally (tiny batched GEMMs of model lambdas: 3.3 us against 9.3); the tall-skinny products of the outer-product
-    producer's backward ([270000, 30] x [30, 18]) are the opposite case: 47 us with hipBLASLt, 80 with rocBLAS."""
+    """``with _blas("hipblaslt"):`` -- torch's BLAS preference for the enclosed GEMMs only, restored on exit.  Model
+    lambdas run under rocBLAS (LAMBDA_BLAS: tiny batched GEMMs, 3.3 us against 9.3); the tall-skinny products of the
+    outer-product producer's backward ([270000, 30] x [30, 18]) are the opposite case: 47 us with hipBLASLt, 80 with
+    rocBLAS."""
 
     def __init__(self, name):
         self.name = name
@@ -1382,7 +1383,11 @@ def _dot_pt(a, b):
     letters = {}
     sub = lambda p: "".join(letters.setdefault(i, chr(ord("a") + len(letters))) for i in p.ids)
     sa, sb = sub(a), sub(b)
-    return PT(t.einsum(f"{sa}Z,{sb}Z->{''.join(letters[i] for i in ids)}", a.x, b.x), dims)
+    expr = f"{sa}Z,{sb}Z->{''.join(letters[i] for i in ids)}"
+    if LAMBDA_BLAS is None:
+        return PT(t.einsum(expr, a.x, b.x), dims)
+    with _blas(LAMBDA_BLAS):                          # (the lambda's own product: its backend, see LAMBDA_BLAS)
+        return PT(t.einsum(expr, a.x, b.x), dims)
 
 
 def _producer_terms(value, terms):
@@ -1436,7 +1441,21 @@ def call_model_lambda(fn, named_args, dimcache=None):
     return _call_lambda_vmap(fn, named_args, dimcache)
 
 
+LAMBDA_BLAS = None if os.environ.get("ALAN_AMD_KEEP_BLAS") == "1" else "hipblas"
+"""torch's BLAS backend WHILE A MODEL LAMBDA RUNS (None: torch's own choice).  A lambda such as movielens' ``z @ x`` that
+runs as written is a tiny batched GEMM ([300,30,18] x [300,18,5]): torch's default backend on ROCm (hipBLASLt) takes 9.3 us
+for it, rocBLAS 3.3 us (tools/small_bmm_probe.py).  Scoped to the lambda's call -- the host application's other GEMMs
+keep torch's preference (until round 3 the package set it process-wide at import)."""
+
+
 def _call_lambda_vmap(fn, named_args, dimcache=None):
+    if LAMBDA_BLAS is None or not t.cuda.is_available():
+        return _call_lambda_vmap_(fn, named_args, dimcache)
+    with _blas(LAMBDA_BLAS):
+        return _call_lambda_vmap_(fn, named_args, dimcache)
+
+
+def _call_lambda_vmap_(fn, named_args, dimcache=None):
     vals = [v for _, v in named_args]
     if LAMBDA_BACKEND != "vmap" or not all(isinstance(v, PT) for v in vals):
         val = fn(*[_as_dim(v, n, dimcache) for n, v in named_args])

@@ -105,6 +105,28 @@ class ResultRing:
         return s
 
 
+class ResultStrip(ResultRing):
+    """A result ring whose slots are the consecutive elements of ONE buffer: for a caller that issues many replays before
+    it reads any result (sample.EvalPipeline) -- replay k of the evaluation delivers to element k % n, nothing is claimed
+    or recycled, and a run of results is a view."""
+
+    def __init__(self, device, n):
+        self.device, self.n = device, int(n)
+        self.buf = t.empty(self.n, dtype=t.float32, device=device)
+        self.slots = None
+        self.table = t.arange(self.n, dtype=t.int64, device=device) * 4 + self.buf.data_ptr()
+        self.counter = t.zeros((), dtype=t.int32, device=device)
+        self.placeholder = t.empty((), dtype=t.float32, device=device)
+        self.pos, self.taken, self.declined = 0, 0, False
+
+    def sync_position(self):
+        self.counter.zero_()                       # (warm-ups advanced it: replays start at element 0)
+        self.pos = 0
+
+    def claim(self):
+        raise RuntimeError("a ResultStrip's elements are read in runs, not claimed one by one")
+
+
 FP64_SMALL_FACTORS = "fused"
 """What the fused plate step does with an fp64 small factor (the likelihood of fp64 observations, which the reference's
 sum of factors promotes to fp64 before its log-sum-exp, utils.py:218-220).  "fused" (default): the factor enters the fp32
@@ -533,7 +555,7 @@ def _normal_lse_forward(a, log_scale, want_lse, partials=False):
     d = _normal_lse_desc(a, log_scale)
     device = a["xv"].device
     n_parts = 0
-    if partials and not N.COMBINE_IN_LAUNCH:
+    if partials:
         import ctypes as C
         d.out = d.value                                  # (planning only: any non-null pointer)
         n_parts = int(N.lib().alan_normal_lse_n_partials(C.byref(d)))

@@ -98,7 +98,7 @@ class NormalLseDesc(C.Structure):
                 ("small", C.c_void_p * 4), ("small_sm", C.c_int64 * 4), ("small_sk", C.c_int64 * 4),
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
                 ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64),
-                ("lse_out", C.c_void_p), ("add_const", C.c_double), ("counters", C.c_void_p), ("n_counters", C.c_int64),
+                ("lse_out", C.c_void_p), ("add_const", C.c_double),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("keep_partials", C.c_int32)]
 
 
@@ -140,38 +140,15 @@ def lib():
         L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_normal_lse_n_partials.restype = C.c_int64
         L.alan_normal_lse_n_partials.argtypes = [C.POINTER(NormalLseDesc)]
-        PP = C.POINTER(C.POINTER(ReduceDesc))
-        L.alan_normal_lse_chained_check.restype = C.c_int
-        L.alan_normal_lse_chained_check.argtypes = [C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32]
-        L.alan_normal_lse_chained.restype = C.c_int
-        L.alan_normal_lse_chained.argtypes = [C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32, C.c_void_p, C.c_void_p]
         L.alan_normal_lse_backward.restype = C.c_int
         L.alan_normal_lse_backward.argtypes = [C.POINTER(NormalLseBackwardDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_backward_workspace_bytes.restype = C.c_size_t
         L.alan_normal_lse_backward_workspace_bytes.argtypes = [C.POINTER(NormalLseBackwardDesc)]
-        L.alan_chain_workspace_bytes.restype = C.c_size_t
-        L.alan_chain_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
-        L.alan_chain_logmmexp.restype = C.c_int
-        L.alan_chain_logmmexp.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.alan_chain_backward_workspace_bytes.restype = C.c_size_t
-        L.alan_chain_backward_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int32]
-        L.alan_chain_logmmexp_backward.restype = C.c_int
-        L.alan_chain_logmmexp_backward.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 5), *([C.c_void_p] * 6),
-                                                   C.c_size_t, C.c_void_p]
         L.alan_chain_batched_workspace_bytes.restype = C.c_size_t
         L.alan_chain_batched_workspace_bytes.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32]
         L.alan_chain_logmmexp_batched.restype = C.c_int
         L.alan_chain_logmmexp_batched.argtypes = [C.c_void_p, C.c_int32, *([C.c_int64] * 7), C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_size_t, C.c_void_p]
-        L.alan_chain_logmmexp_terms.restype = C.c_int
-        L.alan_chain_logmmexp_terms.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
-                                                C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_size_t, C.c_void_p]
-        L.alan_chain_logmmexp_terms_normal.restype = C.c_int
-        L.alan_chain_logmmexp_terms_normal.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
-                                                       C.POINTER(ChainNormal), C.c_int32, C.c_int64, C.c_int64, C.c_int64,
-                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_chain_logmmexp_terms_final.restype = C.c_int
         L.alan_chain_logmmexp_terms_final.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
                                                       C.POINTER(ChainNormal), C.POINTER(ChainFinal), C.c_int32, C.c_int64,
@@ -201,25 +178,24 @@ def lib():
         L.alan_exchange_destroy.argtypes = [C.c_void_p]
         L.alan_calls_create.restype = C.c_int
         L.alan_calls_create.argtypes = [C.POINTER(C.c_void_p)]
-        L.alan_calls_add_reduce.restype = C.c_int
-        L.alan_calls_add_reduce.argtypes = [C.c_void_p, C.POINTER(ReduceDesc), C.c_void_p, C.c_size_t]
-        L.alan_calls_add_reduce_batch.restype = C.c_int
-        L.alan_calls_add_reduce_batch.argtypes = [C.c_void_p, C.POINTER(C.POINTER(ReduceDesc)), C.c_int32]
-        L.alan_calls_add_normal_lse.restype = C.c_int
-        L.alan_calls_add_normal_lse.argtypes = [C.c_void_p, C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t]
-        L.alan_calls_add_chain_terms_final.restype = C.c_int
-        L.alan_calls_add_chain_terms_final.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
-                                                       C.POINTER(ChainNormal), C.POINTER(ChainFinal), C.c_int32, C.c_int64,
-                                                       C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t]
-        L.alan_calls_add_normal_lse_chained.restype = C.c_int
-        L.alan_calls_add_normal_lse_chained.argtypes = [C.c_void_p, C.POINTER(NormalLseDesc), PP, C.c_int32, PP, C.c_int32,
-                                                        C.c_void_p]
-        L.alan_calls_add_exchange_sum.restype = C.c_int
-        L.alan_calls_add_exchange_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.alan_calls_begin.restype = C.c_int
+        L.alan_calls_begin.argtypes = [C.c_void_p]
+        L.alan_calls_end.restype = C.c_int
+        L.alan_calls_end.argtypes = [C.c_void_p]
+        L.alan_calls_count.restype = C.c_int64
+        L.alan_calls_count.argtypes = [C.c_void_p]
         L.alan_noise_handon.restype = C.c_int
         L.alan_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.alan_calls_add_noise_handon.restype = C.c_int
-        L.alan_calls_add_noise_handon.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.alan_pipeline_create.restype = C.c_int
+        L.alan_pipeline_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.alan_pipeline_submit.restype = C.c_int
+        L.alan_pipeline_submit.argtypes = [C.c_void_p, C.c_int64]
+        L.alan_pipeline_join.restype = C.c_int
+        L.alan_pipeline_join.argtypes = [C.c_void_p, C.c_void_p]
+        L.alan_pipeline_fence.restype = C.c_int
+        L.alan_pipeline_fence.argtypes = [C.c_void_p, C.c_void_p]
+        L.alan_pipeline_destroy.restype = C.c_int
+        L.alan_pipeline_destroy.argtypes = [C.c_void_p]
         L.alan_calls_replay.restype = C.c_int
         L.alan_calls_replay.argtypes = [C.c_void_p, C.c_void_p]
         L.alan_calls_destroy.restype = C.c_int
@@ -232,19 +208,16 @@ def lib():
 
 EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
-           "alan_normal_lse_n_partials", "alan_normal_lse_chained_check", "alan_normal_lse_chained",
-           "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
-           "alan_chain_workspace_bytes",
-           "alan_chain_logmmexp", "alan_chain_backward_workspace_bytes", "alan_chain_logmmexp_backward",
-           "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms",
-           "alan_chain_logmmexp_terms_normal", "alan_chain_logmmexp_terms_final",
+           "alan_normal_lse_n_partials", "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
+           "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms_final",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
            "alan_exchange_create", "alan_exchange_connect", "alan_exchange_sum", "alan_exchange_status",
            "alan_exchange_destroy",
-           "alan_calls_create", "alan_calls_add_reduce", "alan_calls_add_reduce_batch", "alan_calls_add_normal_lse",
-           "alan_calls_add_chain_terms_final", "alan_calls_add_normal_lse_chained", "alan_calls_add_exchange_sum", "alan_noise_handon", "alan_calls_add_noise_handon", "alan_calls_replay",
-           "alan_calls_destroy",
+           "alan_calls_create", "alan_calls_begin", "alan_calls_end", "alan_calls_count", "alan_calls_replay",
+           "alan_calls_destroy", "alan_noise_handon",
+           "alan_pipeline_create", "alan_pipeline_submit", "alan_pipeline_join", "alan_pipeline_fence",
+           "alan_pipeline_destroy",
            "alan_abi_version", "alan_build_target")
 
 
@@ -258,10 +231,20 @@ class CallList:
         check(lib().alan_calls_create(C.byref(h)), "alan_calls_create")
         self._h, self.n, self.spoiled, self.keep = h, 0, False, []
 
-    def add(self, rc):
-        if rc != 0:
+    def record(self, fn, *args):
+        """The library call fn(*args) -- one that was just issued for real -- once more, with its launches kept in this
+        list instead of issued (alan_calls_begin .. alan_calls_end)."""
+        L = lib()
+        if L.alan_calls_begin(self._h) != 0:
+            self.spoiled = True
+            return
+        rc = fn(*args)
+        if L.alan_calls_end(self._h) != 0 or rc != 0:
             self.spoiled = True
         self.n += 1
+
+    def launches(self):
+        return int(lib().alan_calls_count(self._h))
 
     def replay(self, stream):
         check(lib().alan_calls_replay(self._h, stream), "alan_calls_replay")
@@ -318,7 +301,7 @@ class Exchange:
             raise NativeError(f"alan_exchange_sum failed ({rc})")
         if _REC[0] is not None:
             _REC[0].keep.append((x, out))
-            _REC[0].add(lib().alan_calls_add_exchange_sum(_REC[0]._h, self._h, x.data_ptr(), out.data_ptr(), x.numel()))
+            _REC[0].record(lib().alan_exchange_sum, self._h, x.data_ptr(), out.data_ptr(), x.numel(), None)
         return out
 
     def status(self):
@@ -384,7 +367,6 @@ class _Queue(threading.local):
     def __init__(self):
         self.pending = []        # [(desc, device, keepalive tensors)]
         self.depth = [0, 0]      # nesting of deferring() / may_defer()
-        self.fused = None        # a fused plate step waiting for its launch (_Fused), issued BEFORE ``pending``
         self.chain = None        # a single timeseries chain waiting for its launch (_PendingChain): the final contraction may join it
         self.tail_ok = 0         # nesting of tail_attach(): launches of an evaluation's final contraction
 
@@ -414,76 +396,7 @@ def deferring():
         _Q.depth[0] -= 1
         if _Q.depth[0] == 0:
             _Q.pending.clear()          # (only non-empty after an exception)
-            _Q.fused = None
             _Q.chain = None
-
-
-# ---- the chained launch (alan_normal_lse_chained) ------------------------------------------------------------------
-# Inside ``deferring()`` a gradient-free fused plate step is itself only queued: the producers queued so far (and any
-# queued before it goes out) ride in its launch as the PRELUDE -- its first workgroups run them, or its tiles compute
-# them -- and the launches of the evaluation's final contraction (engine.contract(final=True), under ``tail_attach()``)
-# can join it as the TAIL, run by its last-arriving workgroup.
-#   CHAIN_LAUNCHES = 1: only launches in which nothing waits for anything else (alan_normal_lse_chained_check == 0: the
-#       plate's [plate, K] producers computed in the plate step's tiles, the parent level's producers as extra
-#       workgroups, no tail) -- movielens at K <= 32: two launches per evaluation instead of three;
-#   CHAIN_LAUNCHES = 2: every chained launch the library takes, hand-offs and tail included (one launch per evaluation);
-#   CHAIN_LAUNCHES = 0 (default): every call a launch of its own.
-# Both chained forms are measured NO FASTER than the three launches (round 3, K = 30, tools/chain_parts.py and
-# tools/chain_check.py: the plate step alone replays every 14.3 us; with the two [M, K] producers computed in its tiles
-# 19.2-19.6; with the other producers and the arrival counter 22.8; with the tail 29.0 -- evaluations of 28.1 (sync-free)
-# and 29-30 us (everything) against 27.4-27.6 us for three launches).  An in-launch hand-off between workgroups
-# (write-through stores drained, an agent-scope add that returns, an acquire) costs the 4-5 us a dependent launch costs on
-# this chip, a small problem's chain of load latencies is as long inside another launch as in its own, and the in-tile
-# producers are recomputed by each of the 15 workgroups that share a plate slice.
-CHAIN_LAUNCHES = int(os.environ.get("ALAN_AMD_CHAIN", "0"))
-CHAIN_TAIL = os.environ.get("ALAN_AMD_CHAIN_TAIL", "1") != "0"      # False: the final contraction stays a launch of its own
-CHAIN_MAX_PRELUDE, CHAIN_MAX_TAIL = 4, 2
-_CHAIN_STATE = {}        # device index -> 4 zeroed int32 (the launch leaves the counters zero)
-
-
-class _Fused:
-    def __init__(self, desc, device, prelude, keepalive):
-        self.desc, self.device, self.prelude, self.keepalive = desc, device, prelude, keepalive
-        self.tail = []
-
-    def arrays(self, prelude=None, tail=None):
-        pre = self.prelude if prelude is None else prelude
-        tl = self.tail if tail is None else tail
-        PA = (C.POINTER(ReduceDesc) * max(1, len(pre)))(*[C.pointer(d) for d, _, _ in pre])
-        TA = (C.POINTER(ReduceDesc) * max(1, len(tl)))(*[C.pointer(d) for d, _, _ in tl])
-        return PA, len(pre), TA, len(tl)
-
-    def check(self, prelude=None, tail=None):
-        """Does the library take this chained launch, and does the CHAIN_LAUNCHES policy want it?"""
-        PA, n, TA, m = self.arrays(prelude, tail)
-        rc = lib().alan_normal_lse_chained_check(C.byref(self.desc), PA, n, TA, m)
-        return rc == 0 or (rc == 1 and CHAIN_LAUNCHES >= 2)
-
-
-_CHAIN_STATE_FOR_CAPTURE = [None]     # set by whoever captures a graph: that graph's own words (allocated before the capture)
-
-
-def chain_state(device):
-    """The zeroed words a chained launch synchronises through: a captured graph's own (two graphs replayed on different
-    streams must not share them), else one set per device -- evaluations launched kernel by kernel from different streams
-    at the same time are not supported with CHAIN_LAUNCHES.  None while a capture is under way and no set exists yet
-    (allocating it then would put its fill kernel into the graph)."""
-    if _CHAIN_STATE_FOR_CAPTURE[0] is not None and _CHAIN_STATE_FOR_CAPTURE[0].device == device:
-        return _CHAIN_STATE_FOR_CAPTURE[0]
-    st = _CHAIN_STATE.get(device.index)
-    if st is None and not t.cuda.is_current_stream_capturing():
-        st = _CHAIN_STATE[device.index] = t.zeros(4, dtype=t.int32, device=device)
-    return st
-
-
-@contextlib.contextmanager
-def own_chain_state(device):
-    """Around the warm-up and capture of one graph: its chained launches get words of their own."""
-    saved, _CHAIN_STATE_FOR_CAPTURE[0] = _CHAIN_STATE_FOR_CAPTURE[0], t.zeros(4, dtype=t.int32, device=device)
-    try:
-        yield _CHAIN_STATE_FOR_CAPTURE[0]
-    finally:
-        _CHAIN_STATE_FOR_CAPTURE[0] = saved
 
 
 class GraphNoise:
@@ -537,7 +450,7 @@ class GraphNoise:
             a, b = self.state.data_ptr(), self.state.data_ptr() + 16
             check(L.alan_noise_handon(b, a, current_stream(self.device)), "alan_noise_handon")
             if _REC[0] is not None:
-                _REC[0].add(L.alan_calls_add_noise_handon(_REC[0]._h, b, a))
+                _REC[0].record(L.alan_noise_handon, b, a, None)
             self.handon = True
 
     def close(self):
@@ -589,7 +502,7 @@ def own_graph_noise(device):
 
 
 def fused_pending():
-    return _Q.fused is not None or _Q.chain is not None
+    return _Q.chain is not None
 
 
 CHAIN_FINAL = os.environ.get("ALAN_AMD_CHAIN_FINAL", "1") != "0"
@@ -649,48 +562,6 @@ def tail_attach():
             flush()
 
 
-def _launch_fused():
-    f, _Q.fused = _Q.fused, None
-    L = lib()
-    stream = current_stream(f.device)
-    if not f.prelude and not f.tail:
-        rc = L.alan_normal_lse(C.byref(f.desc), None, 0, stream)
-        check(rc, "alan_normal_lse")
-        if _REC[0] is not None:
-            _REC[0].add(L.alan_calls_add_normal_lse(_REC[0]._h, C.byref(f.desc), None, 0))
-        return
-    st = chain_state(f.device)
-    if st is None:                                       # (first seen inside a capture: the separate launches)
-        _spoil()
-        _flush_items(f.prelude)
-        check(L.alan_normal_lse(C.byref(f.desc), None, 0, stream), "alan_normal_lse")
-        for d, _, _ in f.tail:
-            check(L.alan_reduce(C.byref(d), None, 0, stream), "alan_reduce")
-        return
-    PA, n, TA, m = f.arrays()
-    rc = L.alan_normal_lse_chained(C.byref(f.desc), PA, n, TA, m, st.data_ptr(), stream)
-    check(rc, "alan_normal_lse_chained")
-    if _REC[0] is not None:
-        _REC[0].keep.append(st)
-        _REC[0].add(L.alan_calls_add_normal_lse_chained(_REC[0]._h, C.byref(f.desc), PA, n, TA, m, st.data_ptr()))
-
-
-def _try_tail(desc, device, keepalive):
-    """Attach an alan_reduce call to the pending fused launch as (the next step of) its tail.  True: attached."""
-    f = _Q.fused
-    if f is None or not _Q.tail_ok or CHAIN_LAUNCHES < 2 or not CHAIN_TAIL or len(f.tail) >= CHAIN_MAX_TAIL or f.device != device:
-        return False
-    if any(dev != device for _, dev, _ in _Q.pending) or len(f.prelude) + len(_Q.pending) > CHAIN_MAX_PRELUDE:
-        return False
-    item = (desc, device, keepalive)
-    pre, tail = f.prelude + list(_Q.pending), f.tail + [item]
-    if not f.check(pre, tail):
-        return False
-    f.prelude, f.tail = pre, tail
-    _Q.pending.clear()
-    return True
-
-
 @contextlib.contextmanager
 def may_defer():
     _Q.depth[1] += 1
@@ -705,14 +576,6 @@ def flush():
     if _Q.chain is not None:
         c, _Q.chain = _Q.chain, None
         c.launch(None)
-    if _Q.fused is not None:
-        f = _Q.fused
-        # producers queued behind the fused launch read nothing it writes: they ride in its prelude while there is room
-        if _Q.pending and len(f.prelude) + len(_Q.pending) <= CHAIN_MAX_PRELUDE and \
-                all(dev == f.device for _, dev, _ in _Q.pending) and f.check(f.prelude + list(_Q.pending)):
-            f.prelude = f.prelude + list(_Q.pending)
-            _Q.pending.clear()
-        _launch_fused()
     if not _Q.pending:
         return
     items = list(_Q.pending)
@@ -733,13 +596,13 @@ def _flush_items(items):
         rc = L.alan_reduce(C.byref(items[0][0]), None, 0, current_stream(device))
         check(rc, "alan_reduce")
         if rec is not None:
-            rec.add(L.alan_calls_add_reduce(rec._h, C.byref(items[0][0]), None, 0))
+            rec.record(L.alan_reduce, C.byref(items[0][0]), None, 0, None)
         return
     arr = (C.POINTER(ReduceDesc) * len(items))(*[C.pointer(d) for d, _, _ in items])
     rc = L.alan_reduce_batch(arr, len(items), current_stream(device))
     check(rc, "alan_reduce_batch")
     if rec is not None:
-        rec.add(L.alan_calls_add_reduce_batch(rec._h, arr, len(items)))
+        rec.record(L.alan_reduce_batch, arr, len(items), None)
 
 
 def run_reduce(desc, device, algo_bytes=0, keepalive=()):
@@ -767,9 +630,6 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     if _Q.chain is not None and _Q.tail_ok and _TIMER[0] is None and not t.is_grad_enabled() and \
             _Q.chain.try_final(desc, device, keepalive):
         return True
-    if _Q.fused is not None and _Q.tail_ok and not lin_grad and _TIMER[0] is None and not t.is_grad_enabled() and \
-            L.alan_reduce_workspace_bytes(C.byref(desc)) == 0 and _try_tail(desc, device, keepalive):
-        return True
     flush()
     if _TIMER[0] is not None and not desc.noise.on:     # (a launch that generates noise carries no timing events)
         _TIMER[0].attach(desc, algo_bytes)
@@ -782,7 +642,7 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     check(rc, "alan_reduce")
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
-        _REC[0].add(L.alan_calls_add_reduce(_REC[0]._h, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes))
+        _REC[0].record(L.alan_reduce, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
     return True
 
 
@@ -810,43 +670,10 @@ def run_reduce_backward(desc, device):
     return True
 
 
-_COUNTERS = {}          # device index -> zeroed int32 arrival counters (every launch leaves them zero)
-N_COUNTERS = 8192
-COMBINE_IN_LAUNCH = False
-"""True: alan_normal_lse adds up its per-chunk partial sums itself (the last workgroup to arrive does it) instead of in
-a second launch.  Off by default -- measured slower: at K=30 the kernel goes from 16.9 to 26.7 us (600 workgroups each
-pay an agent-scope release fence, ~2-6 us of write-back per workgroup on gfx950) to save one 4.6 us launch: 48.3 us per
-evaluation against 42.3.  When on, the arrival counters are ONE array per device, shared by every call on that device:
-evaluations whose kernels may overlap in time on different streams must not share it (the C ABI takes the array from
-the caller and keeps no state of its own)."""
-
-
-def arrival_counters(device):
-    """The device's counter array, or None while a capture is under way and it does not exist yet (allocating it then
-    would put its fill kernel into the graph and tie its memory to the graph's pool)."""
-    c = _COUNTERS.get(device.index)
-    if c is None and not t.cuda.is_current_stream_capturing():
-        c = _COUNTERS[device.index] = t.zeros(N_COUNTERS, dtype=t.int32, device=device)
-    return c
-
-
 def run_normal_lse(desc, device, keepalive=()):
     """The fused plate step (alan_normal_lse).  False when the library declines the shape."""
     L = lib()
-    if (CHAIN_LAUNCHES and _Q.depth[0] and _Q.fused is None and desc.keep_partials and not desc.lse_out and _TIMER[0] is None
-            and not t.is_grad_enabled() and not COMBINE_IN_LAUNCH and len(_Q.pending) <= CHAIN_MAX_PRELUDE
-            and all(dev == device for _, dev, _ in _Q.pending)):
-        f = _Fused(desc, device, list(_Q.pending), keepalive)
-        if f.check():
-            # queued: goes out with the producers as its prelude (and the final contraction as its tail) at the next flush
-            _Q.pending.clear()
-            _Q.fused = f
-            return True
     flush()
-    if COMBINE_IN_LAUNCH and not desc.keep_partials and desc.NL * ((desc.NS + 31) // 32) <= N_COUNTERS:
-        c = arrival_counters(device)
-        if c is not None:
-            desc.counters, desc.n_counters = c.data_ptr(), N_COUNTERS
     nbytes = L.alan_normal_lse_workspace_bytes(C.byref(desc))
     if nbytes == 0:
         return False
@@ -859,7 +686,7 @@ def run_normal_lse(desc, device, keepalive=()):
     check(rc, "alan_normal_lse")
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
-        _REC[0].add(L.alan_calls_add_normal_lse(_REC[0]._h, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes))
+        _REC[0].record(L.alan_normal_lse, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
     return True
 
 
@@ -962,9 +789,9 @@ def chain_logmmexp_terms(terms, normal=None):
         check(rc, "alan_chain_logmmexp_terms_final")
         if _REC[0] is not None:
             _REC[0].keep.append((terms, normal, tree, vec))
-            _REC[0].add(L.alan_calls_add_chain_terms_final(
-                _REC[0]._h, ptrs, strides, len(terms), C.byref(nd) if nd is not None else None,
-                C.byref(fin) if fin is not None else None, code, B, T, K, vec.data_ptr(), tree.data_ptr(), nbytes))
+            _REC[0].record(L.alan_chain_logmmexp_terms_final, ptrs, strides, len(terms),
+                           C.byref(nd) if nd is not None else None, C.byref(fin) if fin is not None else None, code, B, T, K,
+                           None, vec.data_ptr(), tree.data_ptr(), nbytes, None)
         return True
 
     if CHAIN_FINAL and _Q.depth[0] and _Q.chain is None and B == 1 and 12 < K <= 32 and terms[0].dtype == t.float32 \

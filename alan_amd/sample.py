@@ -42,21 +42,16 @@ graph is still captured -- it owns the memory, and its node list is how the eval
 
 def calls_if_equivalent(graph, rec):
     """The recorded library calls ``rec`` (native.CallList), if issuing them again IS the captured evaluation: every node
-    of the graph a kernel, and as many of them as the calls launch by themselves (counted by capturing the calls alone
-    into a throwaway graph) -- i.e. no kernel of torch's anywhere in the evaluation (a model lambda's arithmetic, a
-    conversion, a copy).  None otherwise: the graph is what gets replayed."""
+    of the graph a kernel, and as many of them as the list holds launches (alan_calls_count) -- i.e. no kernel of torch's
+    anywhere in the evaluation (a model lambda's arithmetic, a conversion, a copy).  None otherwise: the graph is what
+    gets replayed."""
     from .training import node_kinds
     if rec is None or rec.spoiled or rec.n == 0:
         return None
     whole = node_kinds(graph)
     if whole is None or whole[1] != 0:
         return None
-    probe = t.cuda.CUDAGraph(keep_graph=True)
-    with t.cuda.graph(probe, pool=graph.pool(), capture_error_mode="thread_local"):
-        rec.replay(t.cuda.current_stream().cuda_stream)
-    alone = node_kinds(probe)
-    del probe
-    return rec if (alone is not None and alone[1] == 0 and alone[0] == whole[0]) else None
+    return rec if rec.launches() == whole[0] else None
 
 
 class _GraphedELBO:
@@ -69,10 +64,8 @@ class _GraphedELBO:
         from .training import check_no_memset_nodes
         timer, N._TIMER[0] = N._TIMER[0], None       # event records must not be captured
         device = t.device("cuda", t.cuda.current_device())
-        self.ring = E.ResultRing.create(device) if (ring and RESULT_RING) else None
+        self.ring = ring if isinstance(ring, E.ResultRing) else (E.ResultRing.create(device) if (ring and RESULT_RING) else None)
         E._RING[0] = self.ring
-        own = N.own_chain_state(device)
-        self.chain_state = own.__enter__()           # (kept: the graph's chained launches synchronise through it)
         try:
             side = t.cuda.Stream()
             side.wait_stream(t.cuda.current_stream())
@@ -108,7 +101,6 @@ class _GraphedELBO:
             # that went through RCCL keeps its graph)
             self.calls = self._direct(rec, side) if (rec is not None and ALL_REDUCES[0] == n_collectives) else None
         finally:
-            own.__exit__(None, None, None)
             N._TIMER[0] = timer
             E._RING[0] = None
         if self.ring is not None:
@@ -134,6 +126,92 @@ class _GraphedELBO:
         slot = self.ring.claim()
         self.replay()
         return slot.detach()
+
+
+class EvalPipeline:
+    """INDEPENDENT evaluations of one sample's ELBO, overlapped (include/alan_mi355.h: alan_pipeline_*).  The reference's
+    loop evaluates one ELBO after another (basic_runner.py:81-112; logpq.py:68-155 per evaluation); one evaluation is a
+    chain of dependent launches most of which fill a fraction of the chip.  ``lanes`` copies of the captured evaluation --
+    each with intermediates, result strip and recorded launch list of its own -- are issued round-robin on streams of
+    their own by the library's issuing threads, so one evaluation's producers and final log-sum-exp run beside
+    another's plate step (movielens K=30 on MI355X: 23 us per evaluation one after another, 8-11 us overlapped).
+
+        pipe = sample.pipeline(strategy, lanes=3)
+        elbos = pipe.run(1000)              # [1000] fp32, evaluation order; valid on the current stream
+
+    ``submit(n)`` first makes the lanes wait for the current stream (in-place updates of parameters or particles made
+    before it are seen), ``results()`` makes the current stream wait for the lanes; neither synchronises the host with
+    the device.  Only evaluations that are library launches alone can be pipelined (NativeError otherwise: a model
+    lambda's torch kernels, an RCCL collective)."""
+
+    def __init__(self, sample, computation_strategy=checkpoint, lanes=3, threads=None, results=4096):
+        import ctypes as C
+        from . import engine as E
+        from . import native as N
+        if sample.device.type != "cuda":
+            raise N.NativeError("alan_amd: an EvalPipeline runs on the GPU")
+        if not 1 <= lanes <= 8:
+            raise ValueError("1 to 8 lanes")
+        self.sample, self.strategy, self.n_lanes, self.capacity = sample, computation_strategy, lanes, int(results)
+        self.fingerprint = sample.problem.memory_fingerprint()
+        self._h = None
+        self.lanes = [_GraphedELBO(sample, computation_strategy, ring=E.ResultStrip(sample.device, results))
+                      for _ in range(lanes)]
+        for ln in self.lanes:
+            if ln.calls is None or not isinstance(ln.ring, E.ResultStrip):
+                raise N.NativeError("alan_amd: this evaluation is not library launches alone (a model lambda's torch kernels, "
+                                    "a collective, an fp64 result): it cannot be pipelined -- use sample.elbo_nograd()")
+        handles = (C.c_void_p * lanes)(*[ln.calls._h for ln in self.lanes])
+        h = C.c_void_p()
+        N.check(N.lib().alan_pipeline_create(handles, lanes, lanes if threads is None else int(threads), C.byref(h)),
+                "alan_pipeline_create")
+        self._h = h
+        self.total = 0          # evaluations submitted so far
+        self.first = 0          # ... before the batch whose results are due
+
+    def submit(self, n):
+        """n more evaluations (at most lanes x results between two results() calls); returns at once."""
+        from . import native as N
+        if n > self.n_lanes * self.capacity - (self.total - self.first):
+            raise ValueError(f"at most {self.n_lanes * self.capacity} evaluations between two results() calls")
+        if self.sample.problem.memory_fingerprint() != self.fingerprint:
+            raise N.NativeError("alan_amd: the problem's tensors moved since this pipeline was built: build a new one")
+        L = N.lib()
+        stream = t.cuda.current_stream(self.sample.device).cuda_stream
+        N.check(L.alan_pipeline_fence(self._h, stream), "alan_pipeline_fence")
+        N.check(L.alan_pipeline_submit(self._h, int(n)), "alan_pipeline_submit")
+        self.total += int(n)
+
+    def results(self):
+        """The ELBOs of every evaluation submitted since the last results() call, in submission order: a new [n] fp32
+        tensor, ordered after the evaluations on the current stream."""
+        from . import native as N
+        stream = t.cuda.current_stream(self.sample.device).cuda_stream
+        N.check(N.lib().alan_pipeline_join(self._h, stream), "alan_pipeline_join")
+        i0, i1, L, R = self.first, self.total, self.n_lanes, self.capacity
+        self.first = i1
+        if i1 == i0:
+            return t.empty(0, dtype=t.float32, device=self.sample.device)
+        # evaluation i ran on lane i % L as that lane's evaluation i // L: element (i // L) % R of its strip
+        idx = t.arange(i0, i1, device=self.sample.device)
+        strips = t.stack([ln.ring.buf for ln in self.lanes])
+        return strips[idx % L, (idx // L) % R]
+
+    def run(self, n):
+        self.submit(n)
+        return self.results()
+
+    def close(self):
+        if self._h is not None:
+            from . import native as N
+            N.lib().alan_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def strategy_key(strategy):
@@ -311,8 +389,7 @@ class Sample:
         from . import logpq as LP
         from . import split as SP
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS, N.CHAIN_LAUNCHES, N.CHAIN_TAIL,
-                N.CHAIN_FINAL)
+                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, SP.GATHER_PARTIALS, N.CHAIN_FINAL)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)
@@ -320,6 +397,21 @@ class Sample:
         if key not in cache:
             cache[key] = _GraphedELBO(self, computation_strategy)
         return cache[key]
+
+    def pipeline(self, computation_strategy=checkpoint, lanes=3, threads=None, results=4096):
+        """An EvalPipeline of this sample's ELBO under the strategy (cached per strategy, routing and lane count)."""
+        key = (self._graph_key(computation_strategy), lanes, threads, results)
+        cache = self.__dict__.setdefault("_pipelines", {})
+        p = cache.get(key)
+        if p is None or p.fingerprint != self.problem.memory_fingerprint():
+            if p is not None:
+                p.close()
+            p = cache[key] = EvalPipeline(self, computation_strategy, lanes, threads, results)
+        return p
+
+    def elbo_nograd_many(self, n, computation_strategy=checkpoint, lanes=3):
+        """n independent evaluations of ``elbo_nograd`` (Sample.py:135-148), overlapped on the chip: a [n] fp32 tensor."""
+        return self.pipeline(computation_strategy, lanes).run(n)
 
     # ---- the path's backward in production use (Sample.py:208-346) ---------------------------------
     def _marginal_idxs(self, joints, computation_strategy):

@@ -258,8 +258,6 @@ class GraphedEval:
         self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING and unroll == 1) else None
         E._RING[0] = self.ring
         from . import native as N
-        own = N.own_chain_state(problem.device)
-        self.chain_state = own.__enter__()           # (kept: the graph's chained launches synchronise through it)
         try:
             side = t.cuda.Stream()
             side.wait_stream(t.cuda.current_stream())
@@ -284,7 +282,6 @@ class GraphedEval:
             finally:
                 N._REC[0] = None
         finally:
-            own.__exit__(None, None, None)
             E._RING[0] = None
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedEval")
         # (sample.DIRECT_REPLAY: the evaluation's library launches issued again one by one where that is all the graph holds)

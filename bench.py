@@ -532,23 +532,6 @@ def main():
         t.cuda.synchronize()
         out["plain_call"] = {"us_per_eval": (time.perf_counter() - t0) / 50 * 1e6,
                              "what": "sample.elbo_nograd(strategy), as the reference spells it"}
-        # the same evaluation with its launches chained into fewer (alan_normal_lse_chained; off by default: not faster)
-        try:
-            from alan_amd import native as N_
-            ab, saved = {}, (N_.CHAIN_LAUNCHES, N_.CHAIN_TAIL)
-            for name, (mode, tail) in (("three_launches", (0, False)), ("two_launches_no_handoff", (1, False)),
-                                       ("one_launch_with_handoffs", (2, True))):
-                N_.CHAIN_LAUNCHES, N_.CHAIN_TAIL = mode, tail
-                d_c, v_c = timed_evals(draw(prob, K), strat, 200, 20, world, graph=True)
-                ab[name] = {"us_per_eval": d_c / 200 * 1e6, "elbo": v_c}
-            N_.CHAIN_LAUNCHES, N_.CHAIN_TAIL = saved
-            ab["default"] = "three_launches"
-            ab["what"] = ("producers / fused plate step / final contraction as separate launches, with the [M, K] producers "
-                          "computed in the plate step's tiles and the other producers as extra workgroups (no hand-off), and "
-                          "as ONE launch whose workgroups hand results to each other (tools/chain_parts.py has the parts)")
-            out["launch_chaining"] = ab
-        except Exception as e:
-            out["launch_chaining"] = {"error": f"{type(e).__name__}: {e}"}
         # sample() + elbo per iteration, as examples/basic_runner.py:86-97 of the reference counts it (eager)
         for _ in range(3):
             prob.sample(K, reparam=False).elbo_nograd(strat)

@@ -15,8 +15,8 @@
  *                                          grad_f = sum_{dims not in f} grad_out * exp(sum_f lp_f - lse)
  *   alan_reduce(mode = ALAN_MODE_NORMAL)   TorchDimDist.py:127-162 log_prob of a Normal over the K cross-product with
  *                                          the event-dim sum (utils.py:147-152) fused in: the factor PRODUCER
- *   alan_chain_logmmexp                    utils.py:478-510 chain_logmmexp  (+ logpq.py:139 logsumexp(-1))
- *   alan_chain_logmmexp_backward           autograd through the same
+ *   alan_chain_logmmexp_batched            utils.py:478-510 chain_logmmexp  (+ logpq.py:139 logsumexp(-1))
+ *   alan_chain_logmmexp_backward_batched   autograd through the same
  *
  * Conventions
  *   - Plain pointers and sizes only; every pointer is DEVICE memory owned by the caller.
@@ -243,12 +243,6 @@ typedef struct {
     void *out;          int64_t o_sl, o_ss;            /* [NL, NS]   */
     void *lse_out;                                     /* optional [M, NL, NS] fp32 contiguous */
     double add_const;
-    void *counters; int64_t n_counters;                /* optional int32[n_counters], n_counters >= NL * ceil(NS / 32):
-                                                          ZERO on entry, left zero.  When given, the per-chunk partial
-                                                          sums are added up by the launch itself (the last workgroup to
-                                                          arrive, agent-scope release / acquire) instead of by a second
-                                                          launch.  One array per stream: two calls in flight at once
-                                                          must not share it */
     void *ev_start, *ev_stop;                          /* optional hipEvent_t pair (NULL = off) recorded immediately
                                                           before / after the MFMA kernel of the call (forward, or the
                                                           backward when the descriptor sits in a backward desc) */
@@ -258,41 +252,9 @@ typedef struct {
                                                           that adds them itself (alan_reduce, role ALAN_PRESUM) */
 } alan_normal_lse_desc_t;
 size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
-/* How many partial results per output a keep_partials call leaves (0: the library declines the shape, or would add
- * them up inside the launch: then keep_partials must not be set). */
+/* How many partial results per output a keep_partials call leaves (0: the library declines the shape). */
 int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
-
-/* The plate step TOGETHER WITH the launches either side of it, as ONE launch -- what the reference runs as lp_getter +
- * reduce_Ks at two plate levels (logpq.py:68-155: the plate's factors are produced, reduce_Ks.py:236-298 eliminates its
- * K and logpq.py:149 sums it out; the result is a factor of the parent's reduce_Ks, Sample.py:69-86 for the top level):
- *   prelude  up to 4 alan_reduce problems of the small single-launch kind (the log-prob producers alan_reduce_batch
- *            would launch together: -(log Q + log K) of the plate's latent, the likelihood with linear logits, the parent
- *            level's log P - log Q - log K), run by the launch's first workgroups.  They may write desc->small[] and the
- *            tail's factors; they read nothing this launch writes.
- *   desc     the plate step, keep_partials set: desc->out receives [alan_normal_lse_n_partials(desc), NL, NS].
- *   tail     up to 2 alan_reduce problems of that kind run IN ORDER by the launch's last-arriving workgroup -- the
- *            parent's contraction: typically tail[0] reads desc->out with a dim of role ALAN_PRESUM and the prelude's
- *            outputs, tail[1] (K = 100: the second K peeled) reads tail[0]'s output; the last may deliver through a
- *            result ring (ring_*, one output element).
- *   state    16 bytes of device memory, zero before the FIRST call and never touched by the caller again (the launch
- *            leaves the first 8 zero; bytes 8..11 become non-zero if a workgroup ever gave up waiting for the prelude --
- *            never in a healthy launch -- and the results of that launch are NaN).  Launches that may run concurrently
- *            (different streams) need separate `state`.
- * Results are those of alan_reduce_batch(prelude); alan_normal_lse(desc); alan_reduce(tail[0]); alan_reduce(tail[1]).
- * ALAN_ERR_UNSUPPORTED (from either function, nothing launched): some part is not of the single-launch small kind, or
- * the plate step is not the bf16x3 kernel's -- issue the calls separately.
- * alan_normal_lse_chained_check tells the two kinds of chained launch apart: ALAN_OK -- nothing inside the launch waits
- * for anything else in it (no tail, and every desc->small[] the prelude writes is a function of the value rows that the
- * plate step computes in its own tiles instead: the Normal -(log Q + log K) and the linear-logits likelihood at NS <= 32;
- * THOSE prelude outputs are then never written) -- or ALAN_CHAIN_HANDOFFS (> 0): workgroups hand results to each other
- * through `state`, which costs what a dependent launch costs on this chip (measured: tools/chain_parts.py). */
-#define ALAN_CHAIN_HANDOFFS 1
-int alan_normal_lse_chained_check(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,
-                                  int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail);
-int alan_normal_lse_chained(const alan_normal_lse_desc_t *desc, const alan_reduce_desc_t *const *prelude,
-                            int32_t n_prelude, const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state,
-                            void *stream);
 
 /* Backward of alan_normal_lse with respect to EVERY input, in one pass that recomputes the log-prob tiles on the matrix
  * cores as the forward does and never writes the [M, NL, NS, NK] factor or its gradient -- what autograd derives from
@@ -321,36 +283,23 @@ size_t alan_normal_lse_backward_workspace_bytes(const alan_normal_lse_backward_d
 int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *desc, void *workspace, size_t workspace_bytes,
                              void *stream);
 
-/* Timeseries plate: utils.py:478-510 chain_logmmexp + the t.logsumexp(., -1) of logpq.py:139.
- *   ms         [T, K, K] with element strides (sT, sRow, sCol); ms[t][i][j] = log weight of going from particle i
- *              of step t-1 to particle j of step t
- *   out_chain  optional [K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)
- *   out_vec    optional [K]   contiguous: logsumexp(chain, -1)                    (what the ELBO uses)
- * The reference's own pairwise tree (one launch per round, an odd leftover carried to the end, utils.py:488-495) with
- * its normalisation and eps-in-log (utils.py:503-507): where that eps floors entries the bracketing matters, so it
- * is kept.  The workspace receives EVERY round of the tree (alan_chain_workspace_bytes is about the size of ms);
- * keep it if a backward is to follow. */
-size_t alan_chain_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
-int alan_chain_logmmexp(const void *ms, int32_t dtype, int64_t T, int64_t K,
-                        int64_t sT, int64_t sRow, int64_t sCol,
-                        void *out_chain, void *out_vec,
-                        void *workspace, size_t workspace_bytes, void *stream);
-
-/* Backward of the above with respect to ms: what autograd derives from utils.py:478-510 (+ logpq.py:139), INCLUDING
- * the paths through the eps floor and through amax.  `tree` is the forward's workspace, untouched since.  The
- * upstream gradient is grad_vec [K] (of out_vec; then out_vec must be given) and / or grad_chain [K, K] (of
- * out_chain); both given = their sum.  grad_ms receives [T, K, K] contiguous.  One launch per round of the tree. */
-size_t alan_chain_backward_workspace_bytes(int64_t T, int64_t K, int32_t dtype);
-int alan_chain_logmmexp_backward(const void *ms, int32_t dtype, int64_t T, int64_t K,
-                                 int64_t sT, int64_t sRow, int64_t sCol,
-                                 const void *tree, const void *out_vec, const void *grad_vec, const void *grad_chain,
-                                 void *grad_ms, void *workspace, size_t workspace_bytes, void *stream);
-
-/* The same two operations on a BATCH of B independent chains: a timeseries plate nested under other plates or carrying
- * parent K dims (logpq.py:133-135: lp.order(T, K_init, K_curr) leaves every other torchdim as a batch dim of the
- * matmuls in utils.py:503-507).  ms is [B, T, K, K] with element strides (sB, sT, sRow, sCol); out_chain [B, K, K],
- * out_vec / grad_vec [B, K], grad_chain [B, K, K] and grad_ms [B, T, K, K] are contiguous.  B <= 65535.  The
- * unbatched entry points above are these with B = 1. */
+/* Timeseries plate: utils.py:478-510 chain_logmmexp + the t.logsumexp(., -1) of logpq.py:139, for a BATCH of B
+ * independent chains (B = 1: the reference's call; B > 1: a timeseries plate nested under other plates or carrying parent
+ * K dims -- logpq.py:133-135: lp.order(T, K_init, K_curr) leaves every other torchdim as a batch dim of the matmuls in
+ * utils.py:503-507).
+ *   ms         [B, T, K, K] with element strides (sB, sT, sRow, sCol); ms[b][t][i][j] = log weight of going from
+ *              particle i of step t-1 to particle j of step t
+ *   out_chain  optional [B, K, K] contiguous: the log of the ordered matrix product  (chain_logmmexp)
+ *   out_vec    optional [B, K]   contiguous: logsumexp(chain, -1)                    (what the ELBO uses)
+ * The reference's own pairwise tree (an odd leftover carried to the end, utils.py:488-495) with its normalisation and
+ * eps-in-log (utils.py:503-507): where that eps floors entries the bracketing matters, so it is kept.  The workspace
+ * receives EVERY round of the tree (alan_chain_batched_workspace_bytes is about the size of ms); keep it if a backward
+ * is to follow.  B <= 65535.
+ *
+ * alan_chain_logmmexp_backward_batched: the gradient with respect to ms -- what autograd derives from utils.py:478-510
+ * (+ logpq.py:139), INCLUDING the paths through the eps floor and through amax.  `tree` is the forward's workspace,
+ * untouched since.  The upstream gradient is grad_vec [B, K] (of out_vec; then out_vec must be given) and / or grad_chain
+ * [B, K, K] (of out_chain); both given = their sum.  grad_ms receives [B, T, K, K] contiguous. */
 size_t alan_chain_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                 int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
@@ -360,16 +309,13 @@ int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_
  * the reference adds into one [T, K_init, K] tensor first (reduce_Ks with no K to sum, logpq.py:128): the first round
  * adds them on load.  terms[i] is [B, T, K, K] with element strides strides[4 i .. 4 i + 3] = (sB, sT, sRow, sCol), 0
  * where a term lacks a dim.  Workspace as alan_chain_batched_workspace_bytes.  (No backward of its own: with
- * gradients to record, add the factors first.) */
-int alan_chain_logmmexp_terms(const void *const *terms, const int64_t *strides, int32_t n_terms, int32_t dtype,
-                              int64_t B, int64_t T, int64_t K, void *out_chain, void *out_vec,
-                              void *workspace, size_t workspace_bytes, void *stream);
-/* The same with one MORE term that is computed on load instead of read: the transition log-prob of a timeseries
+ * gradients to record, add the factors first.)
+ * `normal` (optional): one MORE term that is computed on load instead of read: the transition log-prob of a timeseries
  * `ts ~ Normal(c * prev, scale)` (Timeseries.py:205-245 evaluating TorchDimDist.py:127-162 on the [T, K_init, K] cross
  * product): log N(value; loc_mul * loc, scale), each operand a [B, T, K_init, K] view given by four element strides
  * (0 where it lacks a dim: value = x[t, k] has no K_init stride, loc = prev[t, k_init] no K stride).  That factor --
- * 40 MB at T=1000, K=100 -- is then never written.  normal == NULL: alan_chain_logmmexp_terms.  With loc0 the
- * location is the previous state without its concatenation: loc0 at step 0, loc shifted by one step after it. */
+ * 40 MB at T=1000, K=100 -- is then never written.  With loc0 the location is the previous state without its
+ * concatenation: loc0 at step 0, loc shifted by one step after it. */
 typedef struct {
     const void *value, *loc, *scale;      /* dtype as the terms */
     int64_t v_stride[4], l_stride[4], s_stride[4];     /* (sB, sT, sRow, sCol) */
@@ -380,15 +326,12 @@ typedef struct {
                                              as cat(init, x[:-1]) -- the previous state -- taken from its two sources */
     int64_t l0_stride[4];
 } alan_chain_normal_t;
-int alan_chain_logmmexp_terms_normal(const void *const *terms, const int64_t *strides, int32_t n_terms,
-                                     const alan_chain_normal_t *normal, int32_t dtype, int64_t B, int64_t T, int64_t K,
-                                     void *out_chain, void *out_vec, void *workspace, size_t workspace_bytes, void *stream);
-/* The same with the PARENT's contraction of the chain's result run by the chain's last launch (one workgroup) behind its
- * last round -- the evaluation's final reduce_Ks when the timeseries plate sits under the top level (Sample.py:69-86,
+/* `fin` (optional): the PARENT's contraction of the chain's result run by the chain's last launch (one workgroup) behind
+ * its last round -- the evaluation's final reduce_Ks when the timeseries plate sits under the top level (Sample.py:69-86,
  * reduce_Ks.py:249-251 + utils.py:218-220 on [K_init] vectors): one launch fewer per evaluation.
  *     out = log(sum_k exp(x_k - max_k x_k) + eps) + max_k x_k + add_const,   x_k = out_vec[k] + sum_f extra_f[k * stride_f]
  * written to *out, or through a result ring (ring_*, as alan_reduce_desc_t).  One chain (B = 1), fp32, 12 < K <= 32 (the
- * one-wave-per-product kernel); ALAN_ERR_UNSUPPORTED otherwise (nothing launched: issue the chain and alan_reduce). */
+ * one-wave-per-product kernel); ALAN_ERR_UNSUPPORTED otherwise (nothing launched: pass fin = NULL and call alan_reduce). */
 typedef struct {
     int32_t n_extra;                  /* 0 .. 3 further [K] factors */
     const void *extra[3];
@@ -455,32 +398,48 @@ int alan_exchange_sum(void *exchange, const void *src, void *out, int64_t n, voi
 int alan_exchange_status(void *exchange, uint32_t *completed, uint32_t *failed_at);
 int alan_exchange_destroy(void *exchange);
 
-/* A recorded sequence of alan_reduce / alan_reduce_batch / alan_normal_lse calls, issued again in order by ONE call on
- * the given stream: for a caller that evaluates the same contraction again and again (Sample.elbo_nograd on a fixed
- * sample -- logpq.py:68-155 once per call of the reference's runner loop).  Measured against replaying the same launches
- * as a captured HIP graph on MI355X: 23 us per movielens K=30 evaluation instead of 27 (a graph launch leaves the GPU
- * idle for several microseconds between two replays; launches issued one by one do not).  alan_calls_add_* plans the
- * call exactly as the entry point of the same name would and keeps its kernel launches -- kernel, grid, a copy of every
- * argument (host memory of the library's own) -- WITHOUT issuing them; alan_calls_replay issues the kept launches in
- * order and plans nothing.  Every device pointer of the descriptors, workspaces included, must stay valid for as long as
- * the list is replayed.  Descriptors carrying timing events are refused (ALAN_ERR_UNSUPPORTED). */
+/* A recorded sequence of this library's launches, issued again in order by ONE call on the given stream: for a caller that
+ * evaluates the same contraction again and again (Sample.elbo_nograd on a fixed sample -- logpq.py:68-155 once per call of
+ * the reference's runner loop).  Measured against replaying the same launches as a captured HIP graph on MI355X: 23 us per
+ * movielens K=30 evaluation instead of 27 (a graph launch leaves the GPU idle for several microseconds between two
+ * replays; launches issued one by one do not).
+ *   alan_calls_begin   from now until alan_calls_end, every entry point of this library called BY THIS THREAD plans its
+ *                      call exactly as usual and keeps its kernel launches -- kernel, grid, a copy of every argument (host
+ *                      memory of the library's own) -- in `calls` WITHOUT issuing them.  One list at a time per thread.
+ *   alan_calls_end     ALAN_ERR_UNSUPPORTED if some launch could not be kept (a descriptor carrying timing events): the
+ *                      list must not be replayed.
+ *   alan_calls_count   kernel launches the list holds (what a caller compares with the node count of a captured graph
+ *                      of the same evaluation, to know that the list IS the evaluation).
+ *   alan_calls_replay  issues the kept launches in order and plans nothing.
+ * Every device pointer of the recorded calls, workspaces included, must stay valid for as long as the list is replayed. */
 int alan_calls_create(void **calls);
-int alan_calls_add_reduce(void *calls, const alan_reduce_desc_t *desc, void *workspace, size_t workspace_bytes);
-int alan_calls_add_reduce_batch(void *calls, const alan_reduce_desc_t *const *descs, int32_t n);
-int alan_calls_add_normal_lse(void *calls, const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes);
-int alan_calls_add_normal_lse_chained(void *calls, const alan_normal_lse_desc_t *desc,
-                                      const alan_reduce_desc_t *const *prelude, int32_t n_prelude,
-                                      const alan_reduce_desc_t *const *tail, int32_t n_tail, void *state);
-int alan_calls_add_exchange_sum(void *calls, void *exchange, const void *src, void *out, int64_t n);
-int alan_noise_handon(const void *from, void *to, void *stream);
-int alan_calls_add_noise_handon(void *calls, const void *from, void *to);
-/* (alan_chain_logmmexp_terms_final without out_chain: delivering the chain is a copy, and a list holds launches only) */
-int alan_calls_add_chain_terms_final(void *calls, const void *const *terms, const int64_t *strides, int32_t n_terms,
-                                     const alan_chain_normal_t *normal, const alan_chain_final_t *fin, int32_t dtype,
-                                     int64_t B, int64_t T, int64_t K, void *out_vec, void *workspace,
-                                     size_t workspace_bytes);
+int alan_calls_begin(void *calls);
+int alan_calls_end(void *calls);
+int64_t alan_calls_count(void *calls);
 int alan_calls_replay(void *calls, void *stream);
 int alan_calls_destroy(void *calls);
+/* Copies one generator slot {counter, seed} to another (see alan_noise_t). */
+int alan_noise_handon(const void *from, void *to, void *stream);
+
+/* INDEPENDENT evaluations overlapped.  Consecutive ELBO evaluations of the reference's loop (basic_runner.py:81-112;
+ * logpq.py:68-155 per evaluation) do not depend on each other, while ONE evaluation is a chain of dependent launches most
+ * of which occupy a fraction of the chip.  A pipeline holds n_lanes recorded copies of the evaluation (each alan_calls
+ * list recorded over intermediates and outputs of its own) and issues evaluation i on lane i % n_lanes, every lane on a
+ * stream the pipeline owns, so that one evaluation's small launches run beside another's plate step.  n_threads issuing
+ * threads of the library's own (0: alan_pipeline_submit issues from the caller's thread) -- with the chip kept busy the
+ * host's launch calls are the bound, and threads issuing to different streams do not serialise.
+ *   alan_pipeline_submit  `count` more evaluations; returns at once (n_threads > 0).
+ *   alan_pipeline_join    returns when every submitted evaluation has been ISSUED, having made `stream` wait for all of
+ *                         them: work enqueued on `stream` afterwards sees every result.  Does not synchronise the device.
+ *   alan_pipeline_fence   the lanes wait for everything enqueued on `stream` so far -- after the caller changed, on that
+ *                         stream, memory the evaluations read (an optimiser step, new particles).
+ * The one place beside alan_exchange_* where the library owns resources (streams, events, threads). */
+#define ALAN_PIPELINE_MAX_LANES 8
+int alan_pipeline_create(void *const *calls, int32_t n_lanes, int32_t n_threads, void **pipeline);
+int alan_pipeline_submit(void *pipeline, int64_t count);
+int alan_pipeline_join(void *pipeline, void *stream);
+int alan_pipeline_fence(void *pipeline, void *stream);
+int alan_pipeline_destroy(void *pipeline);
 
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);

@@ -753,45 +753,6 @@ def test_merged_split_keeps_the_memory_bound(oracle_backend, monkeypatch):
     assert abs(chunked - ref) <= 1e-4 * abs(ref) and abs(merged - ref) <= 1e-4 * abs(ref)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("K,split", [(10, None), (30, None), (100, ("plate_1", 38))], ids=["K10", "K30", "K100_split38"])
-@pytest.mark.parametrize("mode,tail", [(1, False), (2, False), (2, True)], ids=["sync_free", "prelude", "prelude+tail"])
-def test_chained_launch_equals_the_separate_launches(K, split, mode, tail, monkeypatch):
-    """alan_normal_lse_chained (producers + fused plate step + final contraction as ONE launch; off by default: measured
-    slower) against the separate launches -- whose value the tests above pin to the reference's -- on particles drawn by
-    the Problem (the layout the bf16x3 kernel takes), eagerly and as a replayed graph; its synchronisation words are left
-    zero and no workgroup ever gave up waiting."""
-    from alan_amd import native as N
-    g = t.Generator().manual_seed(5)
-    x = t.randn(300, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
-    obs = (t.rand(300, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")      # (fp32 data: fp64 takes the wide route)
-    prob = models.movielens(sizes={"plate_1": 300, "plate_2": 5}, x=x, obs=obs)
-    prob.to("cuda")
-    t.manual_seed(3)
-    sample = prob.sample(K, reparam=False)
-    strat = alan.Split(*split) if split else alan.no_checkpoint
-    monkeypatch.setattr(N, "CHAIN_LAUNCHES", 0)
-    separate = float(sample.elbo_nograd(strat, graph=False))
-    monkeypatch.setattr(N, "CHAIN_LAUNCHES", mode)
-    monkeypatch.setattr(N, "CHAIN_TAIL", tail)
-    launched = []
-    real = N._launch_fused
-    monkeypatch.setattr(N, "_launch_fused", lambda: (launched.append((len(N._Q.fused.prelude), len(N._Q.fused.tail))), real())[1])
-    eager = float(sample.elbo_nograd(strat, graph=False))
-    if mode == 1 and K > 32:
-        # (the default policy chains only launches without hand-offs: at K = 100 the [plate, K] producers are not
-        # computed in the tiles, so the plate step goes out alone)
-        assert all(n == (0, 0) for n in launched), launched
-    else:
-        assert launched and launched[-1][0] >= 2 and (launched[-1][1] >= 1) == tail, launched
-    replayed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(4)]
-    t.cuda.synchronize()
-    for got in (eager, *replayed):
-        assert abs(got - separate) <= 2e-6 * abs(separate), (got, separate)
-    for st in (*N._CHAIN_STATE.values(), *[g.chain_state for g in sample.__dict__.get("_graphs", {}).values()]):
-        assert st.tolist() == [0, 0, 0, 0]
-
-
 def _leaves(tree):
     for v in tree.values():
         if isinstance(v, dict):
@@ -886,3 +847,77 @@ def test_direct_replay_of_the_recorded_library_calls_is_the_graphs_replay(monkey
     gb = next(iter(sb.__dict__["_graphs"].values()))
     assert abs(vb - float(sb.elbo_nograd(graph=False))) <= 1e-6 * abs(vb)
     print("bus_breakdown replays through", "its call list" if gb.calls is not None else "its graph")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,threads", [(1, 0), (2, 2), (3, None), (4, 2)], ids=["1lane_caller", "2x2", "3x3", "4lanes_2threads"])
+def test_pipelined_evaluations_equal_the_evaluations_one_by_one(lanes, threads):
+    """sample.EvalPipeline (alan_pipeline_*): independent evaluations issued round-robin on the lanes' own streams by the
+    library's threads -- EVERY result equal to the eager evaluation's, in-place parameter updates made before a submit
+    seen by all of it, more evaluations than a strip holds refused, a second batch after the first."""
+    g = t.Generator().manual_seed(5)
+    x = t.randn(300, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(300, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 300, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    t.manual_seed(3)
+    sample = prob.sample(30, reparam=False)
+    eager = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    pipe = sample.pipeline(alan.no_checkpoint, lanes=lanes, threads=threads, results=64)
+    assert sample.pipeline(alan.no_checkpoint, lanes=lanes, threads=threads, results=64) is pipe
+    for n in (1, 7, 64 * lanes):
+        vals = pipe.run(n)
+        assert vals.shape == (n,)
+        assert float((vals - eager).abs().max()) <= 2e-6 * abs(eager), (n, vals[:8], eager)
+    with pytest.raises(ValueError):
+        pipe.submit(64 * lanes + 1)
+    with t.no_grad():
+        for p in prob.parameters():
+            p.add_(0.05)
+    moved = float(sample.elbo_nograd(alan.no_checkpoint, graph=False))
+    assert abs(moved - eager) > 1e-3 * abs(eager)
+    # two submits before the results are read, the strips wrapping round
+    pipe.submit(40)
+    pipe.submit(2 * lanes + 1)
+    vals = pipe.results()
+    assert vals.shape == (40 + 2 * lanes + 1,)
+    assert float((vals - moved).abs().max()) <= 2e-6 * abs(moved)
+    assert pipe.results().numel() == 0
+    pipe.close()
+
+
+@pytest.mark.gpu
+def test_a_pipeline_refuses_an_evaluation_that_is_not_library_launches_alone():
+    from alan_amd import native as N
+    fx = load_golden("e2e_bus_breakdown_K3.pt")
+    pb = models.BUILDERS["bus_breakdown"](fx).to("cuda")
+    sb = models.sample_from_fixture(pb, fx, "cuda")
+    gb = None
+    try:
+        sb.pipeline(alan.no_checkpoint, lanes=2)
+    except N.NativeError as e:
+        gb = str(e)
+    # (bus_breakdown's lambdas run torch kernels today; should a later round make it library launches alone, the pipeline
+    # must then reproduce the eager value)
+    if gb is None:
+        v = sb.elbo_nograd_many(5, alan.no_checkpoint, lanes=2)
+        eager = float(sb.elbo_nograd(alan.no_checkpoint, graph=False))
+        assert float((v - eager).abs().max()) <= 2e-6 * abs(eager)
+    else:
+        assert "library launches alone" in gb
+
+
+@pytest.mark.gpu
+def test_pipelined_split_evaluation_at_K100():
+    """C4's single-GPU workload (movielens K=100 under Split('plate_1', 38)) through the pipeline."""
+    g = t.Generator().manual_seed(9)
+    x = t.randn(76, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(76, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 76, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    t.manual_seed(4)
+    sample = prob.sample(100, reparam=False)
+    strat = alan.Split("plate_1", 38)
+    eager = float(sample.elbo_nograd(strat, graph=False))
+    vals = sample.elbo_nograd_many(10, strat, lanes=3)
+    assert float((vals - eager).abs().max()) <= 2e-6 * abs(eager), (vals, eager)

@@ -291,11 +291,11 @@ def test_chain_terms_normal_rejects_malformed_descriptors():
     nbytes = L.alan_chain_batched_workspace_bytes(1, 4, 3, 0)
     ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=DEV)
     nd = N.ChainNormal()                                                 # null operands
-    assert L.alan_chain_logmmexp_terms_normal(ptrs, strides, 1, ctypes.byref(nd), 0, 1, 4, 3, None, vec.data_ptr(),
+    assert L.alan_chain_logmmexp_terms_final(ptrs, strides, 1, ctypes.byref(nd), None, 0, 1, 4, 3, None, vec.data_ptr(),
                                               ws.data_ptr(), nbytes, None) == -1
-    assert L.alan_chain_logmmexp_terms_normal(None, strides, 1, None, 0, 1, 4, 3, None, vec.data_ptr(), ws.data_ptr(),
+    assert L.alan_chain_logmmexp_terms_final(None, strides, 1, None, None, 0, 1, 4, 3, None, vec.data_ptr(), ws.data_ptr(),
                                               nbytes, None) == -1
-    assert L.alan_chain_logmmexp_terms_normal(ptrs, strides, 1, None, 0, 1, 4, 3, None, None, ws.data_ptr(), nbytes,
+    assert L.alan_chain_logmmexp_terms_final(ptrs, strides, 1, None, None, 0, 1, 4, 3, None, None, ws.data_ptr(), nbytes,
                                               None) == -1
 
 

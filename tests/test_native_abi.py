@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 12
+    assert L.alan_abi_version() == 13
     assert L.alan_build_target() == b"gfx950"
 
 
@@ -71,7 +71,7 @@ def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
 def test_fused_plate_step_struct_layout_and_rejections():
     """alan_normal_lse_desc_t / alan_normal_lse_backward_desc_t as the header lays them out (natural alignment), and
     malformed descriptors refused before any GPU work."""
-    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 2 * 8 + 8   # (keep_partials + padding)
+    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8   # (keep_partials + padding)
     assert ctypes.sizeof(N.NormalLseDesc) == fwd
     assert ctypes.sizeof(N.NormalLseBackwardDesc) == fwd + 8 + 8 + 2 * 8 + 4 * 8
     L = N.lib()
@@ -115,7 +115,7 @@ def test_bad_descriptors_are_rejected_without_touching_the_gpu():
     d.role[0] = N.REDUCE
     d.n_factors = 1              # null factor pointer
     assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
-    assert L.alan_chain_logmmexp(None, 0, 4, 3, 9, 3, 1, None, None, None, 0, None) == -1
+    assert L.alan_chain_logmmexp_batched(None, 0, 1, 4, 3, 0, 9, 3, 1, None, None, None, 0, None) == -1
 
 
 def test_workspace_query():
@@ -130,8 +130,8 @@ def test_workspace_query():
     d.role[0] = N.KEEP
     assert L.alan_reduce_workspace_bytes(ctypes.byref(d)) == 0
     # every round of the pairwise tree stays in the workspace: 500 + 250 + 125 + 63 + 32 + 16 + 8 + 4 + 2 + 1 nodes
-    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) >= 1001 * 30 * 30 * 4
-    assert L.alan_chain_workspace_bytes(1000, 30, N.F32) < 1001 * 30 * 30 * 4 + 10 * 256
+    assert L.alan_chain_batched_workspace_bytes(1, 1000, 30, N.F32) >= 1001 * 30 * 30 * 4
+    assert L.alan_chain_batched_workspace_bytes(1, 1000, 30, N.F32) < 1001 * 30 * 30 * 4 + 10 * 256
     assert L.alan_chain_batched_workspace_bytes(7, 1, 5, N.F64) == (7 * 25 * 8 + 255) // 256 * 256
     assert L.alan_chain_backward_batched_workspace_bytes(3, 9, 4, N.F32) == L.alan_chain_batched_workspace_bytes(3, 9, 4, N.F32)
 
@@ -203,11 +203,11 @@ def test_new_entry_points_reject_malformed_arguments_without_touching_the_gpu():
     assert L.alan_reduce_batch(None, 0, None) == -1
     one = (ctypes.POINTER(N.ReduceDesc) * 1)(ctypes.POINTER(N.ReduceDesc)())
     assert L.alan_reduce_batch(one, 1, None) == -1                        # a null descriptor in the list
-    assert L.alan_chain_logmmexp_terms(None, None, 1, N.F32, 1, 4, 3, None, None, None, 0, None) == -1
+    assert L.alan_chain_logmmexp_terms_final(None, None, 1, None, None, N.F32, 1, 4, 3, None, None, None, 0, None) == -1
     ptrs = (ctypes.c_void_p * 1)(None)
     st = (ctypes.c_int64 * 4)(0, 9, 3, 1)
-    assert L.alan_chain_logmmexp_terms(ptrs, st, 1, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # null term
-    assert L.alan_chain_logmmexp_terms(ptrs, st, 4, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # > 3 terms
+    assert L.alan_chain_logmmexp_terms_final(ptrs, st, 1, None, None, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # null term
+    assert L.alan_chain_logmmexp_terms_final(ptrs, st, 4, None, None, N.F32, 1, 4, 3, None, None, None, 0, None) == -1     # > 3 terms
     assert L.alan_chain_logmmexp_batched(None, N.F32, 2, 4, 3, 36, 9, 3, 1, None, None, None, 0, None) == -1
     assert L.alan_chain_logmmexp_backward_batched(None, N.F32, 2, 4, 3, 36, 9, 3, 1, None, None, None, None, None, None,
                                                   0, None) == -1
@@ -219,3 +219,26 @@ def test_new_entry_points_reject_malformed_arguments_without_touching_the_gpu():
     d.ndim, d.n_factors = 1, 4
     d.size[0], d.role[0] = 4, N.KEEP
     assert L.alan_reduce(ctypes.byref(d), None, 0, None) == -1
+
+
+def test_launch_lists_and_pipelines_reject_misuse_without_touching_the_gpu():
+    """alan_calls_* / alan_pipeline_*: an empty list records and counts nothing; a pipeline needs lanes that hold launches."""
+    L = N.lib()
+    h = ctypes.c_void_p()
+    assert L.alan_calls_create(ctypes.byref(h)) == 0
+    assert L.alan_calls_count(h) == 0
+    assert L.alan_calls_end(h) == -1                     # (not being recorded)
+    assert L.alan_calls_begin(h) == 0
+    h2 = ctypes.c_void_p()
+    assert L.alan_calls_create(ctypes.byref(h2)) == 0
+    assert L.alan_calls_begin(h2) == -1                  # (one list at a time per thread)
+    assert L.alan_calls_end(h2) == -1
+    assert L.alan_calls_end(h) == 0
+    assert L.alan_calls_count(h) == 0
+    pipe = ctypes.c_void_p()
+    lanes = (ctypes.c_void_p * 2)(h, h2)
+    assert L.alan_pipeline_create(lanes, 2, 2, ctypes.byref(pipe)) == -1     # (lanes without launches)
+    assert L.alan_pipeline_create(lanes, 0, 0, ctypes.byref(pipe)) == -1
+    assert L.alan_pipeline_create(lanes, 99, 0, ctypes.byref(pipe)) == -1
+    assert L.alan_pipeline_submit(None, 1) == -1 and L.alan_pipeline_join(None, None) == -1
+    assert L.alan_calls_destroy(h) == 0 and L.alan_calls_destroy(h2) == 0
