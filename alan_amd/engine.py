@@ -106,21 +106,22 @@ class ResultRing:
 
 
 class ResultStrip(ResultRing):
-    """A result ring whose slots are the consecutive elements of ONE buffer: for a caller that issues many replays before
-    it reads any result (sample.EvalPipeline) -- replay k of the evaluation delivers to element k % n, nothing is claimed
-    or recycled, and a run of results is a view."""
+    """A result ring whose slots are elements of ONE buffer, ``stride`` apart from ``offset`` on: for a caller that issues
+    many replays before it reads any result (sample.EvalPipeline, whose lanes interleave their slots so that evaluation i
+    of the whole pipeline lands in element i) -- replay k of the evaluation delivers to element offset + stride (k % n),
+    nothing is claimed or recycled, and a run of results is a view."""
 
-    def __init__(self, device, n):
+    def __init__(self, device, n, buf=None, offset=0, stride=1):
         self.device, self.n = device, int(n)
-        self.buf = t.empty(self.n, dtype=t.float32, device=device)
+        self.buf = buf if buf is not None else t.empty(self.n * stride, dtype=t.float32, device=device)
         self.slots = None
-        self.table = t.arange(self.n, dtype=t.int64, device=device) * 4 + self.buf.data_ptr()
+        self.table = (t.arange(self.n, dtype=t.int64, device=device) * stride + offset) * 4 + self.buf.data_ptr()
         self.counter = t.zeros((), dtype=t.int32, device=device)
         self.placeholder = t.empty((), dtype=t.float32, device=device)
         self.pos, self.taken, self.declined = 0, 0, False
 
     def sync_position(self):
-        self.counter.zero_()                       # (warm-ups advanced it: replays start at element 0)
+        self.counter.zero_()                       # (warm-ups advanced it: replays start at the first element)
         self.pos = 0
 
     def claim(self):

@@ -155,8 +155,11 @@ class EvalPipeline:
         self.sample, self.strategy, self.n_lanes, self.capacity = sample, computation_strategy, lanes, int(results)
         self.fingerprint = sample.problem.memory_fingerprint()
         self._h = None
-        self.lanes = [_GraphedELBO(sample, computation_strategy, ring=E.ResultStrip(sample.device, results))
-                      for _ in range(lanes)]
+        # (the lanes' result slots interleaved in one buffer: evaluation i of the pipeline delivers to element i mod its size)
+        self.buf = t.empty(lanes * self.capacity, dtype=t.float32, device=sample.device)
+        self.lanes = [_GraphedELBO(sample, computation_strategy,
+                                   ring=E.ResultStrip(sample.device, results, buf=self.buf, offset=l, stride=lanes))
+                      for l in range(lanes)]
         for ln in self.lanes:
             if ln.calls is None or not isinstance(ln.ring, E.ResultStrip):
                 raise N.NativeError("alan_amd: this evaluation is not library launches alone (a model lambda's torch kernels, "
@@ -182,20 +185,22 @@ class EvalPipeline:
         N.check(L.alan_pipeline_submit(self._h, int(n)), "alan_pipeline_submit")
         self.total += int(n)
 
-    def results(self):
-        """The ELBOs of every evaluation submitted since the last results() call, in submission order: a new [n] fp32
-        tensor, ordered after the evaluations on the current stream."""
+    def results(self, copy=True):
+        """The ELBOs of every evaluation submitted since the last results() call, in submission order, ordered after the
+        evaluations on the current stream: a new [n] fp32 tensor -- or, ``copy=False``, a VIEW of the pipeline's result
+        buffer (no kernel at all), valid until lanes x results further evaluations have been submitted."""
         from . import native as N
         stream = t.cuda.current_stream(self.sample.device).cuda_stream
         N.check(N.lib().alan_pipeline_join(self._h, stream), "alan_pipeline_join")
-        i0, i1, L, R = self.first, self.total, self.n_lanes, self.capacity
+        i0, i1, size = self.first, self.total, self.n_lanes * self.capacity
         self.first = i1
+        # evaluation i ran on lane i % L as that lane's evaluation i // L: element i mod (L R) of the shared buffer
+        a, b = i0 % size, i1 % size
         if i1 == i0:
             return t.empty(0, dtype=t.float32, device=self.sample.device)
-        # evaluation i ran on lane i % L as that lane's evaluation i // L: element (i // L) % R of its strip
-        idx = t.arange(i0, i1, device=self.sample.device)
-        strips = t.stack([ln.ring.buf for ln in self.lanes])
-        return strips[idx % L, (idx // L) % R]
+        if a < b:
+            return self.buf[a:b].clone() if copy else self.buf[a:b]
+        return t.cat([self.buf[a:], self.buf[:b]])
 
     def run(self, n):
         self.submit(n)

@@ -171,6 +171,54 @@ def timed_evals(sample, strat, steps, warmup, world, timer=None, graph=False):
     return dt, float(val)
 
 
+def pipelined_figure(sample, strat, n, lanes, single_us):
+    """A secondary configuration through sample.EvalPipeline: n evaluations, every result checked against the eager value."""
+    try:
+        with t.no_grad():
+            ev = float(sample.elbo_nograd(strat, graph=False))
+        pipe = sample.pipeline(strat, lanes=lanes, results=max(64, -(-n // lanes) + 8))
+        pipe.run(2 * lanes)
+        t.cuda.synchronize()
+        t0 = time.perf_counter()
+        vals = pipe.run(n)
+        t.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        worst = float((vals - ev).abs().max()) / abs(ev)
+        pipe.close()
+        sample.__dict__.get("_pipelines", {}).clear()
+        if not worst <= 2e-6:
+            return {"error": f"pipelined evaluations differ from the eager value by {worst:.3g} (relative)"}
+        return {"n_streams": lanes, "evaluations": n, "us_per_eval": dt * 1e6, "evals_per_s": 1 / dt,
+                "max_rel_diff_vs_eager": worst, "against_one_after_another": single_us / (dt * 1e6)}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def timed_pipeline(sample, strat, steps, warmup, lanes, eager_value):
+    """`steps` INDEPENDENT evaluations through sample.EvalPipeline (alan_pipeline_*: `lanes` recorded copies of the
+    evaluation, each on a stream of its own, issued round-robin by the library's threads), timed as the contract says
+    (synchronize on both sides), EVERY result checked against the eager evaluation's value."""
+    pipe = sample.pipeline(strat, lanes=lanes)
+    pipe.run(max(warmup, 1))
+    pipe.run(max(warmup, 1))
+    t.cuda.synchronize()
+    t0 = time.perf_counter()
+    vals = pipe.run(steps)
+    t.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    worst = float((vals - eager_value).abs().max()) / abs(eager_value)
+    if not worst <= 2e-6:
+        raise RuntimeError(f"pipelined evaluations differ from the eager value by {worst:.3g} (relative)")
+    # the steady state beside it: the same pipeline over 150 x as many evaluations (what a long loop sees)
+    n_long = min(150 * steps, lanes * pipe.capacity)
+    t.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(n_long)
+    t.cuda.synchronize()
+    dt_long = (time.perf_counter() - t0) / n_long
+    return dt, float(vals[-1]), worst, dt_long
+
+
 def sample_on_cpu(sample, cpu_prob):
     """The same particles as a Sample of the CPU problem (fresh Dim objects, matched by name)."""
     import alan_amd as alan
@@ -394,6 +442,24 @@ def main():
         except Exception as e:                           # capture unsupported: eager
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
+    # ---- the headline: independent evaluations OVERLAPPED (one GPU, library launches alone); the one-after-another figure
+    # stays beside it as `single_stream`
+    PIPE_LANES = int(os.environ.get("ALAN_BENCH_LANES", "4"))
+    single = None
+    pipelined = None
+    if use_graph and world == 1 and PIPE_LANES > 1:
+        try:
+            with t.no_grad():
+                eager_val = float(sample.elbo_nograd(strat, graph=False))
+            dt_p, elbo_p, worst, dt_long = timed_pipeline(sample, strat, args.steps, args.warmup, PIPE_LANES, eager_val)
+            single = {"evals_per_s": args.steps / dt, "us_per_eval": dt / args.steps * 1e6, "launch": launch_mode(sample, use_graph)}
+            pipelined = {"n_streams": PIPE_LANES, "issuing_threads": PIPE_LANES,
+                         "max_rel_diff_vs_eager": worst, "steady_state_us_per_eval": dt_long * 1e6,
+                         "steady_state_evals_per_s": 1.0 / dt_long}
+            dt, elbo = dt_p, elbo_p
+        except Exception as e:
+            print(f"[bench] pipelined evaluations unavailable ({type(e).__name__}: {e}); one after another", file=sys.stderr)
+            single = pipelined = None
     kt = KernelTimer(min_bytes=1 << 20)
     if use_graph:
         # per-kernel HIP events cannot be recorded inside a replayed graph: time the same launches
@@ -412,7 +478,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"movielens M={M_USERS} N={N_FILMS} d_z={D_Z}, K={K}, elbo_nograd on a fixed sample",
-                   "launch": launch_mode(sample, use_graph),
+                   "launch": (f"{pipelined['n_streams']} independent evaluations in flight (sample.EvalPipeline / alan_pipeline_*: "
+                              f"{pipelined['n_streams']} recorded copies of the evaluation, each re-issued on a stream of its "
+                              "own by a library thread; every result checked against the eager value); one evaluation after "
+                              "another: `single_stream`") if pipelined else launch_mode(sample, use_graph),
+                   "n_streams": pipelined["n_streams"] if pipelined else 1,
                    "plate_step": "fused (alan_normal_lse: producer + log-sum-exp + plate sum in one launch)"
                    if adist.FUSE_PLATE_STEP else "materialised factor (producer kernel + rows kernel)",
                    "computation_strategy": type(strat).__name__ +
@@ -421,6 +491,9 @@ def main():
                    if world > 1 else "single GPU"},
         "elbo": elbo,
     }
+    if pipelined:
+        out["pipelined"] = pipelined
+        out["single_stream"] = single
     # ---- roofline of the DOMINANT kernel of the evaluation, timed live with HIP events handed to its launch
     rf = fused_roofline(res, native.MODE_FUSED_FWD,
                         "alan::normal_lse_x3_kernel (plate_1 step, the factor F[M,K,K,K] never materialised: per "
@@ -456,6 +529,9 @@ def main():
                                         # chunks one slice unless that would break Split's memory bound)
                                         "merged": st100.merging() and len(getattr(st100, "last_sizes", [])) == max(1, world),
                                         "effective_chunk_sizes": getattr(st100, "last_sizes", None)}
+            if world == 1 and use_graph:
+                # independent evaluations overlapped (alan_pipeline_*), as the headline
+                out["c4_movielens_K100"]["pipelined"] = pipelined_figure(s100, st100, 200, 3, d100 / 10 * 1e6)
             with KernelTimer() as kt100:
                 for _ in range(5):
                     s100.elbo_nograd(st100)
@@ -490,6 +566,16 @@ def main():
                                       # [K, K] partial, 40 KB, comes on top)
                                       "projected_speedup_before_collective":
                                           out["c4_movielens_K100"]["ms_per_eval"] * 1e3 / (dn / 10 * 1e6)}
+                    if use_graph:
+                        # the rank's evaluations overlapped: THROUGHPUT per evaluation of one rank's share, and what it
+                        # allows against the one-GPU evaluation -- one after another, and overlapped as well
+                        pf = pipelined_figure(sn, alan.no_checkpoint, 400, 4, dn / 10 * 1e6)
+                        if "error" not in pf:
+                            pf["projected_speedup_before_collective"] = out["c4_movielens_K100"]["ms_per_eval"] * 1e3 / pf["us_per_eval"]
+                            p1 = out["c4_movielens_K100"].get("pipelined", {})
+                            if "us_per_eval" in p1:
+                                pf["projected_speedup_before_collective_vs_pipelined_n1"] = p1["us_per_eval"] / pf["us_per_eval"]
+                        share[f"N{n}"]["pipelined"] = pf
                     del pn, sn
                 out["c4_movielens_K100"]["rank_share_no_collective"] = share
             except Exception as e:
