@@ -275,11 +275,12 @@ class Problem(nn.Module):
         # (the tensors are read from every module's own _parameters / _buffers dicts on every call; what is remembered is
         # only the LIST of modules -- nn.Module.parameters() spends most of its time re-walking the module tree, a third of
         # a replayed evaluation's host time -- and that list is rebuilt whenever a module gained or lost a child)
+        # -- or had one REPLACED by another module: the children are compared by identity, not counted)
         mods = self.__dict__.get("_fp_modules")
-        if mods is None or sum(len(m._modules) for m in mods) != self.__dict__.get("_fp_children"):
+        if mods is None or tuple(id(c) for m in mods for c in m._modules.values()) != self.__dict__.get("_fp_children"):
             mods = list(self.modules())
             self.__dict__["_fp_modules"] = mods
-            self.__dict__["_fp_children"] = sum(len(m._modules) for m in mods)
+            self.__dict__["_fp_children"] = tuple(id(c) for m in mods for c in m._modules.values())
         out, seen = [], set()
         for m in mods:
             for x in (*m._parameters.values(), *m._buffers.values()):

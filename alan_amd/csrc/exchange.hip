@@ -46,7 +46,9 @@ __global__ __launch_bounds__(EX_THREADS) void exchange_sum_kernel(const ExDesc d
     const int q = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
         s_step = __hip_atomic_load(d.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        s_bad = 0;
+        // a rank that has timed out once stays failed: its peers may have completed that exchange with a valid sum, so its
+        // later results are NaN too (it still delivers and waits: the peers' protocol goes on) until the caller resets
+        s_bad = __hip_atomic_load(d.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
     }
     __syncthreads();
     const unsigned step = s_step;
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(EX_THREADS) void exchange_sum_kernel(const ExDesc d
     }
     __syncthreads();
     if (tid == 0) {
-        if (bad) __hip_atomic_store(d.state + 2, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bad) {                                // (the FIRST exchange that failed; later ones leave it)
+            unsigned expect = 0u;
+            __hip_atomic_compare_exchange_strong(d.state + 2, &expect, step, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __atomic_thread_fence(__ATOMIC_RELEASE);
         unsigned ticket = __hip_atomic_fetch_add(d.state + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == (unsigned)d.world - 1u) {   // every workgroup has read state[0] and finished: publish the number

@@ -522,6 +522,8 @@ class _DrawBatch:
                     res = _affine_batch([(mine[k][0], mine[k][1], mine[k][2], eps[k], specs[k]) for k in rest])
                 for k, x in zip(rest, res):
                     outs[k] = x
+            if BATCH_NOISE:
+                _release_unused_slot(src)
             for j, x in zip(mine, outs):
                 j[5]._val = x
 
@@ -546,6 +548,8 @@ def _affine_batch(jobs):
                 z.declined = True
                 e.normal_()
                 x = E._produce(N.MODE_AFFINE, args, axes, scales=[1.0, 1.0, 2.0 if lg else 1.0])
+            elif z is not None:
+                z.src.used = True
             outs.append(x)
     N.flush()                                             # (inside someone else's deferring() the exit above issues nothing)
     return outs
@@ -563,7 +567,7 @@ False: the noise is torch's, drawn into memory."""
 class _NoiseSource:
     """Where one batch of draws gets its noise: (seed, offset) by value from torch's generator, or a captured graph's
     device-side state."""
-    __slots__ = ("seed", "offset", "cell", "receipt", "advance", "advance_by")
+    __slots__ = ("seed", "offset", "cell", "receipt", "advance", "advance_by", "state", "used")
 
 
 def _noise_source(dev, dtype, total, reparam):
@@ -572,7 +576,7 @@ def _noise_source(dev, dtype, total, reparam):
         return None
     inc = 4 * ((total + 3) // 4)
     src = _NoiseSource()
-    src.advance_by = inc
+    src.advance_by, src.state, src.used = inc, None, False
     if t.cuda.is_current_stream_capturing():
         st = N.graph_noise(dev)
         if st is None:                                    # (someone else's capture: torch's generator knows how to be captured)
@@ -583,11 +587,21 @@ def _noise_source(dev, dtype, total, reparam):
         src.seed, src.offset, (src.cell, src.advance) = 0, 0, slot
         src.receipt = t.empty(2, dtype=t.int64, device=dev) if reparam else None
         st.per_replay += inc
+        src.state = st                                    # (given back by _release_unused_slot if no launch takes it)
         return src
     gen = t.cuda.default_generators[dev.index if dev.index is not None else t.cuda.current_device()]
     src.seed, src.offset, src.cell, src.receipt, src.advance = gen.initial_seed(), gen.get_offset(), None, None, None
     gen.set_offset(src.offset + inc)
     return src
+
+
+def _release_unused_slot(src):
+    """A captured graph's ring slot that NO launch of its batch took (the library declined every job: the draws fell back
+    to torch's normal_): given back, so that the ring the capture closes holds only slots some launch reads and writes --
+    a reserved slot nobody writes would leave every later drawing launch reading {counter 0, seed 0} on every replay."""
+    if src is not None and src.state is not None and not src.used:
+        src.state.release_last(src.advance_by)
+        src.state = None
 
 
 class _NoiseSpec:

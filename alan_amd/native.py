@@ -425,6 +425,12 @@ class GraphNoise:
         j, self.n = self.n, self.n + 1
         return self.state[2 * j:2 * j + 2], self.state[2 * self.MAX_LAUNCHES + j:2 * self.MAX_LAUNCHES + j + 1]
 
+    def release_last(self, inc):
+        """The most recent next_launch() taken back: no launch reads or writes that slot (dist._release_unused_slot)."""
+        if self.n > 0:
+            self.n -= 1
+            self.per_replay -= inc
+
     def carry(self, items):
         """A batch of queued launches issued inside the capture, behind the only launch that drew so far: its first
         small-problem launch also copies slot 1 back to slot 0 (alan_noise_t.on = 2) -- the hand-on without a launch of

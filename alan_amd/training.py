@@ -131,23 +131,25 @@ def stale_grad_accumulators(params):
     profiles/r3_graphed_step_crash.txt).  The test is structural: a tensor holds its accumulator weakly, so a node
     fetched, tagged and released is gone at the next fetch unless another graph holds it."""
     import gc
-    held = []
-    for p in params:
-        if not p.requires_grad:
-            continue
-
-        def fetch():
+    params = [p for p in params if p.requires_grad]
+    with t.enable_grad():                                 # (under no_grad a view has no grad_fn to reach the node through)
+        def fetch(p):
             return p.view_as(p).grad_fn.next_functions[0][0]
-        node = fetch()
-        node.metadata["alan_amd_probe"] = True
-        del node
-        gc.collect()
-        node = fetch()
-        alive = node.metadata.pop("alan_amd_probe", False)
-        del node
-        if alive:
-            held.append(p)
+        for p in params:                                  # tag every node, ...
+            fetch(p).metadata["alan_amd_probe"] = True
+        gc.collect()                                      # ... ONE collection, ...
+        held = []
+        for p in params:                                  # ... and whoever still carries the tag is held by another graph
+            node = fetch(p)
+            if node.metadata.pop("alan_amd_probe", False):
+                held.append(p)
+            del node
     return held
+
+
+_UNSAFE_SKIP_STALE_CHECK = False
+"""Debugging only (tools/graphed_step_crash_probe.py, one recorded run: profiles/r3_graphed_step_crash.txt): with it set,
+constructing a GraphedStep over a live autograd graph is known to end in SIGSEGV inside hipStreamEndCapture."""
 
 
 class GraphedStep:
@@ -159,7 +161,7 @@ class GraphedStep:
     ``maximize=True`` (the loss is ``-elbo`` for both methods)."""
 
     def __init__(self, problem, K, optimizer, method="vi", computation_strategy=no_checkpoint, warmup=3,
-                 capture_stream=None, allow_memset_nodes=False, _unsafe=False, unroll=1):
+                 capture_stream=None, allow_memset_nodes=False, unroll=1):
         """``capture_stream``: diagnostics (tools/graph_race_probe.py) -- capture on another stream than the warm-up
         one.  ``allow_memset_nodes``: only warn about memset nodes in the captured graph (see ``memset_nodes``).
         ``unroll``: that many consecutive iterations per captured graph -- a replay then runs them all and returns their
@@ -178,7 +180,7 @@ class GraphedStep:
         self.problem, self.K, self.opt, self.method = problem, K, optimizer, method
         self.strategy = computation_strategy
         held = stale_grad_accumulators(problem.parameters())
-        if held and not _unsafe:
+        if held and not _UNSAFE_SKIP_STALE_CHECK:
             raise RuntimeError(_STALE_MSG + f"  (parameters: {len(held)})")
         side = t.cuda.Stream()
         side.wait_stream(t.cuda.current_stream())
@@ -198,7 +200,7 @@ class GraphedStep:
         for w in seen:
             if w not in stale:
                 warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
-        if stale and not _unsafe:
+        if stale and not _UNSAFE_SKIP_STALE_CHECK:
             # (second net, by torch's own stream-mismatch warning during the warm-up: the structural check above is the
             # guard proper and does not depend on this text)
             raise RuntimeError(_STALE_MSG)

@@ -385,8 +385,11 @@ int alan_chain_filter(const void *ms, int64_t C, int64_t T, int64_t K, int64_t s
  *   alan_exchange_sum      out[0..n) = sum over ranks q = 0..world-1, in that order, of rank q's src[0..n); fp32, device
  *                          pointers, enqueued on `stream`.  A peer that has not delivered within ALAN_EXCHANGE_SPIN_MS
  *                          (environment, default 2000) ends the wait: out is filled with NaN and the exchange is marked
- *                          failed (alan_exchange_status) -- no launch spins for ever.  Issue the first exchange only
- *                          after every rank has connected (a host barrier).
+ *                          failed (alan_exchange_status) -- no launch spins for ever.  A rank that has failed once
+ *                          STAYS failed: every later exchange on it yields NaN as well (its peers may have completed
+ *                          the failed exchange with a valid sum: the ranks have diverged, and the failed one says so
+ *                          loudly) -- destroy and re-create the exchange on every rank behind a barrier.  Issue the
+ *                          first exchange only after every rank has connected (a host barrier).
  *   alan_exchange_status   synchronous read-back: exchanges completed on this rank, and the number of the first one
  *                          that timed out (0 = none).
  *   alan_exchange_destroy  closes the peers' inboxes and frees this rank's (after the peers have stopped writing). */

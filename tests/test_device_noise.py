@@ -240,6 +240,36 @@ def test_unrolled_graphs_run_their_iterations_in_order_with_fresh_particles():
 
 
 @pytest.mark.gpu
+def test_a_draw_the_library_declines_inside_a_capture_leaves_the_noise_ring_whole(monkeypatch):
+    """a batch of draws ALL of whose jobs the library declines (here: every draw of more than 10,000 elements,
+    i.e. the plate's z) falls back to torch's normal_ -- the ring slot reserved for it must be given back, or the ring the
+    capture closes wires the neighbouring launches to a slot nobody writes and every replay repeats the same particles.
+    GraphedEval(unroll=2): four draw batches per replay, two of them declined; twelve evaluations, twelve different values,
+    and the values' spread is that of fresh draws."""
+    from alan_amd import engine as E
+    real = E._produce
+
+    def picky(mode, factors, *a, noise=None, **k):
+        if noise is not None and factors[1][0].numel() > 10000:
+            return None
+        return real(mode, factors, *a, noise=noise, **k)
+
+    monkeypatch.setattr(E, "_produce", picky)
+    prob = _movielens()
+    ev = alan.GraphedEval(prob, 8, unroll=2)
+    assert ev.noise.n == 2                      # (the two top-level batches; the two declined ones gave their slots back)
+    t.manual_seed(5)
+    vals = [v for _ in range(6) for v in ev().tolist()]
+    assert len(set(vals)) == 12, vals
+    monkeypatch.setattr(E, "_produce", real)
+    ref = alan.GraphedEval(prob, 8)
+    t.manual_seed(5)
+    plain = t.tensor([float(ref()) for _ in range(24)])
+    got = t.tensor(vals)
+    assert abs(float(got.mean() - plain.mean())) <= 4 * float(plain.std()) / (12 ** 0.5) + 1e-3 * abs(float(plain.mean()))
+
+
+@pytest.mark.gpu
 def test_graphed_eval_replays_through_its_recorded_launches():
     """sample() + elbo on movielens is library launches from the noise to the final log-sum-exp: GraphedEval issues them
     again one by one (sample.DIRECT_REPLAY) -- the same values as its graph would produce under the same seed."""

@@ -238,7 +238,11 @@ def test_fused_plate_step_backward_against_fp64_autograd(M, NK, NL, NS, Ev, n_sm
     for n, a, b in zip(names, grads, ref):
         assert a.shape == b.shape, n
         scale = float(b.abs().max()) + 1e-6
-        t.testing.assert_close(a.cpu().double(), b, rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")
+        # the reference's own acceptance of a backward (tests/test_problem_vs_itself.py:71-88, 264-280: rtol 1e-4, atol 1e-5
+        # on O(1) moments), scaled by the gradient's magnitude -- the default backward (V / U products on bf16 with 2-way
+        # split operands) reaches 0.56 of it at worst, the all-fp32 form 0.48, fp32 autograd through torch 0.08
+        # (tools/nlse_bwd_precision.py, profiles/r4_fused_backward_precision.md)
+        t.testing.assert_close(a.cpu().double(), b, rtol=1e-4, atol=1e-5 * scale, msg=lambda m_: f"{n}: {m_}")
 
 
 def test_fused_plate_step_backward_small_only_and_partial_needs():
@@ -257,7 +261,7 @@ def test_fused_plate_step_backward_small_only_and_partial_needs():
                               log_scale=True)
         (got,) = t.autograd.grad((out * G.to(DEV)).sum(), [ts[which]])
         scale = float(ref[which].abs().max()) + 1e-6
-        t.testing.assert_close(got.cpu().double(), ref[which], rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"arg {which}: {m_}")
+        t.testing.assert_close(got.cpu().double(), ref[which], rtol=1e-4, atol=1e-5 * scale, msg=lambda m_: f"arg {which}: {m_}")
 
 
 def test_fused_plate_step_backward_layouts_and_fp64_small():
@@ -281,7 +285,7 @@ def test_fused_plate_step_backward_layouts_and_fp64_small():
     assert gs.dtype == t.float64 and gz.shape == zt.shape
     for n, a, b in (("value", gz.transpose(0, 1), ref[0]), ("loc", gm, ref[1]), ("scale", gr, ref[2]), ("small", gs, ref[3])):
         scale = float(b.abs().max()) + 1e-6
-        t.testing.assert_close(a.cpu().double(), b, rtol=2e-3, atol=2e-4 * scale, msg=lambda m_: f"{n}: {m_}")
+        t.testing.assert_close(a.cpu().double(), b, rtol=1e-4, atol=1e-5 * scale, msg=lambda m_: f"{n}: {m_}")
 
 
 @pytest.mark.parametrize("method", ["vi", "rws"])

@@ -23,7 +23,9 @@ try:
 except RuntimeError as e:
     print("guard: refused --", str(e)[:120], flush=True)
 print("now with the guard bypassed:", flush=True)
-step = GraphedStep(prob, 10, opt, _unsafe=True)
+import alan_amd.training as _T
+_T._UNSAFE_SKIP_STALE_CHECK = True            # (the guard bypassed: this probe exists to record the crash, once)
+step = GraphedStep(prob, 10, opt)
 print("capture ended without a crash; replaying", flush=True)
 for _ in range(3):
     v = step()
