@@ -34,6 +34,8 @@ from .contract import (reduce_Ks, collect_lps, logsumexp_sum, logsumexp_dims, lo
                        chain_logmmexp)
 
 from .training import GraphedStep, GraphedEval
+from .optim import Adam
+from .sample import EvalPipeline
 
 samplers = [CategoricalSampler, PermutationSampler]
 

@@ -48,7 +48,7 @@ struct SmallDesc {
     float fscale[MAXF];
     float *const *ring_slots;      // result ring (alan_reduce_desc_t.ring_*); ring_n = 0: off
     int32_t *ring_counter;
-    int32_t ring_n;
+    int32_t ring_n, ring_and_out;
     int32_t presum_n, presum_stride;   // role ALAN_PRESUM: factor 0 is the sum of presum_n slices presum_stride apart (0: off)
     int32_t noise_on;                  // alan_noise_t: factor 1 is generated (ALAN_MODE_AFFINE / ALAN_MODE_DOT)
     uint64_t noise_off;
@@ -150,7 +150,7 @@ struct EvPair {
     hipEvent_t start = nullptr, stop = nullptr;
     // result ring of the call (alan_reduce_desc_t.ring_*): only the single-workgroup small kernel honours it
     void *ring_slots = nullptr, *ring_counter = nullptr;
-    int ring_n = 0;
+    int ring_n = 0, ring_and_out = 0;
 };
 inline NoiseLaunch noise_launch(const alan_noise_t *n, bool advance) {
     NoiseLaunch r;

@@ -782,7 +782,7 @@ static int run_presum(const alan_reduce_desc_t &d2, int64_t n, int64_t stride, h
     ev.stop = (hipEvent_t)d2.ev_stop;
     if (d2.ring_n) {
         if (d2.ring_n < 0 || !d2.ring_slots || !d2.ring_counter) return ALAN_ERR_BAD_DESC;
-        ev.ring_slots = d2.ring_slots, ev.ring_counter = d2.ring_counter, ev.ring_n = d2.ring_n;
+        ev.ring_slots = d2.ring_slots, ev.ring_counter = d2.ring_counter, ev.ring_n = d2.ring_n, ev.ring_and_out = d2.ring_and_out;
     }
     const int mode = (d2.mode == ALAN_MODE_LSE && red == 0) ? ALAN_MODE_SUM : d2.mode;     // (log-sum-exp over no dims)
     Canon c;
@@ -918,7 +918,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
             return ALAN_ERR_UNSUPPORTED;
         ev.ring_slots = d->ring_slots;
         ev.ring_counter = d->ring_counter;
-        ev.ring_n = d->ring_n;
+        ev.ring_n = d->ring_n, ev.ring_and_out = d->ring_and_out;
     }
     if (d->mode == ALAN_MODE_LSE && red == 0) {
         // logsumexp over no dims is the identity (utils.py:217): plain broadcast sum of the factors,

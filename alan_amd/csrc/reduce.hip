@@ -438,7 +438,7 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
         if (gd.n_out != 1 || gl.grid != 1) return ALAN_ERR_UNSUPPORTED;
         sd.ring_slots = (float *const *)ev.ring_slots;
         sd.ring_counter = (int32_t *)ev.ring_counter;
-        sd.ring_n = ev.ring_n;
+        sd.ring_n = ev.ring_n, sd.ring_and_out = ev.ring_and_out;
     }
     if (gd.n_out == 0) return ALAN_OK;
     // one output, thousands of loads: the 1024-thread kernel (every load of a thread's share in flight in two rounds)

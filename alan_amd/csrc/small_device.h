@@ -268,6 +268,7 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
             const int32_t slot = *d.ring_counter;
             small_store(d.ring_slots[slot], v + d.add_const);
             *d.ring_counter = slot + 1 == d.ring_n ? 0 : slot + 1;
+            if (d.ring_and_out) small_store(d.out + obase, v + d.add_const);
         } else {
             small_store(d.out + obase, v + d.add_const);
         }

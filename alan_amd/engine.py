@@ -138,6 +138,7 @@ kernel -- at roughly twice the time."""
 
 
 _RING = [None]          # set by sample._GraphedELBO around warm-up + capture of one evaluation
+_MIRROR_RING = [None]   # a mirror ring on its way into _Reduce.forward (training.GraphedStep: the ELBO kept AND delivered)
 
 
 class TooLargeForMergedSplit(Exception):
@@ -159,7 +160,7 @@ def _empty(shape, dtype, device):
 
 
 def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=None, add_const=0.0,
-            scales=None, out_scale=1.0, ring=None, noise=None):
+            scales=None, out_scale=1.0, ring=None, noise=None, ring_and_out=False):
     space = list(sizes)
     if len(space) > N.MAX_DIMS:
         raise N.NativeError(f"alan_amd: {len(space)} dims in one contraction step (max {N.MAX_DIMS})")
@@ -195,6 +196,7 @@ def _launch(mode, factors, sizes, roles, out, out_dims, weight=None, lse_out=Non
         algo += weight[0].numel() * weight[0].element_size()
     if ring is not None:
         desc.ring_slots, desc.ring_counter, desc.ring_n = ring.table.data_ptr(), ring.counter.data_ptr(), ring.n
+        desc.ring_and_out = int(bool(ring_and_out))
     if noise is not None:
         # factor 1 is generated inside the launch (alan_noise_t); noise = (seed, offset, cell, receipt, advance, advance_by),
         # the three in the middle int64 device tensors or None
@@ -263,6 +265,15 @@ def _reduce_forward(spec, tensors, need_grad, ring=None, presum=()):
         ring.declined = True
     out = _empty([sizes[d] for d in out_dims], dtype, device)
     lse = None
+    if (ring is not None and getattr(ring, "mirror", False) and not ring.declined and reduce and not out_dims and not plate
+            and need_grad and dtype == t.float32 and ring.device == device):
+        # a training iteration's ELBO: `out` is kept for the backward, the ring's slot receives the same value (what
+        # training.GraphedStep hands its caller: no copy of the graph's output buffer after a replay)
+        roles = {d: N.REDUCE for d in sizes}
+        if _launch(mode, factors, sizes, roles, out, out_dims, add_const=add_const, ring=ring, ring_and_out=True):
+            ring.taken += 1
+            return out, out_dims, (out, out_dims), sizes
+        ring.declined = True
     if reduce:
         roles = {d: (N.REDUCE if d in reduce else N.PLATE if d in plate else N.KEEP) for d in sizes}
         if plate and need_grad:
@@ -305,7 +316,8 @@ class _Reduce(t.autograd.Function):
     @staticmethod
     def forward(ctx, spec, *tensors):
         dimlists, reduce, plate, add_const = spec
-        out, out_dims, lse, sizes = _reduce_forward(spec, tensors, any(x.requires_grad for x in tensors))
+        ring, _MIRROR_RING[0] = _MIRROR_RING[0], None
+        out, out_dims, lse, sizes = _reduce_forward(spec, tensors, any(x.requires_grad for x in tensors), ring)
         ctx.spec = (dimlists, tuple(reduce), tuple(plate), add_const, tuple(out_dims), sizes)
         ctx.lse_dims = None if lse is None else tuple(lse[1])
         ctx.has_lse = bool(reduce)
@@ -444,7 +456,9 @@ def _reduce_factors(factors, reduce=(), plate=(), add_const=0.0, ring=None, pres
     if not (t.is_grad_enabled() and any(x.requires_grad for x in tensors)):
         out, out_dims, _, _ = _reduce_forward(spec, tensors, False, ring)   # nothing to record: no autograd.Function
         return out, tuple(out_dims)
+    _MIRROR_RING[0] = ring if (ring is not None and getattr(ring, "mirror", False)) else None
     out = _Reduce.apply(spec, *tensors)
+    _MIRROR_RING[0] = None
     sizes = _space(factors)
     keep = [d for d in sizes if d not in reduce and d not in plate]
     return out, tuple(_out_order([(x.detach(), d) for x, d in factors], keep, sizes))

@@ -70,7 +70,7 @@ class ReduceDesc(C.Structure):
         ("ev_stop", C.c_void_p),
         ("ring_slots", C.c_void_p),
         ("ring_counter", C.c_void_p),
-        ("ring_n", C.c_int32),
+        ("ring_n", C.c_int32), ("ring_and_out", C.c_int32),
         ("noise", Noise),
     ]
 
@@ -107,6 +107,18 @@ class NormalLseBackwardDesc(C.Structure):
                 ("grad_out", C.c_void_p), ("g_sl", C.c_int64), ("g_ss", C.c_int64),
                 ("grad_value", C.c_void_p), ("grad_loc", C.c_void_p), ("grad_scale", C.c_void_p),
                 ("grad_small", C.c_void_p)]
+
+
+ADAM_MAX_TENSORS = 24
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("maximize", C.c_int32),
+                ("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", C.c_int64 * ADAM_MAX_TENSORS),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("step", C.c_void_p), ("ticket", C.c_void_p)]
 
 
 _lib = None
@@ -200,6 +212,8 @@ def lib():
         L.alan_calls_replay.argtypes = [C.c_void_p, C.c_void_p]
         L.alan_calls_destroy.restype = C.c_int
         L.alan_calls_destroy.argtypes = [C.c_void_p]
+        L.alan_adam_step.restype = C.c_int
+        L.alan_adam_step.argtypes = [C.POINTER(AdamDesc), C.c_void_p]
         L.alan_abi_version.restype = C.c_int
         L.alan_build_target.restype = C.c_char_p
         _lib = L
@@ -217,7 +231,7 @@ EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "a
            "alan_calls_create", "alan_calls_begin", "alan_calls_end", "alan_calls_count", "alan_calls_replay",
            "alan_calls_destroy", "alan_noise_handon",
            "alan_pipeline_create", "alan_pipeline_submit", "alan_pipeline_join", "alan_pipeline_fence",
-           "alan_pipeline_destroy",
+           "alan_pipeline_destroy", "alan_adam_step",
            "alan_abi_version", "alan_build_target")
 
 
@@ -663,7 +677,6 @@ def _noise_key(desc):
 def run_reduce_backward(desc, device):
     """All gradients of an LSE call in one pass (alan_reduce_backward).  False when the problem does not fit
     the streaming kernel -- the caller then falls back to one WEXPSUM launch per factor."""
-    _spoil()
     L = lib()
     flush()
     nbytes = L.alan_reduce_backward_workspace_bytes(C.byref(desc))
@@ -673,6 +686,9 @@ def run_reduce_backward(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_reduce_backward")
+    if _REC[0] is not None:
+        _REC[0].keep.append(ws)
+        _REC[0].record(L.alan_reduce_backward, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
     return True
 
 
@@ -699,7 +715,6 @@ def run_normal_lse(desc, device, keepalive=()):
 def run_normal_lse_backward(desc, device):
     """Every gradient of the fused plate step in one pass (alan_normal_lse_backward).  False when the library
     declines the shape."""
-    _spoil()
     L = lib()
     flush()
     nbytes = L.alan_normal_lse_backward_workspace_bytes(C.byref(desc))
@@ -714,6 +729,9 @@ def run_normal_lse_backward(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse_backward")
+    if _REC[0] is not None:
+        _REC[0].keep.append(ws)
+        _REC[0].record(L.alan_normal_lse_backward, C.byref(desc), ws.data_ptr(), nbytes, None)
     return True
 
 
@@ -723,7 +741,6 @@ CHAIN_MAX_BATCH = 65535      # the batch rides on gridDim.y
 def chain_logmmexp(ms, want_chain=False):
     """ms: [T,K,K] or a batch [B,T,K,K] (device tensor) -> (vec[(B,)K], chain[(B,)K,K] or None, tree).
     ``tree`` holds every round of the reference's pairwise tree (what the backward walks)."""
-    _spoil()
     require_device(ms, "timeseries factor")
     L = lib()
     flush()
@@ -738,10 +755,13 @@ def chain_logmmexp(ms, want_chain=False):
     chain = t.empty(B, K, K, dtype=ms.dtype, device=ms.device) if want_chain else None
     nbytes = L.alan_chain_batched_workspace_bytes(B, T, K, code)
     tree = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
-    rc = L.alan_chain_logmmexp_batched(m4.data_ptr(), code, B, T, K, *m4.stride(),
-                                       chain.data_ptr() if want_chain else None, vec.data_ptr(),
-                                       tree.data_ptr(), nbytes, current_stream(ms.device))
+    args = (m4.data_ptr(), code, B, T, K, *m4.stride(), chain.data_ptr() if want_chain else None, vec.data_ptr(),
+            tree.data_ptr(), nbytes)
+    rc = L.alan_chain_logmmexp_batched(*args, current_stream(ms.device))
     check(rc, "alan_chain_logmmexp_batched")
+    if _REC[0] is not None:
+        _REC[0].keep.append((m4, chain, vec, tree))
+        _REC[0].record(L.alan_chain_logmmexp_batched, *args, None)
     if not batched:
         return vec[0], (chain[0] if want_chain else None), tree
     return vec, chain, tree
@@ -853,7 +873,6 @@ def chain_filter(ms, init):
 def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=None):
     """Gradient wrt ms [T,K,K] (or [B,T,K,K]) of logsumexp(chain_logmmexp(ms), -1) given grad_vec, and / or of
     chain_logmmexp(ms) given grad_chain -- autograd through utils.py:478-510, walked down the forward's tree."""
-    _spoil()
     require_device(ms, "timeseries factor")
     L = lib()
     batched = ms.ndim == 4
@@ -869,9 +888,11 @@ def chain_logmmexp_backward(ms, tree, out_vec=None, grad_vec=None, grad_chain=No
     nbytes = L.alan_chain_backward_batched_workspace_bytes(B, T, K, code)
     ws = t.empty(max(nbytes, 1), dtype=t.uint8, device=ms.device)
     ptr = lambda x: None if x is None else x.data_ptr()
-    rc = L.alan_chain_logmmexp_backward_batched(m4.data_ptr(), code, B, T, K, *m4.stride(), tree.data_ptr(),
-                                                ptr(out_vec) if grad_vec is not None else None, ptr(grad_vec),
-                                                ptr(grad_chain), grad.data_ptr(), ws.data_ptr(), nbytes,
-                                                current_stream(ms.device))
+    args = (m4.data_ptr(), code, B, T, K, *m4.stride(), tree.data_ptr(), ptr(out_vec) if grad_vec is not None else None,
+            ptr(grad_vec), ptr(grad_chain), grad.data_ptr(), ws.data_ptr(), nbytes)
+    rc = L.alan_chain_logmmexp_backward_batched(*args, current_stream(ms.device))
     check(rc, "alan_chain_logmmexp_backward_batched")
+    if _REC[0] is not None:
+        _REC[0].keep.append((m4, tree, out_vec, grad_vec, grad_chain, grad, ws))
+        _REC[0].record(L.alan_chain_logmmexp_backward_batched, *args, None)
     return grad if batched else grad[0]

@@ -210,15 +210,36 @@ class GraphedStep:
         # was first used on and autograd runs it there; a different capture stream would put the gradient
         # accumulation on a parallel branch of the graph (PyTorch warns "AccumulateGrad node's stream does not match").
         from . import native as N
-        with N.own_graph_noise(problem.device) as self.noise, \
-                t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
-                             capture_error_mode="thread_local"):
-            if unroll == 1:
-                self.elbo = self._iteration()
-            else:
-                self.elbo = t.stack([self._iteration() for _ in range(unroll)])
-            self.noise.finish_capture()
+        from . import engine as E
+        from . import sample as S
+        # the ELBO's launch writes its value to the tensor the backward keeps AND through a result ring (a "mirror"):
+        # no copy of the graph's output buffer after a replay; the library calls are recorded while they are captured
+        self.ring = E.ResultRing.create(problem.device) if (S.RESULT_RING and unroll == 1) else None
+        if self.ring is not None:
+            self.ring.mirror = True
+        rec = N.CallList() if S.DIRECT_REPLAY else None
+        E._RING[0], N._REC[0] = self.ring, rec
+        try:
+            with N.own_graph_noise(problem.device) as self.noise, \
+                    t.cuda.graph(self.graph, stream=side if capture_stream is None else capture_stream,
+                                 capture_error_mode="thread_local"):
+                if unroll == 1:
+                    self.elbo = self._iteration()
+                else:
+                    self.elbo = t.stack([self._iteration() for _ in range(unroll)])
+                self.noise.finish_capture()
+        finally:
+            E._RING[0], N._REC[0] = None, None
         self.n_memset_nodes = check_no_memset_nodes(self.graph, "GraphedStep", allow_memset_nodes)
+        if self.ring is not None:
+            if self.ring.taken == 1:
+                self.ring.sync_position()
+            else:
+                self.ring = None                       # (the ELBO's launch did not take it: the buffer is copied out)
+        # (sample.DIRECT_REPLAY: an iteration that is library launches alone -- the draws, the log-prob producers, the
+        # contraction, its backward, alan_amd.Adam -- is re-issued from its recorded launch list instead of replayed as a
+        # graph; torch.optim.Adam's kernels, or a model lambda's, keep it a graph replay)
+        self.calls = S.calls_if_equivalent(self.graph, rec)
 
     def _iteration(self):
         self.opt.zero_grad(set_to_none=True)
@@ -235,8 +256,12 @@ class GraphedStep:
         """Replay one iteration; returns a COPY of the ELBO (the graph's own output buffer is overwritten by the next
         replay, so ``[step() for _ in range(n)]`` holds n different values)."""
         self.noise.before_replay()
-        self.graph.replay()
-        return self.elbo.clone()
+        slot = self.ring.claim() if self.ring is not None else None
+        if self.calls is not None:
+            self.calls.replay(t.cuda.current_stream().cuda_stream)
+        else:
+            self.graph.replay()
+        return slot.detach() if slot is not None else self.elbo.clone()
 
 
 class GraphedEval:

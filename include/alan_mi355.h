@@ -188,6 +188,8 @@ typedef struct {
      * single-workgroup launch. */
     void *ring_slots, *ring_counter;
     int32_t ring_n;
+    int32_t ring_and_out;                 /* != 0: the value goes through the ring AND to `out` (a caller that keeps `out` for
+                                             a backward -- the ELBO of a training iteration -- and hands the ring's slot on) */
     alan_noise_t noise;                   /* on = 0: off */
 } alan_reduce_desc_t;
 
@@ -443,6 +445,27 @@ int alan_pipeline_submit(void *pipeline, int64_t count);
 int alan_pipeline_join(void *pipeline, void *stream);
 int alan_pipeline_fence(void *pipeline, void *stream);
 int alan_pipeline_destroy(void *pipeline);
+
+/* The optimiser step of the reference's training loop (basic_runner.py:108-110: opt.step() of a torch.optim.Adam) for up to
+ * ALAN_ADAM_MAX_TENSORS fp32 parameter tensors in ONE launch, the step count on the device: a training iteration is then
+ * library launches from the draws to the update and can be recorded and re-issued like an evaluation (alan_calls_*).
+ * Arithmetic: Adam as torch.optim.Adam(capturable=True, fused=True) evaluates it (no weight decay, no amsgrad):
+ *     m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g g;  p -= (lr / (1 - beta1^t)) m / (sqrt(v / (1 - beta2^t)) + eps)
+ * with g -> -g when `maximize`.  All tensors contiguous fp32 of numel[i] elements.
+ *   step    device float: the number of steps taken so far (0 before the first); this launch uses step + 1 and stores it
+ *   ticket  device int32, ZERO before the first call and left zero by every launch (the last workgroup to finish advances
+ *           `step`); one per optimiser, calls on it ordered by the stream */
+#define ALAN_ADAM_MAX_TENSORS 24
+typedef struct {
+    int32_t n_tensors, maximize;
+    void *param[ALAN_ADAM_MAX_TENSORS];
+    const void *grad[ALAN_ADAM_MAX_TENSORS];
+    void *exp_avg[ALAN_ADAM_MAX_TENSORS], *exp_avg_sq[ALAN_ADAM_MAX_TENSORS];
+    int64_t numel[ALAN_ADAM_MAX_TENSORS];
+    double lr, beta1, beta2, eps;
+    void *step, *ticket;
+} alan_adam_desc_t;
+int alan_adam_step(const alan_adam_desc_t *desc, void *stream);
 
 /* Library/ABI version and the gfx target it was built for (e.g. "gfx950"). */
 int alan_abi_version(void);

@@ -921,3 +921,85 @@ def test_pipelined_split_evaluation_at_K100():
     eager = float(sample.elbo_nograd(strat, graph=False))
     vals = sample.elbo_nograd_many(10, strat, lanes=3)
     assert float((vals - eager).abs().max()) <= 2e-6 * abs(eager), (vals, eager)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maximize", [False, True])
+def test_library_adam_takes_the_steps_of_torchs_fused_capturable_adam(maximize):
+    """alan_amd.Adam (alan_adam_step: one launch for all parameter tensors, step count on the device) against
+    torch.optim.Adam(capturable=True, fused=True) over 100 steps on the same gradients: 30 tensors of mixed sizes (two
+    launches per step), parameters / both moments compared after steps 1, 2, 10 and 100 -- bitwise where the arithmetic
+    is the same instruction sequence, else to 2 ulp-ish (rtol 3e-7): reported, and asserted at 1e-6."""
+    g = t.Generator().manual_seed(1)
+    shapes = [(18,), (300, 18), (1,), (7, 5), (1025,), (4096,)] * 5
+    p0 = [t.randn(*s, generator=g).to("cuda") for s in shapes]
+    mine = [p.clone().requires_grad_(True) for p in p0]
+    theirs = [p.clone().requires_grad_(True) for p in p0]
+    o1 = alan.Adam(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, maximize=maximize)
+    o2 = t.optim.Adam(theirs, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, maximize=maximize, capturable=True, fused=True)
+    worst, bitwise = 0.0, True
+    for step in range(1, 101):
+        grads = [t.randn(*s, generator=g).to("cuda") * (1.0 + 0.1 * step) for s in shapes]
+        for a, b, gr in zip(mine, theirs, grads):
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o1.step()
+        o2.step()
+        if step in (1, 2, 10, 100):
+            for a, b in zip(mine, theirs):
+                sa, sb = o1.state[a], o2.state[b]
+                for x, y in ((a, b), (sa["exp_avg"], sb["exp_avg"]), (sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                    bitwise = bitwise and bool(t.equal(x, y))
+                    worst = max(worst, float(((x - y).abs() / (y.abs() + 1e-12)).max()))
+                    t.testing.assert_close(x.detach(), y.detach(), rtol=1e-6, atol=1e-9)
+    assert float(o1.param_groups[0]["_alan"]["step"]) == 100.0 and int(o1.param_groups[0]["_alan"]["ticket"]) == 0
+    print(f"alan_amd.Adam vs torch fused capturable Adam over 100 steps: bitwise equal = {bitwise}, worst relative difference {worst:.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["vi", "rws"])
+def test_training_iteration_with_the_library_adam_replays_from_its_launch_list(method):
+    """GraphedStep over alan_amd.Adam: the captured iteration holds library launches alone, so it is re-issued from its
+    recorded launch list (step.calls) and its ELBO arrives through the result ring -- the same ELBOs and the same parameters
+    as the same iterations launched one by one, and as the graph's own replay (sample.DIRECT_REPLAY off)."""
+    from alan_amd import sample as S
+
+    def run(direct, eager=False):
+        g = t.Generator().manual_seed(5)
+        x = t.randn(60, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+        obs = (t.rand(60, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+        prob = models.movielens(sizes={"plate_1": 60, "plate_2": 5}, x=x, obs=obs)
+        prob.to("cuda")
+        params = list(prob.parameters()) if method == "vi" else list(prob.Q.parameters())
+        opt = alan.Adam(params, lr=1e-2, maximize=(method == "rws"))
+        vals = []
+        if eager:
+            t.manual_seed(11)
+            for _ in range(3 + 6):
+                opt.zero_grad(set_to_none=True)
+                sample = prob.sample(8, reparam=(method == "vi"))
+                elbo = sample.elbo_vi(alan.no_checkpoint) if method == "vi" else sample.elbo_rws(alan.no_checkpoint)
+                (-elbo).backward()
+                opt.step()
+                vals.append(float(elbo))
+            return vals[3:], [p.detach().clone() for p in params], None
+        saved = S.DIRECT_REPLAY
+        S.DIRECT_REPLAY = direct
+        try:
+            t.manual_seed(11)
+            step = alan.GraphedStep(prob, 8, opt, method=method)
+            vals = [float(step()) for _ in range(6)]
+        finally:
+            S.DIRECT_REPLAY = saved
+        return vals, [p.detach().clone() for p in params], step
+
+    v_direct, p_direct, step = run(True)
+    assert step.calls is not None and step.ring is not None, "the iteration did not record as library launches alone"
+    v_graph, p_graph, step_g = run(False)
+    assert step_g.calls is None
+    v_eager, p_eager, _ = run(False, eager=True)
+    assert len(set(v_direct)) == 6
+    for a, b, c in zip(v_direct, v_graph, v_eager):
+        assert abs(a - b) <= 2e-6 * abs(b) and abs(a - c) <= 1e-4 * abs(c), (v_direct, v_graph, v_eager)
+    for a, b, c in zip(p_direct, p_graph, p_eager):
+        t.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        t.testing.assert_close(a, c, rtol=1e-3, atol=1e-4)
