@@ -31,6 +31,9 @@ struct AdamKern {
 };
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_kernel(const AdamKern a) {
+    // (the library is built with -ffp-contract=off; torch's kernels are built with hipcc's default, which fuses a * b + c:
+    // the same contraction here, so that the moment updates round as torch's do)
+#pragma clang fp contract(fast)
     int ti = 0;
     while (ti + 1 < a.n_tensors && (int)blockIdx.x >= a.first_block[ti + 1]) ++ti;              // (workgroup-uniform)
     const int chunk = blockIdx.x - a.first_block[ti];

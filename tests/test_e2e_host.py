@@ -929,7 +929,7 @@ def test_library_adam_takes_the_steps_of_torchs_fused_capturable_adam(maximize):
     """alan_amd.Adam (alan_adam_step: one launch for all parameter tensors, step count on the device) against
     torch.optim.Adam(capturable=True, fused=True) over 100 steps on the same gradients: 30 tensors of mixed sizes (two
     launches per step), parameters / both moments compared after steps 1, 2, 10 and 100 -- bitwise where the arithmetic
-    is the same instruction sequence, else to 2 ulp-ish (rtol 3e-7): reported, and asserted at 1e-6."""
+    is the same instruction sequence, else to a few ulp: reported (pytest -s), asserted at rtol 2e-6 / atol 2e-7."""
     g = t.Generator().manual_seed(1)
     shapes = [(18,), (300, 18), (1,), (7, 5), (1025,), (4096,)] * 5
     p0 = [t.randn(*s, generator=g).to("cuda") for s in shapes]
@@ -950,7 +950,8 @@ def test_library_adam_takes_the_steps_of_torchs_fused_capturable_adam(maximize):
                 for x, y in ((a, b), (sa["exp_avg"], sb["exp_avg"]), (sa["exp_avg_sq"], sb["exp_avg_sq"])):
                     bitwise = bitwise and bool(t.equal(x, y))
                     worst = max(worst, float(((x - y).abs() / (y.abs() + 1e-12)).max()))
-                    t.testing.assert_close(x.detach(), y.detach(), rtol=1e-6, atol=1e-9)
+                    t.testing.assert_close(x.detach(), y.detach(), rtol=2e-6, atol=2e-7)
+    assert bitwise, f"not bitwise torch's fused capturable Adam any more (worst relative difference {worst:.2e})"
     assert float(o1.param_groups[0]["_alan"]["step"]) == 100.0 and int(o1.param_groups[0]["_alan"]["ticket"]) == 0
     print(f"alan_amd.Adam vs torch fused capturable Adam over 100 steps: bitwise equal = {bitwise}, worst relative difference {worst:.2e}")
 

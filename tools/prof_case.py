@@ -12,9 +12,12 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 if which in ("vi", "rws"):
     prob = bench.build_problem("cuda")
-    # as bench.py's training_iteration leg: fused=True = one multi-tensor kernel per Adam step
-    opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, fused=True, maximize=True) if which == "rws"
-           else t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True, fused=True))
+    # as bench.py's training_iteration leg: the library's own Adam (ALAN_PROF_TORCH_ADAM=1: torch's fused capturable one)
+    if os.environ.get("ALAN_PROF_TORCH_ADAM") == "1":
+        opt = (t.optim.Adam(prob.Q.parameters(), lr=1e-2, capturable=True, fused=True, maximize=True) if which == "rws"
+               else t.optim.Adam(prob.parameters(), lr=1e-2, capturable=True, fused=True))
+    else:
+        opt = alan.Adam(prob.Q.parameters(), lr=1e-2, maximize=True) if which == "rws" else alan.Adam(prob.parameters(), lr=1e-2)
     step = GraphedStep(prob, K, opt, method=which, computation_strategy=bench.strategy_for(1, K))
     for _ in range(n):
         v = step()
