@@ -8,8 +8,9 @@ contraction itself is hand-written HIP for gfx950 in libalan_mi355.so (include/a
 There is no CPU fallback: evaluating an ELBO needs the library and a GPU.
 
 Where a drop-in user sees something other than the reference (each with a switch that restores the reference's way):
-  * ``importance_sample`` on a Timeseries draws exact JOINT trajectories by default; the reference draws every timestep
-    independently from a filtering marginal (reduce_Ks.py:85-232).  ``posterior.TIMESERIES_POSTERIOR = "reference"``.
+  * (not a deviation any more: since round 4 ``importance_sample`` on a Timeseries draws what the reference draws -- every
+    timestep independently from a filtering marginal, reduce_Ks.py:85-232.  ``posterior.TIMESERIES_POSTERIOR = "smoothing"``
+    is the opt-in improvement: exact JOINT trajectories, whose moments agree with ``marginals()``.)
   * fp64 observations enter the fused fp32 plate step converted (result returned as fp64, within 1e-6 of the reference's
     fp64 log-sum-exp on the BASELINE configurations).  ``engine.FP64_SMALL_FACTORS = "exact"``.
   * ``Split(plate, size)`` evaluates a rank's chunks as one slice while every tensor that needs stays under

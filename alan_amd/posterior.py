@@ -99,17 +99,19 @@ def sample_Ks(lps, Ks, N_dim, N):
     return indices
 
 
-TIMESERIES_POSTERIOR = "smoothing"
+TIMESERIES_POSTERIOR = "reference"
 """How ``importance_sample`` draws a timeseries variable's K indices.
 
-"smoothing" (default): an exact joint draw of the whole trajectory from p(k_0..k_{T-1} | everything), by backward
-messages + forward sampling (two launches, O(T K^2)).
+"reference" (default since round 4: a drop-in draws from the reference's distribution): what reduce_Ks.py:85-232
+evaluates -- every timestep drawn INDEPENDENTLY from the filtering marginal p(k_t | factors up to t), mixed over the N
+sampled initial states.  (Its backward term is added on the K_init torchdim while the filtered term lives on the K
+torchdim; after indexing K_init with the sampled initial states and summing over N it is a constant over k, so the
+normalised "smoothed" table equals the filtered one -- tests/golden/posterior.pt records exactly that.)  One forward
+recursion (alan_chain_filter) instead of the reference's O(T^2) chain evaluations; the trajectories are not joint draws.
 
-"reference": what reduce_Ks.py:85-232 evaluates -- every timestep drawn INDEPENDENTLY from the filtering marginal
-p(k_t | factors up to t), mixed over the N sampled initial states.  (Its backward term is added on the K_init torchdim
-while the filtered term lives on the K torchdim; after indexing K_init with the sampled initial states and summing over
-N it is a constant over k, so the normalised "smoothed" table equals the filtered one -- tests/golden/posterior.pt
-records exactly that.)  Kept for parity checks; the trajectories it returns are not joint draws."""
+"smoothing" (opt-in improvement): an exact joint draw of the whole trajectory from p(k_0..k_{T-1} | everything), by
+backward messages + forward sampling (two launches, O(T K^2)); its moments agree with ``marginals()`` and the Kalman
+smoother, which the reference's draws do not."""
 
 
 def _timeseries_factor(lps, Ks, K_cur, K_init, T_dim, indices):
@@ -154,8 +156,14 @@ def sample_Ks_timeseries(lps, Ks, K_currs, K_inits, T_dim, indices, N_dim, N):
     init = init.expand(N, *[d.size for d in plates]).reshape(N, B)
     flat = ms.reshape(-1, T, K, K)
     if ms.dtype != t.float32 or K > N_.POSTERIOR_MAX_K or not ms.is_cuda:
-        # (not on the GPU: only under the test-only CPU backend, whose seam is alan_reduce)
-        draws = _sample_chain_by_steps(flat, init, N, B, has_N)
+        # (fp64 factors, more than 128 particles, or not on the GPU -- the latter only under the test-only CPU backend,
+        # whose seam is alan_reduce: the same two distributions, one alan_reduce per timestep)
+        if TIMESERIES_POSTERIOR == "reference":
+            logp = _filtering_by_steps(flat, init, N, B, has_N)                        # [B, T, K]
+            d = t.multinomial(logp.exp().reshape(B * T, K).float(), N, replacement=True)
+            draws = d.reshape(B, T, N).permute(2, 0, 1).contiguous()
+        else:
+            draws = _sample_chain_by_steps(flat, init, N, B, has_N)
     elif TIMESERIES_POSTERIOR == "reference" and has_N:
         # chains that depend on the sample (a drawn K of another group plugged in): the same table, the forward recursion
         # of sample n run on chain n from its own initial state, mixed over n
@@ -181,6 +189,26 @@ def sample_Ks_timeseries(lps, Ks, K_currs, K_inits, T_dim, indices, N_dim, N):
         draws = N_.chain_sample(flat, beta, init, N, B, B if has_N else 0, 1)
     draws = draws.reshape(N, *[d.size for d in plates], T)
     return {id(K_cur): (K_cur, PT(draws, (N_dim, *plates, T_dim)))}
+
+
+def _filtering_by_steps(flat, init, N, B, has_N):
+    """The "reference" table (per-timestep filtering marginals mixed over the sampled initial states, normalised) with one
+    alan_reduce per timestep: flat [C, T, K, K] (C = N B chains when the factor depends on the sample, else B), init
+    [N, B] -> log-probabilities [B, T, K]."""
+    C_, T, K, _ = flat.shape
+    n_idx = t.arange(N, device=flat.device).unsqueeze(1).expand(N, B)
+    b_idx = t.arange(B, device=flat.device).unsqueeze(0).expand(N, B)
+    chain = (n_idx * B + b_idx) if has_N else b_idx                                       # [N, B]
+    alpha = flat[chain, 0, init]                                                         # [N, B, K]: from each initial state
+    tabs = []
+    for step in range(T):
+        if step:
+            trans = flat[chain, step]                                                    # [N, B, K, K]
+            alpha, _ = E.reduce_factors([(alpha.contiguous(), ("n", "b", "a")), (trans.contiguous(), ("n", "b", "a", "k"))],
+                                        reduce=("a",))
+        mix = t.logsumexp(alpha, 0)                                                      # [B, K]
+        tabs.append(mix - t.logsumexp(mix, -1, keepdim=True))
+    return t.stack(tabs, 1)
 
 
 def _sample_chain_by_steps(flat, init, N, B, has_N):

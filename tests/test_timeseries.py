@@ -103,6 +103,14 @@ def test_final_contraction_inside_the_chains_last_launch_is_the_same_elbo(T, K, 
         assert abs(got - separate) <= 2e-6 * abs(separate) + 1e-5, (got, separate)
 
 
+@pytest.fixture
+def smoothing(monkeypatch):
+    """posterior.TIMESERIES_POSTERIOR = "smoothing": exact joint trajectories -- what agrees with marginals() and the
+    Kalman smoother (the default, "reference", draws the reference's per-timestep filtering marginals, which do not)."""
+    from alan_amd import posterior as PS
+    monkeypatch.setattr(PS, "TIMESERIES_POSTERIOR", "smoothing")
+
+
 def _ts_posterior_check(device, K, N):
     """Timeseries posterior: marginals (chain backward) and importance samples (sample_Ks_timeseries) vs
     each other and vs the closed-form Kalman smoother mean (tests/timeseries.py:52-56 of the reference)."""
@@ -137,12 +145,12 @@ def _ts_posterior_check(device, K, N):
     assert set(d.names) == {"N", "T"}
 
 
-def test_timeseries_posterior_host_logic(oracle_backend):
+def test_timeseries_posterior_host_logic(oracle_backend, smoothing):
     _ts_posterior_check("cpu", 60, 4000)
 
 
 @pytest.mark.gpu
-def test_timeseries_posterior_gpu():
+def test_timeseries_posterior_gpu(smoothing):
     _ts_posterior_check("cuda", 300, 20000)
 
 
@@ -340,25 +348,25 @@ def _posterior_samples_match_marginals(prob, device, K, N, varnames):
     return isamp
 
 
-def test_posterior_of_a_nested_timeseries_host_logic(oracle_backend):
+def test_posterior_of_a_nested_timeseries_host_logic(oracle_backend, smoothing):
     prob, _ = nested_problem(4)
     isamp = _posterior_samples_match_marginals(prob, "cpu", 40, 3000, ["ts", "init", "drift"])
     assert set(isamp.dump()["ts"].names) == {"N", "R", "T"}
 
 
-def test_posterior_of_a_timeseries_plate_with_another_group_host_logic(oracle_backend):
+def test_posterior_of_a_timeseries_plate_with_another_group_host_logic(oracle_backend, smoothing):
     _posterior_samples_match_marginals(with_group_problem(5), "cpu", 40, 3000, ["ts", "z", "init"])
 
 
 @pytest.mark.gpu
-def test_posterior_of_a_nested_timeseries_gpu():
+def test_posterior_of_a_nested_timeseries_gpu(smoothing):
     prob, _ = nested_problem(6)
     isamp = _posterior_samples_match_marginals(prob, "cuda", 100, 20000, ["ts", "init", "drift"])
     assert set(isamp.dump()["ts"].names) == {"N", "R", "T"}
 
 
 @pytest.mark.gpu
-def test_posterior_of_a_timeseries_plate_with_another_group_gpu():
+def test_posterior_of_a_timeseries_plate_with_another_group_gpu(smoothing):
     _posterior_samples_match_marginals(with_group_problem(8), "cuda", 100, 20000, ["ts", "z", "init"])
 
 
@@ -462,3 +470,27 @@ def test_transition_factor_computed_on_load_by_the_chain_equals_the_materialised
     with backend.installed():
         cpu = float(cs.elbo_nograd(alan.no_checkpoint))
     assert abs(lazy - cpu) <= 1e-4 * abs(cpu) + 1e-3, (lazy, cpu)
+
+
+def test_reference_mode_posterior_is_the_default_and_draws_the_filtering_marginals(oracle_backend):
+    """posterior.TIMESERIES_POSTERIOR defaults to "reference" (VERDICT r3 item 7): importance_sample draws every timestep
+    from the filtering marginal mixed over the sampled initial states -- on the host-logic route (one alan_reduce per
+    timestep) the per-timestep frequencies match the table computed directly from the factor."""
+    from alan_amd import posterior as PS
+    assert PS.TIMESERIES_POSTERIOR == "reference"
+    g = t.Generator().manual_seed(2)
+    C_, T, K, N = 2, 5, 6, 40000
+    flat = t.randn(C_, T, K, K, generator=g)
+    init = t.randint(0, K, (N, C_), generator=g)
+    logp = PS._filtering_by_steps(flat, init, N, C_, False)
+    # brute force: alpha_t[n] by explicit recursion in fp64, mixed and normalised
+    want = t.empty(C_, T, K, dtype=t.float64)
+    for b in range(C_):
+        alpha = flat[b, 0].double()[init[:, b]]                              # [N, K]
+        for step in range(T):
+            if step:
+                alpha = t.logsumexp(alpha[:, :, None] + flat[b, step].double()[None], 1)
+            mix = t.logsumexp(alpha, 0)
+            want[b, step] = mix - t.logsumexp(mix, 0)
+    t.testing.assert_close(logp.double(), want, rtol=1e-5, atol=1e-5)
+    assert abs(float(logp.exp().sum(-1).mean()) - 1.0) < 1e-5
