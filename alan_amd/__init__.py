@@ -7,19 +7,27 @@ Host code (model definition, sampling, per-factor log-probs) is Python on PyTorc
 contraction itself is hand-written HIP for gfx950 in libalan_mi355.so (include/alan_mi355.h).
 There is no CPU fallback: evaluating an ELBO needs the library and a GPU.
 
-Where a drop-in user sees something other than the reference (each with a switch that restores the reference's way):
-  * (not a deviation any more: since round 4 ``importance_sample`` on a Timeseries draws what the reference draws -- every
-    timestep independently from a filtering marginal, reduce_Ks.py:85-232.  ``posterior.TIMESERIES_POSTERIOR = "smoothing"``
-    is the opt-in improvement: exact JOINT trajectories, whose moments agree with ``marginals()``.)
-  * fp64 observations enter the fused fp32 plate step converted (result returned as fp64, within 1e-6 of the reference's
-    fp64 log-sum-exp on the BASELINE configurations).  ``engine.FP64_SMALL_FACTORS = "exact"``.
-  * ``Split(plate, size)`` evaluates a rank's chunks as one slice while every tensor that needs stays under
-    ``split.MERGE_MAX_BYTES``; ``Split(..., merge=False)`` is the reference's per-chunk loop.
-  * ``Problem.sample`` draws the noise of all its Normal variables together, generated inside the launch that uses it
-    (Philox4x32-10 keyed by torch's generator: same distribution, reproducible under ``torch.manual_seed``, other
-    particles than torch's variable-by-variable ``rsample`` under the same seed).  ``dist.DEVICE_NOISE = False``: the
-    noise is torch's ``normal_`` (one call per batch); ``dist.BATCH_NOISE = False`` keeps torch's particles;
-    ``dist.BATCH_DRAWS = False`` issues every draw where the model meets it.
+Where a drop-in user sees something other than the reference -- every one a module switch, listed as
+`module.SWITCH = default | value that restores the reference's way` (tests/test_native_abi.py checks this table against
+the modules):
+
+  ``engine.FP64_SMALL_FACTORS`` = "fused" | "exact"
+      fp64 observations enter the fused fp32 plate step converted (result returned as fp64, within 1e-6 of the reference's
+      fp64 log-sum-exp on the BASELINE configurations); "exact": such a problem takes the materialised route, added and
+      reduced in fp64 as the reference's promotion does, at roughly twice the time.
+  ``split.MERGE_CHUNKS`` = True | False
+      ``Split(plate, size)`` evaluates a rank's chunks as one slice while every tensor that needs stays under
+      ``split.MERGE_MAX_BYTES``; ``Split(..., merge=False)`` (or the switch) is the reference's per-chunk loop.
+  ``dist.DEVICE_NOISE`` = True | False
+      ``Problem.sample`` draws the noise of all its Normal variables together, generated inside the launch that uses it
+      (Philox4x32-10 keyed by torch's generator: same distribution, reproducible under ``torch.manual_seed``, other
+      particles than torch's variable-by-variable ``rsample`` under the same seed).  False: the noise is torch's ``normal_``
+      (one call per batch); ``dist.BATCH_NOISE = False`` keeps torch's particles; ``dist.BATCH_DRAWS = False`` issues every
+      draw where the model meets it.
+  ``posterior.TIMESERIES_POSTERIOR`` = "reference" | "reference"
+      (no deviation since round 4: ``importance_sample`` on a Timeseries draws every timestep independently from a
+      filtering marginal, as reduce_Ks.py:85-232 does; "smoothing" is the opt-in improvement: exact JOINT trajectories,
+      whose moments agree with ``marginals()``.)
 """
 from .model import Plate, Group, Data
 from .timeseries import Timeseries

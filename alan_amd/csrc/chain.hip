@@ -653,8 +653,7 @@ int launch_pair_mfma<float>(int64_t K, uint32_t n_out, uint32_t B, hipStream_t s
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
     const bool add = ad.n > 0 || ad.norm != 0;
-    static const int stripe_knob = env_knob("ALAN_CHAIN_STRIPE");                     // tuning knob: products per launch below which a product is split
-    const uint32_t stripe_below = stripe_knob != ENV_UNSET ? (uint32_t)std::max(0, stripe_knob) : 96u;
+    const uint32_t stripe_below = 96u;                // products per launch below which a product is split (tuned: DESIGN.md)
     if (!add && (uint64_t)n_out * B < stripe_below) {
         // a launch of few products lasts as long as one of them: one workgroup per tile row of each
         const size_t ssm = (size_t)((32 + 32 * kt) * (32 * kt + 4) + 32 + 32 * kt) * sizeof(float);
@@ -954,7 +953,6 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
     if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
     const T *src = (const T *)ms_;
     int64_t cB = sB, cT = sT, cR = sRow, cC = sCol;
-    static const bool per_round = env_knob("ALAN_CHAIN_PER_ROUND") != ENV_UNSET;  // ablation: one round per launch
     static const bool no_wave = env_knob("ALAN_CHAIN_WAVE") == 0;                     // ablation: chain_tree_kernel instead
     bool fits32 = true;                                   // the wave kernel's 32-bit offsets inside one matrix
     {
@@ -968,7 +966,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
                      ad0.nvs[2] == 0 && ad0.nls[3] == 0 && (!ad0.nl0 || (span(ad0.nl0s[2], 0) && ad0.nl0s[3] == 0));
     }
     // (below K ~ 12 the vector-unit tree kernel is as fast or faster: a 32 x 32 MFMA tile is mostly padding there)
-    if (K > 12 && K <= 32 && !per_round && !no_wave && fits32 && std::is_same<T, float>::value) {
+    if (K > 12 && K <= 32 && !no_wave && fits32 && std::is_same<T, float>::value) {
         const size_t wsmem = (size_t)(25 * WAVE_TILE + 16 * 32) * sizeof(float);     // the largest launch (5 rounds)
         for (auto fn : {(const void *)chain_wave_kernel<0>, (const void *)chain_wave_kernel<1>, (const void *)chain_wave_kernel<2>,
                         (const void *)chain_wave_kernel<0, true, 256>, (const void *)chain_wave_kernel<1, true, 256>,
@@ -980,16 +978,9 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         std::memset(&nonef, 0, sizeof(nonef));
         // rounds per launch: 2^(rounds - 1) waves per workgroup, so few rounds while there are many nodes (the first
         // round of a launch runs 2^(rounds - 3) products per SIMD) and all the rest in the last launch
-        static const int sched_knob = env_knob("ALAN_CHAIN_SCHED");                      // tuning knob: e.g. 334 = 3, 3, 4
-        int digits[12], nd = 0;
-        if (sched_knob != ENV_UNSET && sched_knob > 0)
-            for (int v = sched_knob; v > 0 && nd < 12; v /= 10) digits[nd++] = v % 10;
-        for (int r = 0, li = 0; r < tl.L; ++li) {
+        for (int r = 0; r < tl.L;) {
             int rounds = std::min(WAVE_ROUNDS, tl.L - r);
-            if (nd) {
-                const int want = li < nd ? digits[nd - 1 - li] : WAVE_ROUNDS;
-                rounds = std::min(std::max(1, std::min(want, WAVE_ROUNDS)), tl.L - r);
-            } else if (tl.n[r] * B > 64 || (r == 0 && normal)) {
+            if (tl.n[r] * B > 64 || (r == 0 && normal)) {
                 rounds = std::min(3, tl.L - r);           // (the Normal term's instantiation is built for <= 256 threads)
             }
             if (r == 0 && normal) rounds = std::min(rounds, 3);
@@ -1028,7 +1019,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
         }
     } else if (final_) {
         return ALAN_ERR_UNSUPPORTED;                      // (only the one-wave-per-product kernel carries the parent's contraction)
-    } else if (K <= 32 && !per_round) {
+    } else if (K <= 32) {
         const size_t slot = (KP * (KP + 4) + KP * KP + 2 * KP) * sizeof(T);
         auto tk = chain_tree_kernel<T>;
         if (hipFuncSetAttribute((const void *)tk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8 * slot)) != hipSuccess)
@@ -1052,7 +1043,7 @@ static int chain_run(const void *ms_, int64_t B, int64_t Tn, int64_t K, int64_t 
             cC = 1;
         }
     } else {
-        static const bool no_mfma = env_knob("ALAN_CHAIN_MFMA") == 0;                 // ablation: vector-unit products
+        constexpr bool no_mfma = false;
         for (int r = 1; r <= tl.L; ++r) {
             T *dst = (T *)((char *)ws + tl.off[r]);
             int rc = no_mfma ? (int)ALAN_ERR_UNSUPPORTED

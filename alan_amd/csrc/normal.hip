@@ -413,12 +413,10 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
     const int nst = d.NS <= 32 ? 1 : d.NS <= 64 ? 2 : 4;
     {   // transposed stores (see the kernel): the [NS, kz] block of one (outer value index, loc row) is one 16-byte
         // aligned contiguous run of the output
-        static const int ts_knob = env_knob("ALAN_NORMAL_TS");                               // ablation knob
         const int in = d.nv - 1;
         // (worth it when the rows straddle cache lines and most lanes have one: measured 14.1 -> 12.8 us at kz = 30,
         // but 13.3 -> 14.2 at kz = 32, whose 128-byte rows are already whole lines, and 4.5 -> 5.7 at kz = 10)
-        bool ts = ts_knob != 0 && nst == 1 && d.nv >= 1 && d.v_os[in] == 1 &&
-                  ((d.vdiv[in].d >= 24 && d.vdiv[in].d < 32) || (ts_knob == 2 && d.vdiv[in].d <= 32)) &&
+        bool ts = nst == 1 && d.nv >= 1 && d.v_os[in] == 1 && d.vdiv[in].d >= 24 && d.vdiv[in].d < 32 &&
                   d.s_os == (int64_t)d.vdiv[in].d && (d.NS * d.vdiv[in].d) % 4 == 0 && d.l_os % 4 == 0 &&
                   reinterpret_cast<uintptr_t>(d.out) % 16 == 0;
         for (int k = 0; ts && k < in; ++k) ts = d.v_os[k] % 4 == 0;
@@ -430,8 +428,6 @@ static bool try_normal_mfma(NormalDesc d, int64_t NV, hipStream_t stream, const 
     // 512 slots ran two rounds: 25 us of MFMA phase for 11 us of MFMAs.)
     const uint32_t slots = 256u * (nst == 4 ? 2u : nst == 2 ? 3u : 4u);
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, slots / std::max(1u, gx)));
-    static const int gy_knob = env_knob("ALAN_NORMAL_GY");                                   // tuning knob
-    if (gy_knob != ENV_UNSET) gy = std::min<uint32_t>(d.NL, std::max(1, gy_knob));
     d.l_chunk = (d.NL + gy - 1) / gy;
     gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
     const dim3 grid(gx, gy);
@@ -519,22 +515,16 @@ int try_launch_normal_outer(const Canon &c, bool log_scale, float out_scale, dou
             contig = contig && d.v_vs[k] == run;
             run *= d.vdiv[k].d;
         }
-        static const int stage_knob = env_knob("ALAN_NORMAL_STAGE");                        // tuning knob
-        if (stage_knob != ENV_UNSET) contig = contig && stage_knob != 0;
         d.rows_contig = contig ? 1 : 0;
     }
 
     // two value rows per thread once that still leaves >= 512 workgroups
     int R = (NV * (int64_t)d.NL >= 512ll * 512) ? 2 : 1;
-    static const int r_knob = env_knob("ALAN_NORMAL_R");                      // tuning knob
-    if (r_knob != ENV_UNSET) R = r_knob == 2 ? 2 : 1;
     const uint32_t gx = (uint32_t)((NV + 256 * R - 1) / (256 * R));
     // enough workgroups to fill the chip: split the loc rows over grid.y, one loc row per workgroup when the
     // grid allows (K=30: 25 us with gy = NL, 310 us with gy = 1).  Measured budget at K=30, R=2 (HIP events,
     // 4.7 us of which is the event floor): tables + value staging 3.6 us, FMAs/LDS 4-6 us, stores of F 6 us.
     uint32_t gy = std::min<uint32_t>(d.NL, std::max<uint32_t>(1, 16384 / std::max(1u, gx)));
-    static const int gy_knob = env_knob("ALAN_NORMAL_GY");                                   // tuning knob
-    if (gy_knob != ENV_UNSET) gy = std::min<uint32_t>(d.NL, std::max(1, gy_knob));
     d.l_chunk = (d.NL + gy - 1) / gy;
     gy = (d.NL + d.l_chunk - 1) / d.l_chunk;
     size_t lds_f = 2 * (size_t)d.NS * d.Ep + ((d.NS + 3) & ~3u) + (size_t)d.l_chunk * d.Ep;

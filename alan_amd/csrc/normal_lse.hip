@@ -440,11 +440,6 @@ using namespace alan;
 
 namespace {
 
-bool env_stage_ok() {
-    static const int knob = env_knob("ALAN_NLSE_STAGE");          // ablation knob: 0 = per-lane row loads
-    return knob == ENV_UNSET || knob != 0;
-}
-
 struct NLPlan {
     int eh = 0, nst = 1, nlw = 1, m_chunk = 1, n_chunks = 1;
     bool rag = false, x3 = false;
@@ -465,18 +460,13 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     p.eh = need <= 4 ? 4 : need <= 8 ? 8 : need <= 10 ? 10 : need <= 12 ? 12 : 17;
     const int64_t nst_total = (a.NS + 31) / 32;
     p.nst = nst_total >= 4 ? 4 : nst_total >= 2 ? 2 : 1;
-    static const int nst_knob = env_knob("ALAN_NLSE_NST");                            // tuning knob: scale tiles per wave
-    if (nst_knob == 1 || nst_knob == 2 || nst_knob == 4) p.nst = std::min<int>(p.nst, nst_knob);
     const int64_t nsg = (nst_total + p.nst - 1) / p.nst;
-    static const int nlw_knob = env_knob("ALAN_NLSE_NLW");                            // tuning knob
     p.nlw = (p.nst == 1 && a.NL >= 8) ? 2 : 1;
-    if (nlw_knob != ENV_UNSET) p.nlw = (p.nst == 1 && nlw_knob == 2) ? 2 : 1;
     // the last scale tile as a 16-wide one: a single group of tiles whose last holds at most 16 rows (NS = 100: 4)
-    static const int rag_knob = env_knob("ALAN_NLSE_RAG");                            // ablation knob: 0 = off
-    p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16 && rag_knob != 0;
+    p.rag = p.nst > 1 && nsg == 1 && nst_total == p.nst && a.NS - 32 * (nst_total - 1) <= 16;
     // the bf16x3 kernel (default): contiguous value rows (its staged loads), the chunks added by a second launch
     static const int f32_knob = env_knob("ALAN_NLSE_F32");                            // ablation knob: 1 = the f32 MFMA kernel
-    p.x3 = a.v_se == 1 && a.v_sk == a.E && f32_knob != 1 && env_stage_ok() &&
+    p.x3 = a.v_se == 1 && a.v_sk == a.E && f32_knob != 1 &&
            a.l_sl >= 0 && a.l_se >= 0 && a.s_ss >= 0 && a.s_se >= 0 &&                   // (its 32-bit lane offsets)
            a.NL * a.l_sl + a.E * a.l_se < (1ll << 31) && a.NS * a.s_ss + a.E * a.s_se < (1ll << 31) &&
            a.v_sm >= 0 && a.v_sm < (1ll << 31) && a.NL <= 65535;
@@ -541,8 +531,7 @@ int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o) {
     const int rc = plan_nl(a, p);
     if (rc != ALAN_OK) return rc;
     if (!p.x3) return ALAN_ERR_UNSUPPORTED;
-    static const int flat_knob = env_knob("ALAN_NLSE_FLAT");                          // ablation knob: 0 = off
-    bool flat = p.nlw == 1 && a.NK > 32 && (a.NK & 31) != 0 && (a.NK & 3) == 0 && a.v_sm == a.NK * a.E && flat_knob != 0;
+    bool flat = p.nlw == 1 && a.NK > 32 && (a.NK & 31) != 0 && (a.NK & 3) == 0 && a.v_sm == a.NK * a.E;
     for (int f = 0; f < a.n_small; ++f)
         flat = flat && (int64_t)p.m_chunk * a.small_sm[f] + a.NK * a.small_sk[f] < (1ll << 31);
     X3Desc &x = o.x;
@@ -619,7 +608,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         d.small_sk[f] = used ? a->small_sk[f] : 0;
     }
     // the staged variant needs the tile's 32 rows to be one contiguous run of the value tensor
-    const bool stage = a->v_se == 1 && a->v_sk == a->E && env_stage_ok();
+    const bool stage = a->v_se == 1 && a->v_sk == a->E;
     const bool rag = p.rag && stage;
     const size_t lds = 4 * 32 * 33 * sizeof(float);               // the waves' value tiles
     auto launch = [&](auto kern) {
@@ -627,9 +616,8 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
         return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
     };
     // flat row tiling (see the kernels): the plate elements' k rows as one run
-    static const int flat_knob = env_knob("ALAN_NLSE_FLAT");                          // ablation knob: 0 = off
-    bool flat = stage && p.nlw == 1 && a->NK > 32 && (a->NK & 31) != 0 && (a->NK & 3) == 0 && a->v_sm == a->NK * a->E &&
-                flat_knob != 0;                   // (NK % 4: a lane's groups of four accumulator rows never straddle two elements)
+    bool flat = stage && p.nlw == 1 && a->NK > 32 && (a->NK & 31) != 0 && (a->NK & 3) == 0 && a->v_sm == a->NK * a->E;
+                                                  // (NK % 4: a lane's groups of four accumulator rows never straddle two elements)
     for (int f = 0; f < a->n_small; ++f)          // (32-bit lane offsets into a small factor, inside one chunk of the plate)
         flat = flat && a->small_sm[f] >= 0 && a->small_sk[f] >= 0 &&
                (int64_t)p.m_chunk * a->small_sm[f] + a->NK * a->small_sk[f] < (1ll << 31);

@@ -448,10 +448,9 @@ int plan_nlb(const alan_normal_lse_backward_desc_t &b, NLBPlan &p) {
     p.lds = (size_t)L.total * sizeof(float);
     if (p.lds > 150 * 1024) return ALAN_ERR_UNSUPPORTED;
     // flat row tiling (see the kernel): the plate elements' k rows as one run
-    static const int flat_knob = env_knob("ALAN_NLB_FLAT");                   // ablation knob: 0 = off
     // (not for SMALL_ONLY: with no V and no U a tile is short, and the second log-sum-exp value per lane and the
     // selects cost more than the saved tiles -- K = 100: 334 against 315 us)
-    p.flat = a.NK > 32 && (a.NK & 31) != 0 && (a.NK & 3) == 0 && a.v_sm == a.NK * a.v_sk && flat_knob != 0 &&
+    p.flat = a.NK > 32 && (a.NK & 31) != 0 && (a.NK & 3) == 0 && a.v_sm == a.NK * a.v_sk &&
              (b.grad_value || b.grad_loc || b.grad_scale);
     // workgroups: one per (plate element, k tile), times gy shares of the loc rows so that the chip is covered
     const int64_t base = p.flat ? (a.M * a.NK + 31) / 32 : a.M * p.nkt;
@@ -460,8 +459,6 @@ int plan_nlb(const alan_normal_lse_backward_desc_t &b, NLBPlan &p) {
     // (one share unless the plate is short: every share adds a row of partials to the column sums and the loc-share
     // add launch -- at K=30, M=300 one share is 39 + 4 us, three are 37 + 10 + 4)
     int64_t gy = std::max<int64_t>(1, (256 + base - 1) / base);
-    static const int gy_knob = env_knob("ALAN_NLB_GY");                       // tuning knob
-    if (gy_knob != ENV_UNSET) gy = std::max(1, gy_knob);
     gy = std::min<int64_t>(gy, (a.NL + 3) / 4);
     p.gy = (int)std::min<int64_t>(gy, 65535);
     p.rows_loc = base * p.nst;

@@ -348,9 +348,8 @@ bool pair_prepare(const alan_reduce_desc_t &d, uint32_t keep, uint32_t red, uint
     // few tiles and several plate elements: a workgroup per (tile, plate element) -- bus_breakdown at K = 100 is 98 tiles of
     // 3 plate elements each, a third of the chip's CUs with one wave per SIMD -- and a second launch that adds the plate
     // elements in order
-    static const int split_knob = env_knob("ALAN_PAIR_SPLIT");                         // ablation knob: 0 = off
     pd.bern = bern ? 1 : 0;
-    if (split_knob != 0 && n_plate >= 2 && n_plate <= 65535 && (int64_t)grid.x * grid.y < 512 &&
+    if (n_plate >= 2 && n_plate <= 65535 && (int64_t)grid.x * grid.y < 512 &&
         n_batch * pd.NI * pd.NJ < (1ll << 31)) {
         pd.split = 1;
         grid.z = (uint32_t)n_plate;

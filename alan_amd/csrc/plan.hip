@@ -172,8 +172,6 @@ int plan_group(const Canon &c, int out_dtype, double add_const, GroupDesc &gd, G
         // small launches are latency chains: widen the group until a lane sees one element
         while (logG < 6 && (c.n_out << logG) < want_threads && (1ll << logG) < c.n_red) ++logG;
     }
-    static const int glogg_knob = env_knob("ALAN_GROUP_LOGG");                        // tuning knob
-    if (glogg_knob != ENV_UNSET && glogg_knob >= 0 && glogg_knob <= 6 && c.n_red > 1) logG = glogg_knob;
     gl.block = (logG == 6) && (c.n_out * 64 < want_threads) && (c.n_red >= 512);
     gl.logG = logG;
     if (gl.block) {
@@ -502,8 +500,6 @@ static int lin_prepare(const alan_reduce_desc_t &d, LinDesc &ld, GroupLaunch &gl
     // lanes, 13.6 at 8)
     int logG = 0;
     while (logG < 6 && (n_out << logG) < 160000 && (1ll << logG) < n_red) ++logG;
-    static const int logg_knob = env_knob("ALAN_LIN_LOGG");                           // tuning knob (unset: the rule above)
-    if (logg_knob != ENV_UNSET && logg_knob >= 0 && logg_knob <= 6) logG = logg_knob;
     gl.block = logG == 6 && n_red >= 512 && n_out * 64 < 256ll * 256 * 4;
     gl.logG = logG;
     if (gl.block) {
@@ -965,8 +961,6 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     if (!plate) return run_single(*d, keep, red, d->mode, d->out, d->add_const, stream, ev);
 
     // ---- log-sum-exp over REDUCE, then sum over PLATE (logpq.py:128,149)
-    static const int sp_knob = env_knob("ALAN_SMALL_PLATE");                          // ablation knob: 0 = two launches
-    static const int sp_first = env_knob("ALAN_SMALL_PLATE_FIRST");                   // tuning knob: elements below which
     {
         // a factor of a few hundred KB is not a stream: the rows kernel's windows and two-stage plate sum cost it 15 us
         // (bus_breakdown's Year plate at K = 100, 20,000 elements) where the lane-group kernel takes 5
@@ -974,7 +968,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         for (int i = 0; i < d->ndim; ++i) elems *= d->size[i];
         SmallPlateDesc sp;
         GroupLaunch gl;
-        if (sp_knob != 0 && !d->lse_out.data && elems <= (sp_first != ENV_UNSET ? (int64_t)sp_first : (1ll << 17)) &&
+        if (!d->lse_out.data && elems <= (1ll << 17) &&
             small_plate_prepare(*d, sp, gl))
             return launch_small_plate(sp, gl, stream, ev);
     }
@@ -987,7 +981,7 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     {
         SmallPlateDesc sp;
         GroupLaunch gl;
-        if (sp_knob != 0 && small_plate_prepare(*d, sp, gl)) return launch_small_plate(sp, gl, stream, ev);
+        if (small_plate_prepare(*d, sp, gl)) return launch_small_plate(sp, gl, stream, ev);
     }
     alan_tensor_t v;
     if (d->lse_out.data) {

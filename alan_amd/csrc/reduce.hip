@@ -442,9 +442,8 @@ int try_launch_small(const Canon &c, const GroupDesc &gd, const GroupLaunch &gl,
     }
     if (gd.n_out == 0) return ALAN_OK;
     // one output, thousands of loads: the 1024-thread kernel (every load of a thread's share in flight in two rounds)
-    static const int wide_knob = env_knob("ALAN_WIDE_FINAL");                          // ablation knob: 0 = off
     const int64_t slices = sd.presum_n > 1 ? sd.presum_n : 1;
-    if (wide_knob != 0 && gd.n_out == 1 && gl.block && (mode == ALAN_MODE_LSE || mode == ALAN_MODE_SUM) &&
+    if (gd.n_out == 1 && gl.block && (mode == ALAN_MODE_LSE || mode == ALAN_MODE_SUM) &&
         (int64_t)sd.n_red * (slices + sd.nf - 1) >= 4096) {
         const int per_thread = (int)((sd.n_red + 1023) / 1024);
         auto wide = [&](auto kern) { ALAN_LAUNCH_EXT(kern, dim3(1), dim3(1024), 0, stream, ev.start, ev.stop, 0, sd); };

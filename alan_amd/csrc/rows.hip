@@ -369,13 +369,9 @@ RowsPlan plan_rows(const Canon &c, int mode, int compute_dtype) {
     rp.P = nplate ? (uint32_t)c.ksize[0] : 1u;
     rp.NO = (uint32_t)(c.n_out / rp.P);
     rp.logG = L <= 32 ? 0 : L <= 64 ? 1 : L <= 128 ? 2 : 3;
-    static const int logg_knob = env_knob("ALAN_ROWS_LOGG");                                           // tuning knob
-    if (logg_knob != ENV_UNSET) rp.logG = std::max(rp.logG, std::min(3, logg_knob));
     rp.rot = gcd_i((int)L, 64) >= 16;
     if (rp.rot) while ((1 << rp.logG) > L / 4) --rp.logG;   // (the quad rotation wraps once per step)
     int rbmax = (int)std::min<int64_t>(256 >> rp.logG, (256 * ROWS_UNR * 4 - 4) / L);
-    static const int rbmax_knob = env_knob("ALAN_ROWS_RBMAX");                                      // tuning knob
-    if (rbmax_knob != ENV_UNSET) rbmax = std::max(1, std::min(rbmax, rbmax_knob));
     rp.n_windows = (rp.NO + rbmax - 1) / rbmax;
     rp.RB = (int)((rp.NO + rp.n_windows - 1) / rp.n_windows);
     rp.threads = 256;

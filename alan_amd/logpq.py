@@ -70,11 +70,7 @@ def logPQ_plate(name, P, Q, sample, inputs_params, data, extra_log_factors, scop
         lpq = PT(t.stack([pt_align(p, lpq.ids) for p in parts]).sum(0), lpq.dims)
     assert isinstance(lpq, PT)
     if sharded:
-        from . import split as S
-        if S.GATHER_PARTIALS and not t.is_grad_enabled() and lpq.x.dtype == t.float32:
-            lpq = S.all_gather_parts(lpq, computation_strategy.group)       # (added by the parent's launch: role PRESUM)
-        else:
-            lpq = all_reduce_sum(lpq, computation_strategy.group)
+        lpq = all_reduce_sum(lpq, computation_strategy.group)
     return lpq, (), (), ()
 
 

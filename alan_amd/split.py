@@ -238,27 +238,6 @@ def close_exchanges():
     _EXCHANGES.clear()
 
 
-GATHER_PARTIALS = False
-"""Gradient-free sharded evaluations: instead of all_reduce(SUM) of the rank's [K_parents...] partial, ONE all_gather of
-the ranks' partials into a [world, K_parents...] tensor that the parent's contraction adds as it loads it (role PRESUM:
-dims.PartialSumPT) -- the local sum of SURVEY 5's one-shot exchange fused into the top-level launch, with RCCL as the
-transport.  Off by default: which collective is faster for 40 KB over xGMI has not been measured on a multi-GPU node."""
-
-
-def all_gather_parts(lp, group=None):
-    """The ranks' partial log-marginals side by side: PartialSumPT([world, ...], dims); dims matched across ranks by name."""
-    from .dims import PartialSumPT, pt_align
-    ds = sorted(lp.dims, key=str)
-    pos = pt_align(lp, tuple(id(d) for d in ds)).contiguous()
-    world = dist.get_world_size(group)
-    parts = t.empty((world, *pos.shape), dtype=pos.dtype, device=pos.device)
-    dist.all_gather(list(parts.unbind(0)), pos, group=group)          # (one collective: RCCL's all-gather; gloo in the CPU tests)
-    ALL_REDUCES.append((group, pos.numel(), pos.dtype))
-    ALL_REDUCES[0] += 1
-    del ALL_REDUCES[1:-64]
-    return PartialSumPT(parts, ds)
-
-
 def all_reduce_sum(lp, group=None):
     """all_reduce(SUM) of a PT (or torchdim tensor); dims are matched across ranks by name."""
     from .dims import pt_align

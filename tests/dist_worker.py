@@ -36,13 +36,6 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path, devi
             n_chunks = len(alan.split.chunk_sizes(prob.all_platedims[platename].size, split_size))
             mine = list(strat.my_chunks(n_chunks))
             val = sample.elbo_nograd(strat)
-            # the same with the ranks' partials all-gathered and added by the parent's launch (split.GATHER_PARTIALS)
-            from alan_amd import split as S
-            S.GATHER_PARTIALS = True
-            try:
-                val_gather = sample.elbo_nograd(strat)
-            finally:
-                S.GATHER_PARTIALS = False
             graphed = None
             if backend_name == "nccl":         # the sharded evaluation, collective included, as a replayed HIP graph
                 graphed = [float(sample.elbo_nograd(strat, graph=True)) for _ in range(3)]
@@ -58,7 +51,7 @@ def run(rank, world, port, fixture, model, platename, split_size, out_path, devi
                 gsum.append(g / world)
             ref_val = sample.elbo_rws(alan.Split(platename, split_size))      # sequential Split, this rank alone
             ref_grads = t.autograd.grad(ref_val, params, allow_unused=True) if params else []
-        t.save({"rank": rank, "elbo": float(val), "elbo_gather": float(val_gather), "chunks": mine, "ref": float(fx["elbo"]["split"]), "graphed": graphed,
+        t.save({"rank": rank, "elbo": float(val), "chunks": mine, "ref": float(fx["elbo"]["split"]), "graphed": graphed,
                 "elbo_seq": float(ref_val),
                 "grad_err": max([float((a - (t.zeros_like(a) if b is None else b)).abs().max())
                                  for a, b in zip(gsum, ref_grads)] or [0.0])},

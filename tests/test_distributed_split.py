@@ -37,9 +37,8 @@ def test_sharded_split_world2(fixture, model, plate, size, merge):
     for r in res:
         assert abs(r["elbo"] - r["ref"]) <= 1e-4 * abs(r["ref"]) + 1e-5, r
         assert abs(r["elbo"] - r["elbo_seq"]) <= 1e-5 * abs(r["elbo_seq"]) + 1e-5
-        assert abs(r["elbo_gather"] - r["elbo"]) <= 1e-6 * abs(r["elbo"]) + 1e-6, r      # all-gather + PRESUM == all-reduce
         assert r["grad_err"] < 1e-3, r
-    assert res[0]["elbo"] == res[1]["elbo"] and res[0]["elbo_gather"] == res[1]["elbo_gather"]
+    assert res[0]["elbo"] == res[1]["elbo"]
     # the chunks were really partitioned
     all_chunks = sorted(c for r in res for c in r["chunks"])
     assert all_chunks == list(range(len(all_chunks))) and all(len(r["chunks"]) >= 1 for r in res)

@@ -242,3 +242,20 @@ def test_launch_lists_and_pipelines_reject_misuse_without_touching_the_gpu():
     assert L.alan_pipeline_create(lanes, 99, 0, ctypes.byref(pipe)) == -1
     assert L.alan_pipeline_submit(None, 1) == -1 and L.alan_pipeline_join(None, None) == -1
     assert L.alan_calls_destroy(h) == 0 and L.alan_calls_destroy(h2) == 0
+
+
+def test_documented_deviations_are_the_switches_actual_defaults():
+    """alan_amd/__init__.py lists every place where a drop-in user sees something other than the reference as
+    ``module.SWITCH`` = default | reference value: each switch exists, holds the documented default, and accepts the value
+    that restores the reference's behaviour (own the deviations)."""
+    import ast
+    import importlib
+    import alan_amd
+    rows = re.findall(r"``(\w+)\.(\w+)`` = (\S+) \| (\S+)", alan_amd.__doc__)
+    assert len(rows) >= 4, rows
+    for mod, name, default, ref in rows:
+        m = importlib.import_module(f"alan_amd.{mod}")
+        assert hasattr(m, name), f"alan_amd.{mod}.{name} is documented but does not exist"
+        assert getattr(m, name) == ast.literal_eval(default), (mod, name, getattr(m, name), default)
+        ast.literal_eval(ref)
+    assert ("posterior", "TIMESERIES_POSTERIOR", '"reference"', '"reference"') in rows      # (the reference's draws by default)
