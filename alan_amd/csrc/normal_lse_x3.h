@@ -130,8 +130,25 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
     float *lgp_l = lds + NST * NSTEP * 64 * 4;
     float *tile = lgp_l + NST * 4 * 64 + wave * (32 * 33 + NLW * 36);
     float *locl = tile + 32 * 33;                                   // [NLW][36]: events 0 .. 2 EQ - 1 <= 33
-    // ---- everything the wave needs from memory is requested before anything waits.  The loc rows: one coalesced load
-    // per row, handed to the lanes through LDS (lane (j, h) wants events 2 q + h: ten reads at immediate offsets)
+    // ---- everything the wave needs from memory is requested before anything waits -- the scale rows FIRST: the B table
+    // built from them, and the barrier behind it, are every wave's critical path (round 4: they were requested last, behind
+    // ~150 instructions of address arithmetic for the value tile).  Thread (wave w, lane) takes the event pairs w, w + 4,
+    // ... of its lane's (scale row, half) in every scale tile.
+    constexpr int NQI = (EQ + 3) / 4;
+    float xs[NST][NQI];
+    {
+        const int joff = j * d.s_ss, hoff = h ? d.s_se : 0, last_s = (NS - 1) * d.s_ss, last_e = (E - 1) * d.s_se;
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int qi = 0; qi < NQI; ++qi) {
+                const int q = wave + 4 * qi;                                                           // (scalar)
+                xs[st][qi] = d.scl[(uint32_t)(min(joff + 32 * (sg * NST + st) * d.s_ss, last_s) + min(hoff + q * 2 * d.s_se, last_e))];
+            }
+        asm volatile("" ::: "memory");                // (keep them in front of the loads below)
+    }
+    // The loc rows: one coalesced load per row, handed to the lanes through LDS (lane (j, h) wants events 2 q + h: ten
+    // reads at immediate offsets)
     float lrow[NLW];
 #pragma unroll
     for (int lw = 0; lw < NLW; ++lw)
@@ -203,16 +220,6 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
     // the barrier.  Branch-free and on the fast transcendental instructions (1 ulp): this is every wave's critical path.
     {
         unsigned *bw = reinterpret_cast<unsigned *>(lds);
-        constexpr int NQI = (EQ + 3) / 4;
-        float xs[NST][NQI];
-        const int joff = j * d.s_ss, hoff = h ? d.s_se : 0, last_s = (NS - 1) * d.s_ss, last_e = (E - 1) * d.s_se;
-#pragma unroll
-        for (int st = 0; st < NST; ++st)
-#pragma unroll
-            for (int qi = 0; qi < NQI; ++qi) {
-                const int q = wave + 4 * qi;                                                           // (scalar)
-                xs[st][qi] = d.scl[(uint32_t)(min(joff + 32 * (sg * NST + st) * d.s_ss, last_s) + min(hoff + q * 2 * d.s_se, last_e))];
-            }
 #ifdef ALAN_TIMELINE
         NL_STAMP(14);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -392,8 +392,9 @@ class Sample:
         from . import native as N
         # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
         from . import logpq as LP
+        from . import split as SP
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, N.CHAIN_FINAL)
+                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, N.CHAIN_FINAL, SP.ONE_SHOT_EXCHANGE)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)

@@ -548,6 +548,32 @@ def main():
                 d1, v1 = timed_evals(s100, st1, 10, 2, 1, graph=use_graph)
                 out["c4_movielens_K100"]["n1_same_run"] = {"evals_per_s": 10 / d1, "ms_per_eval": d1 / 10 * 1e3, "elbo": v1}
                 out["c4_movielens_K100"]["speedup_vs_n1_same_run"] = d1 / d100
+                out["c4_movielens_K100"]["collective"] = "RCCL all_reduce(SUM) of the [K, K] partial (the default)"
+                # the same sharded evaluation with the library's own one-shot exchange as its collective
+                # (split.ONE_SHOT_EXCHANGE: every rank writes its partial into every peer's inbox over xGMI and adds what
+                # arrived -- one library launch, so the evaluation is re-issued from its launch list instead of replayed as a
+                # graph), in this very run: both collectives read against the same n1_same_run
+                if True:
+                    from alan_amd import split as asplit
+                    saved = asplit.ONE_SHOT_EXCHANGE
+                    asplit.ONE_SHOT_EXCHANGE = True
+                    try:
+                        s100x = draw(prob, 100)
+                        s100x.elbo_nograd(st100, graph=False)                 # (sets the exchange up: outside any capture)
+                        dx, vx = timed_evals(s100x, st100, 10, 2, world, graph=use_graph)
+                        import torch.distributed as dist_
+                        done, bad = asplit.exchange_for(st100.group).status()
+                        out["c4_movielens_K100"]["one_shot_exchange"] = {
+                            "evals_per_s": 10 / dx, "ms_per_eval": dx / 10 * 1e3, "elbo": vx,
+                            "speedup_vs_n1_same_run": d1 / dx, "against_rccl": d100 / dx,
+                            "exchanges_completed": done, "first_failed_exchange": bad,
+                            "launch": launch_mode(s100x, use_graph),
+                            "elbo_rel_diff_vs_rccl": abs(vx - v100) / abs(v100)}
+                        del s100x
+                    except Exception as e:
+                        out["c4_movielens_K100"]["one_shot_exchange"] = {"error": f"{type(e).__name__}: {e}"}
+                    finally:
+                        asplit.ONE_SHOT_EXCHANGE = saved
         except Exception as e:
             out["c4_movielens_K100"] = {"error": f"{type(e).__name__}: {e}"}
         del s100
