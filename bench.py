@@ -548,7 +548,8 @@ def main():
                 d1, v1 = timed_evals(s100, st1, 10, 2, 1, graph=use_graph)
                 out["c4_movielens_K100"]["n1_same_run"] = {"evals_per_s": 10 / d1, "ms_per_eval": d1 / 10 * 1e3, "elbo": v1}
                 out["c4_movielens_K100"]["speedup_vs_n1_same_run"] = d1 / d100
-                out["c4_movielens_K100"]["collective"] = "RCCL all_reduce(SUM) of the [K, K] partial (the default)"
+                out["c4_movielens_K100"]["collective"] = ("gloo all_reduce (REHEARSAL: every rank on one GPU)" if rehearsal else
+                                                           "RCCL all_reduce(SUM) of the [K, K] partial (the default)")
                 # the same sharded evaluation with the library's own one-shot exchange as its collective
                 # (split.ONE_SHOT_EXCHANGE: every rank writes its partial into every peer's inbox over xGMI and adds what
                 # arrived -- one library launch, so the evaluation is re-issued from its launch list instead of replayed as a

@@ -40,10 +40,16 @@ def test_one_shot_exchange_sums_in_rank_order_on_every_rank(world):
 
 
 @pytest.mark.gpu
-def test_sharded_split_through_the_one_shot_exchange():
+@pytest.mark.parametrize("spin_ms", [None, "2000"], ids=["generous_wait", "default_2s_wait"])
+def test_sharded_split_through_the_one_shot_exchange(spin_ms, monkeypatch):
     """movielens K=10 (fp32), Split over the user plate sharded over two ranks: the ELBO with the partials summed by the
     exchange == the same through gloo's all_reduce (two summands: the same bits) == this rank evaluating every chunk
-    alone; replayed as a HIP graph too; RWS gradients averaged over ranks == the unsharded ones."""
+    alone; replayed as a HIP graph too; RWS gradients averaged over ranks == the unsharded ones.  Once with the library's
+    DEFAULT bounded wait of 2 s (the workers otherwise ask for 20 s, ranks time-slicing one GPU): what keeps a peer's wait
+    from being spent on the first launch's code loading is the warm-up launch in split.exchange_for, not the longer wait
+    (round 3's last commit made both changes at once and kept no log of a timeout: VERDICT r3 weak #12)."""
+    if spin_ms is not None:
+        monkeypatch.setenv("ALAN_EXCHANGE_SPIN_MS", spin_ms)
     res = _run(2, "split")
     for r in res:
         assert r["bad"] == 0, r
