@@ -1398,6 +1398,10 @@ def _dot_pt(a, b):
     sub = lambda p: "".join(letters.setdefault(i, chr(ord("a") + len(letters))) for i in p.ids)
     sa, sb = sub(a), sub(b)
     expr = f"{sa}Z,{sb}Z->{''.join(letters[i] for i in ids)}"
+    from . import native as N_
+    N_.trace("lambda", f"a dot term of a linear-logits lambda with {n_out} outputs (its operands lack some dim of the likelihood's "
+             "index space, so it is evaluated once instead of inside the producer)", torch=True,
+             route="a (batched) GEMM of torch's (rocBLAS): the library's own dot launch takes up to 32768 outputs")
     if LAMBDA_BLAS is None:
         return PT(t.einsum(expr, a.x, b.x), dims)
     with _blas(LAMBDA_BLAS):                          # (the lambda's own product: its backend, see LAMBDA_BLAS)
@@ -1428,16 +1432,28 @@ def _producer_terms(value, terms):
     return out
 
 
+def _lambda_name(fn, named_args):
+    try:
+        src = inspect.getsource(fn).strip().replace("\n", " ")
+        src = src[src.index("lambda"):][:90] if "lambda" in src else getattr(fn, "__name__", "lambda")
+    except Exception:
+        src = getattr(fn, "__name__", "lambda")
+    return f"{src}   (arguments: {', '.join(n for n, _ in named_args)})"
+
+
 def call_model_lambda(fn, named_args, dimcache=None):
+    from . import native as N_
     vals = [v for _, v in named_args]
     if len(vals) == 1 and type(vals[0]) in (PT, ReparamPT) and vals[0].x.is_floating_point() and _is_plain_exp(fn):
         # exp of one variable: keep it lazy (dims.ExpPT) -- a fused Normal producer then takes the log-scale as it is
         # (alan_reduce mode NORMAL_LOGSCALE) and the exp launch never happens; anyone else reading .x gets exp(raw)
+        N_.trace("lambda", _lambda_name(fn, named_args), route="exp of one variable: left unevaluated, the consumer's launch takes the log-scale")
         return ExpPT(vals[0].x, vals[0].dims)
     if LAZY_SCALED and len(vals) == 1 and isinstance(vals[0], ShiftPT) and not vals[0].materialised \
             and vals[0].rest.dtype == t.float32:
         c = _scaled_form(fn)
         if c is not None:                         # c * (the un-concatenated previous state): both stay as they are
+            N_.trace("lambda", _lambda_name(fn, named_args), route=f"{c} x the previous state: left unevaluated, the chain's first round multiplies")
             return ScaledPT(None, c, vals[0].dims, src=vals[0])
     if LAZY_SCALED and len(vals) == 1 and type(vals[0]) is PT and vals[0].x.is_cuda and vals[0].x.dtype == t.float32 \
             and not (t.is_grad_enabled() and vals[0].x.requires_grad):
@@ -1445,13 +1461,18 @@ def call_model_lambda(fn, named_args, dimcache=None):
         if c is not None:
             # a constant multiple of one variable: lazy (dims.ScaledPT) -- a fused Normal producer takes it as the
             # location's scale field and the multiply launch never happens; anyone else reading .x gets c * v
+            N_.trace("lambda", _lambda_name(fn, named_args), route=f"{c} x one variable: left unevaluated, the Normal producer multiplies its location")
             return ScaledPT(vals[0].x, c, vals[0].dims)
     if LINEAR_LOGITS and LAMBDA_BACKEND == "vmap" and len(vals) >= 2 and all(type(v) in (PT, ReparamPT) for v in vals):
         form = _linear_form(fn)
         if form is not None:
             lin = _linear_pt(fn, named_args, form, dimcache)
             if lin is not None:
+                N_.trace("lambda", _lambda_name(fn, named_args), route="sum of arguments / dot products: left unevaluated, the Bernoulli "
+                         "producer computes the logits in its launch (a gradient-carrying use evaluates it: library launches too)")
                 return lin
+    N_.trace("lambda", _lambda_name(fn, named_args), route="RUNS AS WRITTEN through torch (vmap over the K / plate dims): its kernels are "
+             "torch's, so a captured evaluation replays as a HIP graph, not from the library's launch list", torch=True)
     return _call_lambda_vmap(fn, named_args, dimcache)
 
 

@@ -273,6 +273,31 @@ class CallList:
 
 
 _REC = [None]            # the CallList being recorded (sample._GraphedELBO sets it around its capture pass)
+_TRACE = [None]          # a list collecting what an evaluation did (Sample.explain): launches and model-lambda routes
+
+_MODE_NAMES = {0: "LSE", 1: "SUM", 2: "WEXPSUM", 3: "NORMAL", 4: "BERNOULLI", 5: "NORMAL_LOGSCALE", 6: "PRODUCER_GRAD",
+               7: "BERNOULLI_LINEAR", 8: "DOT", 9: "BERNOULLI_LINEAR_GRAD", 10: "AFFINE"}
+
+
+def trace(kind, what, **info):
+    """One line of Sample.explain()'s report (nothing unless a report is being collected)."""
+    if _TRACE[0] is not None:
+        _TRACE[0].append({"kind": kind, "what": what, **info})
+
+
+def _desc_info(desc):
+    sizes = [int(desc.size[i]) for i in range(desc.ndim)]
+    roles = [int(desc.role[i]) for i in range(desc.ndim)]
+    red = 1
+    out = 1
+    for s, r in zip(sizes, roles):
+        if r in (REDUCE, 3):
+            red *= s
+        elif r in (KEEP, PLATE) and r == KEEP:
+            out *= s
+    return {"mode": _MODE_NAMES.get(int(desc.mode), str(int(desc.mode))), "factors": int(desc.n_factors), "outputs": out,
+            "reduced_per_output": red, "plate_dims": sum(r == PLATE for r in roles), "presum": any(r == PRESUM for r in roles),
+            "result_ring": bool(desc.ring_n)}
 
 
 def _spoil():
@@ -612,6 +637,9 @@ def _flush_items(items):
     st = _GRAPH_NOISE[0]
     if st is not None and st.n == 1 and not st.handon and not any(d.noise.on for d, _, _ in items):
         st.carry(items)                                   # (the single launch that drew hands on through this batch's launch)
+    if _TRACE[0] is not None:
+        trace("launch", "alan_reduce" if len(items) == 1 else "alan_reduce_batch (one multi-problem launch per eight small problems)",
+              problems=[_desc_info(d) for d, _, _ in items])
     if len(items) == 1:
         rc = L.alan_reduce(C.byref(items[0][0]), None, 0, current_stream(device))
         check(rc, "alan_reduce")
@@ -660,6 +688,8 @@ def run_reduce(desc, device, algo_bytes=0, keepalive=()):
     if rc == ERR_UNSUPPORTED and desc.ring_n:
         return False
     check(rc, "alan_reduce")
+    if _TRACE[0] is not None:
+        trace("launch", "alan_reduce", problems=[_desc_info(desc)], workspace_bytes=int(nbytes))
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
         _REC[0].record(L.alan_reduce, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
@@ -686,6 +716,7 @@ def run_reduce_backward(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_reduce_backward")
+    trace("launch", "alan_reduce_backward (all gradients of a log-sum-exp in one pass)", problems=[_desc_info(desc.fwd)])
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
         _REC[0].record(L.alan_reduce_backward, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
@@ -706,6 +737,9 @@ def run_normal_lse(desc, device, keepalive=()):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse")
+    trace("launch", "alan_normal_lse (fused plate step: Normal producer + log-sum-exp + plate sum, the factor never written)",
+          M=int(desc.M), K_child=int(desc.NK), loc_rows=int(desc.NL), scale_rows=int(desc.NS), event=int(desc.E),
+          small_factors=int(desc.n_small), partial_slices_kept=bool(desc.keep_partials))
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
         _REC[0].record(L.alan_normal_lse, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)
@@ -729,6 +763,7 @@ def run_normal_lse_backward(desc, device):
     if rc == ERR_UNSUPPORTED:
         return False
     check(rc, "alan_normal_lse_backward")
+    trace("launch", "alan_normal_lse_backward (every gradient of the fused plate step in one pass)")
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
         _REC[0].record(L.alan_normal_lse_backward, C.byref(desc), ws.data_ptr(), nbytes, None)
@@ -759,6 +794,7 @@ def chain_logmmexp(ms, want_chain=False):
             tree.data_ptr(), nbytes)
     rc = L.alan_chain_logmmexp_batched(*args, current_stream(ms.device))
     check(rc, "alan_chain_logmmexp_batched")
+    trace("launch", "alan_chain_logmmexp_batched (timeseries chain)", chains=int(B), T=int(T), K=int(K))
     if _REC[0] is not None:
         _REC[0].keep.append((m4, chain, vec, tree))
         _REC[0].record(L.alan_chain_logmmexp_batched, *args, None)
@@ -813,6 +849,9 @@ def chain_logmmexp_terms(terms, normal=None):
         if rc == ERR_UNSUPPORTED and fin is not None:
             return False
         check(rc, "alan_chain_logmmexp_terms_final")
+        trace("launch", "alan_chain_logmmexp_terms_final (timeseries chain" + (", Normal transition computed on load" if nd is not None else "")
+              + (", the evaluation's final log-sum-exp behind its last round" if fin is not None else "") + ")", chains=int(B), T=int(T), K=int(K),
+              terms=len(terms))
         if _REC[0] is not None:
             _REC[0].keep.append((terms, normal, tree, vec))
             _REC[0].record(L.alan_chain_logmmexp_terms_final, ptrs, strides, len(terms),

@@ -418,6 +418,60 @@ class Sample:
         """n independent evaluations of ``elbo_nograd`` (Sample.py:135-148), overlapped on the chip: a [n] fp32 tensor."""
         return self.pipeline(computation_strategy, lanes).run(n)
 
+    def explain(self, computation_strategy=checkpoint, as_text=True):
+        """Which route ``elbo_nograd(computation_strategy)`` takes (VERDICT r3 item 9 iii): every library launch of one eager
+        evaluation in order (entry point, mode, sizes), every model lambda with what became of it (left unevaluated for a
+        launch that computes it, or run as written through torch), and how a captured evaluation replays -- from the
+        library's recorded launch list, as a HIP graph (it holds kernels that are not the library's: their count is given),
+        or not at all.  Runs one eager evaluation and, on the GPU, one capture.  -> text, or the dict behind it."""
+        from . import native as N
+        rep = {"launches": [], "lambdas": [], "replay": None}
+        saved, N._TRACE[0] = N._TRACE[0], []
+        try:
+            with t.no_grad():
+                val = self._elbo(self._pt_detached, None, computation_strategy)
+            events = N._TRACE[0]
+        finally:
+            N._TRACE[0] = saved
+        rep["elbo"] = float(val)
+        rep["launches"] = [e for e in events if e["kind"] == "launch"]
+        rep["lambdas"] = [e for e in events if e["kind"] == "lambda"]
+        if self.device.type == "cuda":
+            try:
+                from .training import node_kinds
+                g = self._graphed(computation_strategy)
+                kinds = node_kinds(g.graph)
+                rep["replay"] = {"how": "the library's recorded launch list (alan_calls_replay)" if g.calls is not None else "HIP graph replay",
+                                 "graph_kernel_nodes": None if kinds is None else kinds[0],
+                                 "graph_other_nodes": None if kinds is None else kinds[1],
+                                 "library_launches_recorded": g.calls.launches() if g.calls is not None else None,
+                                 "result": "through the result ring (no copy)" if g.ring is not None else "copied out of the graph's buffer"}
+            except Exception as e:
+                rep["replay"] = {"how": f"not capturable: {type(e).__name__}: {e}"[:300]}
+        if not as_text:
+            return rep
+        lines = [f"elbo_nograd({type(computation_strategy).__name__ if not isinstance(computation_strategy, type) else computation_strategy.__name__}) = {rep['elbo']:.6g}",
+                 f"library launches of one evaluation: {len(rep['launches'])}"]
+        for i, e in enumerate(rep["launches"]):
+            extra = {k: v for k, v in e.items() if k not in ("kind", "what", "problems")}
+            lines.append(f"  {i + 1}. {e['what']}" + (f"  {extra}" if extra else ""))
+            for p in e.get("problems", []):
+                lines.append(f"       - {p['mode']}: {p['factors']} factor(s), {p['outputs']} output(s) x {p['reduced_per_output']} reduced"
+                             + (", plate sum fused" if p["plate_dims"] else "") + (", adds partial slices on load" if p["presum"] else "")
+                             + (", delivers through the result ring" if p["result_ring"] else ""))
+        lines.append(f"model lambdas: {len(rep['lambdas'])}")
+        for e in rep["lambdas"]:
+            lines.append(f"  - {e['what']}\n      -> {e['route']}")
+        if rep["replay"] is not None:
+            r = rep["replay"]
+            lines.append("a captured evaluation replays through: " + r["how"])
+            if r.get("graph_kernel_nodes") is not None:
+                lib = r.get("library_launches_recorded")
+                lines.append(f"  captured graph: {r['graph_kernel_nodes']} kernel node(s), {r['graph_other_nodes']} other node(s)"
+                             + (f"; all {lib} are the library's" if lib is not None else "; some are not the library's (see the lambdas above)"))
+                lines.append(f"  result: {r['result']}")
+        return "\n".join(lines)
+
     # ---- the path's backward in production use (Sample.py:208-346) ---------------------------------
     def _marginal_idxs(self, joints, computation_strategy):
         """{frozenset(groupvarnames): posterior weights over their K dims (and active plates)}: the

@@ -1004,3 +1004,44 @@ def test_training_iteration_with_the_library_adam_replays_from_its_launch_list(m
     for a, b, c in zip(p_direct, p_graph, p_eager):
         t.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
         t.testing.assert_close(a, c, rtol=1e-3, atol=1e-4)
+
+
+def test_explain_reports_the_lambdas_routes_on_the_host_logic_route(oracle_backend):
+    """Sample.explain(): every model lambda with what became of it (bus_breakdown: two exps left unevaluated; on the CPU
+    the likelihood's lambda runs as written)."""
+    fx = load_golden("e2e_bus_breakdown_K3.pt")
+    pb = models.BUILDERS["bus_breakdown"](fx)
+    sb = models.sample_from_fixture(pb, fx, "cpu")
+    rep = sb.explain(alan.no_checkpoint, as_text=False)
+    assert abs(rep["elbo"] - float(fx["elbo"]["no_checkpoint"])) <= 1e-4 * abs(rep["elbo"])
+    routes = [e["route"] for e in rep["lambdas"]]
+    assert sum("exp of one variable" in r for r in routes) == 2 and any("RUNS AS WRITTEN" in r for r in routes)
+    assert "model lambdas: 3" in sb.explain(alan.no_checkpoint)
+
+
+@pytest.mark.gpu
+def test_explain_names_the_launches_and_how_an_evaluation_replays():
+    """movielens K=30: three library launches (the producers as one multi-problem launch, the fused plate step, the final
+    log-sum-exp that adds the partial slices and delivers through the ring), the `z @ x` lambda left to the Bernoulli
+    producer, replay from the recorded launch list; bus_breakdown: its dot terms are torch GEMMs, so it replays as a graph
+    and the report says which lambda part is torch's."""
+    g = t.Generator().manual_seed(5)
+    x = t.randn(300, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+    obs = (t.rand(300, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+    prob = models.movielens(sizes={"plate_1": 300, "plate_2": 5}, x=x, obs=obs)
+    prob.to("cuda")
+    t.manual_seed(3)
+    sample = prob.sample(30, reparam=False)
+    rep = sample.explain(alan.no_checkpoint, as_text=False)
+    assert [e["what"].split(" ")[0] for e in rep["launches"]] == ["alan_reduce_batch", "alan_normal_lse", "alan_reduce"], rep["launches"]
+    assert rep["launches"][2]["problems"][0]["presum"] and rep["launches"][2]["problems"][0]["result_ring"] is False   # (eager: no ring)
+    assert any("left unevaluated, the Bernoulli" in e["route"] for e in rep["lambdas"]) and not any(e.get("torch") for e in rep["lambdas"])
+    assert rep["replay"]["how"].startswith("the library's recorded launch list") and rep["replay"]["library_launches_recorded"] == 3
+    text = sample.explain(alan.no_checkpoint)
+    assert "alan_normal_lse" in text and "launch list" in text
+    fx = load_golden("e2e_bus_breakdown_K10.pt")
+    pb = models.BUILDERS["bus_breakdown"](fx).to("cuda")
+    sb = models.sample_from_fixture(pb, fx, "cuda")
+    rb = sb.explain(alan.no_checkpoint, as_text=False)
+    if rb["replay"]["how"].startswith("HIP graph"):
+        assert any(e.get("torch") for e in rb["lambdas"]), rb["lambdas"]
