@@ -100,6 +100,7 @@ class _GraphedELBO:
             # (a sharded evaluation whose collective is the library's own one-shot exchange is library launches too; one
             # that went through RCCL keeps its graph)
             self.calls = self._direct(rec, side) if (rec is not None and ALL_REDUCES[0] == n_collectives) else None
+            self.recorded_launches = rec.launches() if (rec is not None and not rec.spoiled) else None
         finally:
             N._TIMER[0] = timer
             E._RING[0] = None
@@ -444,7 +445,7 @@ class Sample:
                 rep["replay"] = {"how": "the library's recorded launch list (alan_calls_replay)" if g.calls is not None else "HIP graph replay",
                                  "graph_kernel_nodes": None if kinds is None else kinds[0],
                                  "graph_other_nodes": None if kinds is None else kinds[1],
-                                 "library_launches_recorded": g.calls.launches() if g.calls is not None else None,
+                                 "library_launches_recorded": getattr(g, "recorded_launches", None),
                                  "result": "through the result ring (no copy)" if g.ring is not None else "copied out of the graph's buffer"}
             except Exception as e:
                 rep["replay"] = {"how": f"not capturable: {type(e).__name__}: {e}"[:300]}
@@ -466,9 +467,11 @@ class Sample:
             r = rep["replay"]
             lines.append("a captured evaluation replays through: " + r["how"])
             if r.get("graph_kernel_nodes") is not None:
-                lib = r.get("library_launches_recorded")
-                lines.append(f"  captured graph: {r['graph_kernel_nodes']} kernel node(s), {r['graph_other_nodes']} other node(s)"
-                             + (f"; all {lib} are the library's" if lib is not None else "; some are not the library's (see the lambdas above)"))
+                lib, nk = r.get("library_launches_recorded"), r["graph_kernel_nodes"]
+                lines.append(f"  captured graph: {nk} kernel node(s), {r['graph_other_nodes']} other node(s)"
+                             + (f"; all {lib} are the library's" if lib == nk and not r["graph_other_nodes"]
+                                else f"; {lib} are the library's, the other {nk - lib} are torch's (a model lambda's arithmetic, a dtype "
+                                     "conversion, a copy)" if lib is not None else ""))
                 lines.append(f"  result: {r['result']}")
         return "\n".join(lines)
 
