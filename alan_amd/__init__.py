@@ -44,7 +44,7 @@ from .contract import (reduce_Ks, collect_lps, logsumexp_sum, logsumexp_dims, lo
 
 from .training import GraphedStep, GraphedEval
 from .optim import Adam
-from .sample import EvalPipeline
+from .sample import EvalPipeline, SamplingPipeline
 
 samplers = [CategoricalSampler, PermutationSampler]
 

@@ -145,26 +145,36 @@ class EvalPipeline:
     the device.  Only evaluations that are library launches alone can be pipelined (NativeError otherwise: a model
     lambda's torch kernels, an RCCL collective)."""
 
-    def __init__(self, sample, computation_strategy=checkpoint, lanes=3, threads=None, results=4096):
+    def __init__(self, sample, computation_strategy=checkpoint, lanes=3, threads=None, results=4096, fresh_samples_of=None):
+        """``fresh_samples_of=(problem, K)`` (``sample`` is then ignored: see ``SamplingPipeline``): every evaluation draws its
+        own particles first -- the lanes are training.GraphedEval captures."""
         import ctypes as C
         from . import engine as E
         from . import native as N
-        if sample.device.type != "cuda":
+        self.problem = sample.problem if fresh_samples_of is None else fresh_samples_of[0]
+        if self.problem.device.type != "cuda":
             raise N.NativeError("alan_amd: an EvalPipeline runs on the GPU")
         if not 1 <= lanes <= 8:
             raise ValueError("1 to 8 lanes")
         self.sample, self.strategy, self.n_lanes, self.capacity = sample, computation_strategy, lanes, int(results)
-        self.fingerprint = sample.problem.memory_fingerprint()
+        self.fingerprint = self.problem.memory_fingerprint()
         self._h = None
+        device = self.problem.device
         # (the lanes' result slots interleaved in one buffer: evaluation i of the pipeline delivers to element i mod its size)
-        self.buf = t.empty(lanes * self.capacity, dtype=t.float32, device=sample.device)
-        self.lanes = [_GraphedELBO(sample, computation_strategy,
-                                   ring=E.ResultStrip(sample.device, results, buf=self.buf, offset=l, stride=lanes))
-                      for l in range(lanes)]
+        self.buf = t.empty(lanes * self.capacity, dtype=t.float32, device=device)
+        strips = [E.ResultStrip(device, results, buf=self.buf, offset=l, stride=lanes) for l in range(lanes)]
+        if fresh_samples_of is None:
+            self.lanes = [_GraphedELBO(sample, computation_strategy, ring=strips[l]) for l in range(lanes)]
+        else:
+            from .training import GraphedEval
+            self.lanes = [GraphedEval(self.problem, fresh_samples_of[1], computation_strategy, ring=strips[l]) for l in range(lanes)]
+        self._noise_expect = None
         for ln in self.lanes:
             if ln.calls is None or not isinstance(ln.ring, E.ResultStrip):
                 raise N.NativeError("alan_amd: this evaluation is not library launches alone (a model lambda's torch kernels, "
                                     "a collective, an fp64 result): it cannot be pipelined -- use sample.elbo_nograd()")
+        if any(getattr(ln, "noise", None) is not None and ln.noise.per_replay != self.lanes[0].noise.per_replay for ln in self.lanes):
+            raise N.NativeError("alan_amd: the lanes' captures draw different amounts of noise")
         handles = (C.c_void_p * lanes)(*[ln.calls._h for ln in self.lanes])
         h = C.c_void_p()
         N.check(N.lib().alan_pipeline_create(handles, lanes, lanes if threads is None else int(threads), C.byref(h)),
@@ -178,27 +188,48 @@ class EvalPipeline:
         from . import native as N
         if n > self.n_lanes * self.capacity - (self.total - self.first):
             raise ValueError(f"at most {self.n_lanes * self.capacity} evaluations between two results() calls")
-        if self.sample.problem.memory_fingerprint() != self.fingerprint:
+        if self.problem.memory_fingerprint() != self.fingerprint:
             raise N.NativeError("alan_amd: the problem's tensors moved since this pipeline was built: build a new one")
         L = N.lib()
-        stream = t.cuda.current_stream(self.sample.device).cuda_stream
+        self._sync_noise(int(n))
+        stream = t.cuda.current_stream(self.problem.device).cuda_stream
         N.check(L.alan_pipeline_fence(self._h, stream), "alan_pipeline_fence")
         N.check(L.alan_pipeline_submit(self._h, int(n)), "alan_pipeline_submit")
         self.total += int(n)
+
+    def _sync_noise(self, n):
+        """Lanes that draw their own particles (GraphedEval captures): each lane's generator state lives on the device and
+        advances by itself; lane l draws from Philox key seed ^ golden(l + 1) -- independent streams per lane, reproducible
+        under torch.manual_seed, NOT the particles the same evaluations launched one by one would draw.  When torch's
+        generator was re-seeded or used by anyone else since the last submit, every lane's state is rewritten (16 bytes each,
+        on the current stream, which the lanes wait for); the generator then moves past what the batch consumes."""
+        noises = [getattr(ln, "noise", None) for ln in self.lanes]
+        if not noises or noises[0] is None or not noises[0].per_replay:
+            return
+        dev = self.problem.device
+        gen = t.cuda.default_generators[dev.index if dev.index is not None else t.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        if (seed, off) != self._noise_expect:
+            for l, nz in enumerate(noises):
+                s_l = (seed ^ (0x9E3779B97F4A7C15 * (l + 1))) & ((1 << 64) - 1)
+                nz.state[0:2].copy_(t.tensor([off, s_l - (1 << 64) if s_l >= (1 << 63) else s_l], dtype=t.int64))
+        adv = noises[0].per_replay * (-(-n // self.n_lanes))
+        gen.set_offset(off + adv)
+        self._noise_expect = (seed, off + adv)
 
     def results(self, copy=True):
         """The ELBOs of every evaluation submitted since the last results() call, in submission order, ordered after the
         evaluations on the current stream: a new [n] fp32 tensor -- or, ``copy=False``, a VIEW of the pipeline's result
         buffer (no kernel at all), valid until lanes x results further evaluations have been submitted."""
         from . import native as N
-        stream = t.cuda.current_stream(self.sample.device).cuda_stream
+        stream = t.cuda.current_stream(self.problem.device).cuda_stream
         N.check(N.lib().alan_pipeline_join(self._h, stream), "alan_pipeline_join")
         i0, i1, size = self.first, self.total, self.n_lanes * self.capacity
         self.first = i1
         # evaluation i ran on lane i % L as that lane's evaluation i // L: element i mod (L R) of the shared buffer
         a, b = i0 % size, i1 % size
         if i1 == i0:
-            return t.empty(0, dtype=t.float32, device=self.sample.device)
+            return t.empty(0, dtype=t.float32, device=self.problem.device)
         if a < b:
             return self.buf[a:b].clone() if copy else self.buf[a:b]
         return t.cat([self.buf[a:], self.buf[:b]])
@@ -218,6 +249,16 @@ class EvalPipeline:
             self.close()
         except Exception:
             pass
+
+
+class SamplingPipeline(EvalPipeline):
+    """``SamplingPipeline(problem, K, strategy, lanes=4).run(n)``: n times ``problem.sample(K).elbo_nograd(strategy)`` --
+    FRESH particles per evaluation, what the reference's runner times per iteration (basic_runner.py:86-97) -- overlapped
+    as an EvalPipeline's evaluations are.  Every lane draws from a generator state of its own on the device (Philox key =
+    torch's seed mixed with the lane's number): n independent ELBO estimates, reproducible under ``torch.manual_seed``."""
+
+    def __init__(self, problem, K, computation_strategy=checkpoint, lanes=4, threads=None, results=4096):
+        super().__init__(None, computation_strategy, lanes, threads, results, fresh_samples_of=(problem, K))
 
 
 def strategy_key(strategy):

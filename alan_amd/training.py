@@ -282,7 +282,8 @@ class GraphedEval:
         from . import sample as S
         self.problem, self.K, self.strategy, self.unroll = problem, K, computation_strategy, unroll
         # the evaluation's last launch delivers through a result ring (engine.ResultRing): no copy after a replay
-        self.ring = E.ResultRing.create(problem.device) if (ring and S.RESULT_RING and unroll == 1) else None
+        self.ring = ring if isinstance(ring, E.ResultRing) else \
+            (E.ResultRing.create(problem.device) if (ring and S.RESULT_RING and unroll == 1) else None)
         E._RING[0] = self.ring
         from . import native as N
         try:

@@ -685,6 +685,21 @@ def main():
             del ev8
         except Exception as e:
             out["sample_plus_elbo"]["graph_unroll8_error"] = f"{type(e).__name__}: {e}"
+        try:                                      # the same iterations overlapped (alan_amd.SamplingPipeline: a generator state per lane)
+            sp_ = alan.SamplingPipeline(prob, K, strat, lanes=4, results=1024)
+            sp_.run(64)
+            t.cuda.synchronize()
+            t0 = time.perf_counter()
+            v_sp = sp_.run(2000)
+            t.cuda.synchronize()
+            dt_sp = (time.perf_counter() - t0) / 2000
+            out["sample_plus_elbo"].update({"pipelined_ms_per_iter": dt_sp * 1e3, "pipelined_iters_per_s": 1 / dt_sp, "pipelined_n_streams": 4,
+                                            "pipelined_distinct_elbos_of_2000": len(set(v_sp.tolist())),
+                                            "pipelined_mean_elbo": float(v_sp.mean())})
+            sp_.close()
+            del sp_
+        except Exception as e:
+            out["sample_plus_elbo"]["pipelined_error"] = f"{type(e).__name__}: {e}"
         # row a10 (the path's backward) in production use: a whole training iteration -- sample -> elbo_vi | elbo_rws ->
         # backward -> Adam, the loop of examples/basic_runner.py:81-112 -- captured once and replayed
         try:

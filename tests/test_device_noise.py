@@ -288,3 +288,29 @@ def test_graphed_eval_replays_through_its_recorded_launches():
     t.manual_seed(2)
     through_graph = [float(ev2()) for _ in range(5)]
     assert direct == through_graph and len(set(direct)) == 5
+
+
+@pytest.mark.gpu
+def test_sampling_pipeline_draws_fresh_particles_per_evaluation_reproducibly():
+    """SamplingPipeline: n overlapped `sample() + elbo` evaluations, each with its own particles (a generator state per lane
+    on the device, keyed by torch's seed and the lane's number): all values different, the same values again under the same
+    seed, other values under another, and distributed as the one-by-one evaluations' (GraphedEval) are."""
+    prob = _movielens()
+    pipe = alan.SamplingPipeline(prob, 8, alan.no_checkpoint, lanes=3, results=256)
+    t.manual_seed(5)
+    a = pipe.run(300).cpu()
+    t.manual_seed(5)
+    b = pipe.run(300).cpu()
+    t.manual_seed(6)
+    c = pipe.run(300).cpu()
+    assert len(set(a.tolist())) == 300
+    assert t.equal(a, b) and not t.equal(a, c)
+    d = pipe.run(300).cpu()                       # (the generator moved on: new draws without a re-seed)
+    assert not t.equal(c, d) and len(set(c.tolist()) & set(d.tolist())) == 0
+    ev = alan.GraphedEval(prob, 8)
+    t.manual_seed(7)
+    one = t.tensor([float(ev()) for _ in range(300)])
+    se = float(one.std()) / 300 ** 0.5
+    assert abs(float(a.mean() - one.mean())) <= 5 * 2 ** 0.5 * se, (float(a.mean()), float(one.mean()), se)
+    assert 0.7 <= float(a.std() / one.std()) <= 1.4
+    pipe.close()
