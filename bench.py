@@ -825,6 +825,9 @@ def main():
                 us = d_g / n_g * 1e6
                 rec = {"evals_per_s": n_g / d_g, "us_per_eval": us, "elbo": v_g, "algorithmic_bytes": algo(k2),
                        "hbm_floor_us": algo(k2) / HBM_PEAK_GBS / 1e3}
+                if k2 in (30, 100) and world == 1:
+                    # independent evaluations overlapped (alan_pipeline_*), every result checked against the eager value
+                    rec["pipelined"] = pipelined_figure(s2, alan.no_checkpoint, 400 if k2 == 30 else 100, 4, us)
                 if k2 == 30:
                     d_e, _ = timed_evals(s2, alan.no_checkpoint, 20, 3, world)          # graph=False: kernel by kernel
                     rec["evals_per_s_eager"] = 20 / d_e
