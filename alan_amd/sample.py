@@ -163,11 +163,20 @@ class EvalPipeline:
         # (the lanes' result slots interleaved in one buffer: evaluation i of the pipeline delivers to element i mod its size)
         self.buf = t.empty(lanes * self.capacity, dtype=t.float32, device=device)
         strips = [E.ResultStrip(device, results, buf=self.buf, offset=l, stride=lanes) for l in range(lanes)]
-        if fresh_samples_of is None:
-            self.lanes = [_GraphedELBO(sample, computation_strategy, ring=strips[l]) for l in range(lanes)]
-        else:
-            from .training import GraphedEval
-            self.lanes = [GraphedEval(self.problem, fresh_samples_of[1], computation_strategy, ring=strips[l]) for l in range(lanes)]
+        from . import split as SP
+        self.lanes = []
+        try:
+            for l in range(lanes):
+                # (a sharded evaluation whose collective is the library's one-shot exchange: an exchange -- an inbox on every
+                # rank -- per lane; every rank builds its pipeline's lanes in the same order)
+                SP._EXCHANGE_LANE[0] = l + 1
+                if fresh_samples_of is None:
+                    self.lanes.append(_GraphedELBO(sample, computation_strategy, ring=strips[l]))
+                else:
+                    from .training import GraphedEval
+                    self.lanes.append(GraphedEval(self.problem, fresh_samples_of[1], computation_strategy, ring=strips[l]))
+        finally:
+            SP._EXCHANGE_LANE[0] = 0
         self._noise_expect = None
         for ln in self.lanes:
             if ln.calls is None or not isinstance(ln.ring, E.ResultStrip):

@@ -195,6 +195,9 @@ for the ranks of ONE node and tested with processes sharing one GPU -- the arith
 ONE_SHOT_CAPACITY = int(os.environ.get("ALAN_AMD_ONE_SHOT_CAPACITY", str(1 << 16)))      # fp32 elements per partial
 
 _EXCHANGES = {}
+_EXCHANGE_LANE = [0]     # which of a group's exchanges is meant: an EvalPipeline's lanes each take their own (their exchanges
+                         # are then issued on different streams, in an order that may differ between the ranks -- one inbox
+                         # per lane keeps every inbox's sequence the same on all ranks)
 
 
 def one_shot_takes(x, world):
@@ -207,7 +210,7 @@ def exchange_for(group=None):
     """The group's exchange; the first call (every rank makes it together, outside any stream capture) allocates the
     inboxes and carries their IPC handles between the ranks with the group's own all_gather_object."""
     from . import native as N
-    key = id(group) if group is not None else None
+    key = (id(group) if group is not None else None, _EXCHANGE_LANE[0])
     ex = _EXCHANGES.get(key)
     if ex is None:
         if t.cuda.is_current_stream_capturing():

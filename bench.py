@@ -570,6 +570,12 @@ def main():
                             "exchanges_completed": done, "first_failed_exchange": bad,
                             "launch": launch_mode(s100x, use_graph),
                             "elbo_rel_diff_vs_rccl": abs(vx - v100) / abs(v100)}
+                        if use_graph:
+                            # and the rank's sharded evaluations overlapped (an exchange per lane): every rank issues the same batch
+                            pfx = pipelined_figure(s100x, st100, 120, 3, dx / 10 * 1e6)
+                            if "error" not in pfx:
+                                pfx["speedup_vs_n1_same_run"] = d1 / 10 * 1e6 / pfx["us_per_eval"]
+                            out["c4_movielens_K100"]["one_shot_exchange"]["pipelined"] = pfx
                         del s100x
                     except Exception as e:
                         out["c4_movielens_K100"]["one_shot_exchange"] = {"error": f"{type(e).__name__}: {e}"}

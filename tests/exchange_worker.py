@@ -105,6 +105,26 @@ def run(rank, world, port, out_path, what="direct"):
             done, bad = S.exchange_for(None).status()
             res.update(one_shot=one_shot, graphed=graphed, through_gloo=through_gloo, alone=alone, grad_err=gerr,
                        done=done, bad=bad)
+        elif what == "pipeline":
+            import models
+            g = t.Generator().manual_seed(5)
+            x = t.randn(120, 5, 18, generator=g).refine_names("plate_1", "plate_2", None)
+            obs = (t.rand(120, 5, generator=g) < 0.5).float().refine_names("plate_1", "plate_2")
+            prob = models.movielens(sizes={"plate_1": 120, "plate_2": 5}, x=x, obs=obs)
+            prob.to("cuda")
+            t.manual_seed(3)
+            sample = prob.sample(10, reparam=False)
+            strat = alan.Split("plate_1", 60, shard=True)
+            eager = float(sample.elbo_nograd(strat, graph=False))
+            alone = float(sample.elbo_nograd(alan.Split("plate_1", 60), graph=False))
+            pipe = sample.pipeline(strat, lanes=2, results=64)
+            vals = pipe.run(12).cpu()
+            vals2 = pipe.run(5).cpu()
+            t.cuda.synchronize()
+            dist.barrier()
+            bad = [ex.status()[1] for ex in S._EXCHANGES.values()]
+            res.update(eager=eager, alone=alone, vals=vals.tolist() + vals2.tolist(), bad=max(bad), n_exchanges=len(S._EXCHANGES))
+            pipe.close()
         dist.barrier()
         S.close_exchanges()
         t.save(res, f"{out_path}.{rank}")

@@ -61,6 +61,19 @@ def test_sharded_split_through_the_one_shot_exchange(spin_ms, monkeypatch):
     assert res[0]["one_shot"] == res[1]["one_shot"]
 
 
+@pytest.mark.gpu
+def test_sharded_evaluations_pipelined_with_an_exchange_per_lane():
+    """A sharded movielens evaluation (two ranks, the one-shot exchange as its collective) through sample.EvalPipeline with
+    two lanes: every lane has an exchange of its own (three in all with the eager one), all seventeen results on both ranks
+    equal the eager sharded value -- which equals one rank evaluating every chunk alone -- and nothing timed out."""
+    res = _run(2, "pipeline")
+    for r in res:
+        assert r["bad"] == 0 and r["n_exchanges"] == 3, r
+        assert len(r["vals"]) == 17 and all(abs(v - r["eager"]) <= 2e-6 * abs(r["eager"]) for v in r["vals"]), r
+        assert abs(r["eager"] - r["alone"]) <= 2e-6 * abs(r["alone"]), r
+    assert res[0]["vals"] == res[1]["vals"]
+
+
 def test_exchange_refuses_bad_arguments_without_a_gpu():
     """The entry points validate before touching the device (they are exported and bound: test_native_abi)."""
     import ctypes as C
