@@ -266,7 +266,7 @@ def pmc_traffic(name, key):
     --pmc runs as MI355X_MICROARCH.md prescribes: profiles/<name>).  Counters cannot be read from inside this process;
     null when the committed profile does not cover this configuration."""
     try:
-        for cand in (name.replace("r2_", "r3_"), name):
+        for cand in (name.replace("r2_", "r4_"), name.replace("r2_", "r3_"), name):
             p = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(p):
                 return json.load(open(p))[key]["traffic_bytes"]
@@ -277,7 +277,7 @@ def pmc_traffic(name, key):
 
 def fused_pmc_traffic(K, backward=False):
     """The same for the fused plate step at the S-ML sizes profiles/r3_fused_kernel_pmc.json covers (M=300, K=30 / 100)."""
-    for name in ("r3_fused_kernel_pmc.json", "r2_fused_kernel_pmc.json"):
+    for name in ("r4_fused_kernel_pmc.json", "r3_fused_kernel_pmc.json", "r2_fused_kernel_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
             want = 4 * M_USERS * K ** 3
