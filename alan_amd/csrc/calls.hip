@@ -71,8 +71,9 @@ struct Pipeline {
     std::condition_variable cv;
 };
 
-// An issuing thread: lanes w, w + T, ...  It spins for a short while after its last launch (a submit that follows at once
-// -- a loop of evaluations -- finds it awake), then sleeps on the condition variable: an idle pipeline costs no CPU.
+// An issuing thread: lanes w, w + T, ...  It spins for a few milliseconds after its last launch (a submit that follows soon
+// -- a loop of evaluations with some host work between the batches -- finds it awake: a thread woken from the condition
+// variable starts ~100 us late, a third of a 20-evaluation batch), then sleeps: an idle pipeline costs no CPU.
 static void worker(Pipeline *p, int w) {
     (void)hipSetDevice(p->device);
     auto last = std::chrono::steady_clock::now();
@@ -91,7 +92,7 @@ static void worker(Pipeline *p, int w) {
             last = std::chrono::steady_clock::now();
             continue;
         }
-        if (std::chrono::steady_clock::now() - last < std::chrono::microseconds(400)) {
+        if (std::chrono::steady_clock::now() - last < std::chrono::microseconds(3000)) {
             __builtin_ia32_pause();
             continue;
         }
