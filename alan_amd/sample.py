@@ -129,6 +129,26 @@ class _GraphedELBO:
         return slot.detach()
 
 
+_LIVE_PIPELINES = None      # weak set of the pipelines whose issuing threads are running (stopped at interpreter exit)
+
+
+def _track_pipeline(p):
+    global _LIVE_PIPELINES
+    if _LIVE_PIPELINES is None:
+        import atexit
+        import weakref
+        _LIVE_PIPELINES = weakref.WeakSet()
+
+        def _stop_all():
+            for q in list(_LIVE_PIPELINES):
+                try:
+                    q.close()
+                except Exception:
+                    pass
+        atexit.register(_stop_all)      # (the library's threads must be joined before the HIP runtime is torn down)
+    _LIVE_PIPELINES.add(p)
+
+
 class EvalPipeline:
     """INDEPENDENT evaluations of one sample's ELBO, overlapped (include/alan_mi355.h: alan_pipeline_*).  The reference's
     loop evaluates one ELBO after another (basic_runner.py:81-112; logpq.py:68-155 per evaluation); one evaluation is a
@@ -189,6 +209,7 @@ class EvalPipeline:
         N.check(N.lib().alan_pipeline_create(handles, lanes, lanes if threads is None else int(threads), C.byref(h)),
                 "alan_pipeline_create")
         self._h = h
+        _track_pipeline(self)
         self.total = 0          # evaluations submitted so far
         self.first = 0          # ... before the batch whose results are due
 
