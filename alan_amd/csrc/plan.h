@@ -2,6 +2,7 @@
 // coalescing, merge contiguous dims) and pick a kernel + launch geometry.
 #pragma once
 #include <cstring>
+#include <utility>
 
 #include "common.h"
 
@@ -183,14 +184,22 @@ inline uint32_t fill_small_multi(SmallMultiT<NP> &m, const SmallDesc *sd, const 
     std::memset(&m, 0, sizeof(m));
     m.n = n;
     if (lin) m.lin = *lin;
+    // Problems of ONE workgroup first: they are chains of dependent latencies (4 us alone) that should start with the
+    // launch, not behind the hundreds of workgroups of the big problems (heaviest FIRST was measured: 9.3 us against 8.0).
+    int order[SMALL_MULTI];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto weight = [&](int i) { return gl[i].grid <= 2 ? 0 : 1; };
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && weight(order[j]) < weight(order[j - 1]); --j) std::swap(order[j], order[j - 1]);
     uint32_t blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        m.mode[i] = mode[i];
-        m.logG[i] = gl[i].logG;
-        m.block[i] = gl[i].block ? 1 : 0;
-        m.first_block[i] = blocks;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        m.mode[k] = mode[i];
+        m.logG[k] = gl[i].logG;
+        m.block[k] = gl[i].block ? 1 : 0;
+        m.first_block[k] = blocks;
         blocks += gl[i].grid;
-        m.d[i] = sd[i];
+        m.d[k] = sd[i];
     }
     m.first_block[n] = blocks;
     return blocks;
