@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256) void normal_lse_mfma_kernel(const NLDesc d) {
     if (RAG && wave_on && lane < 16 && s16 < NS) d.part[((int64_t)blockIdx.y * d.NL + l) * NS + s16] = accm[NU - 1];
 }
 
-template <int EQ, int NST, int NLW, bool FLAT>
+template <int EQ, int NST, int NLW, bool FLAT, bool TBL = false>
 __global__ __launch_bounds__(256, 2) void normal_lse_x3_kernel(const X3Desc d) {
-    normal_lse_x3_body<EQ, NST, NLW, FLAT>(d, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+    normal_lse_x3_body<EQ, NST, NLW, FLAT, TBL>(d, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 }  // namespace alan
@@ -456,8 +456,7 @@ int plan_nl(const alan_normal_lse_desc_t &a, NLPlan &p) {
     if (a.E > 32 || a.NK > 4096 || a.NS > 4096 || a.NL > (1 << 20) || a.M > (1 << 24)) return ALAN_ERR_UNSUPPORTED;
     // a wave per (loc row, group of up to 4 tiles of 32 scale rows), 4 per workgroup; the plate in chunks so that the
     // chip holds every wave at once (3 per SIMD)
-    const int need = (int)(a.E + 2) / 2;
-    p.eh = need <= 4 ? 4 : need <= 8 ? 8 : need <= 10 ? 10 : need <= 12 ? 12 : 17;
+    p.eh = nl_eq_for((int)a.E);
     const int64_t nst_total = (a.NS + 31) / 32;
     p.nst = nst_total >= 4 ? 4 : nst_total >= 2 ? 2 : 1;
     const int64_t nsg = (nst_total + p.nst - 1) / p.nst;
@@ -537,6 +536,8 @@ int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o) {
     X3Desc &x = o.x;
     std::memset(&x, 0, sizeof(x));
     x.val = (const float *)a.value, x.loc = (const float *)a.loc, x.scl = (const float *)a.scale;
+    o.tbl = a.scale_table != nullptr && p.nst == 1;                 // (a table the kernel cannot use is ignored: scale is there)
+    x.tbl = o.tbl ? (const u32x4v *)a.scale_table : nullptr;
     x.part = (float *)part, x.lse = (float *)a.lse_out;
     x.M = (int)a.M, x.NK = (int)a.NK, x.NL = (int)a.NL, x.NS = (int)a.NS, x.E = (int)a.E, x.n_sub = 4 * p.n_chunks;
     x.n_small = a.n_small, x.log_scale = a.log_scale;
@@ -548,6 +549,7 @@ int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o) {
         x.small_sk[f] = used ? (int32_t)a.small_sk[f] : 0;
     }
     x.nkt = (x.NK + 31) / 32, x.nlg = (x.NL + p.nlw - 1) / p.nlw;
+    x.m_q = x.M / x.n_sub, x.m_r = x.M % x.n_sub;
     x.rcp_e = (65536u + (uint32_t)x.E - 1) / (uint32_t)x.E;
     o.gx = p.grid.x, o.gy = p.grid.y, o.gz = p.grid.z;
     o.eq = p.eh, o.nst = p.nst, o.nlw = p.nlw, o.flat = flat, o.n_chunks = p.n_chunks;
@@ -574,6 +576,13 @@ extern "C" size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *
     return (p.part_bytes + 255) & ~(size_t)255;
 }
 
+extern "C" size_t alan_normal_lse_table_bytes(const alan_normal_lse_desc_t *a) {
+    if (!a) return 0;
+    NLPlan p;
+    if (plan_nl(*a, p) != ALAN_OK || !p.x3 || p.nst != 1) return 0;
+    return nl_table_bytes_for(p.eh);
+}
+
 extern "C" int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *a) {
     if (!a) return 0;
     NLPlan p;
@@ -589,6 +598,7 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
     int rc = plan_nl(*a, p);
     if (rc != ALAN_OK) return rc;
     const bool keep = a->keep_partials != 0;
+    if ((uintptr_t)a->scale_table & 15) return ALAN_ERR_BAD_DESC;
     if (!keep && (!workspace || workspace_bytes < p.part_bytes)) return ALAN_ERR_WORKSPACE;
     NLDesc d;
     std::memset(&d, 0, sizeof(d));
@@ -642,6 +652,9 @@ extern "C" int alan_normal_lse(const alan_normal_lse_desc_t *a, void *workspace,
                                   : launch_x3(normal_lse_x3_kernel<EQV, 4, 1, false>, EQV, 4, 1))                      \
              : p.nst == 2 ? (flat ? launch_x3(normal_lse_x3_kernel<EQV, 2, 1, true>, EQV, 2, 1)                        \
                                   : launch_x3(normal_lse_x3_kernel<EQV, 2, 1, false>, EQV, 2, 1))                      \
+             : xp.tbl ? (p.nlw == 2 ? launch_x3(normal_lse_x3_kernel<EQV, 1, 2, false, true>, EQV, 1, 2)               \
+                                    : (flat ? launch_x3(normal_lse_x3_kernel<EQV, 1, 1, true, true>, EQV, 1, 1)        \
+                                            : launch_x3(normal_lse_x3_kernel<EQV, 1, 1, false, true>, EQV, 1, 1)))     \
              : p.nlw == 2 ? launch_x3(normal_lse_x3_kernel<EQV, 1, 2, false>, EQV, 1, 2)                               \
                           : (flat ? launch_x3(normal_lse_x3_kernel<EQV, 1, 1, true>, EQV, 1, 1)                        \
                                   : launch_x3(normal_lse_x3_kernel<EQV, 1, 1, false>, EQV, 1, 1));                     \

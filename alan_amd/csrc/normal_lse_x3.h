@@ -2,13 +2,12 @@
 // gfx950 only.
 #pragma once
 #include "common.h"
+#include "normal_lse_table.h"
 
 namespace alan {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530942f;
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same tile on the bf16 matrix instructions with 3-way split operands (the default since round 3).
@@ -25,43 +24,14 @@ constexpr float NL_LOG2E = 1.44269504088896340736f, NL_LN2 = 0.69314718055994530
 //     A: (ah, ah) (am, ah) (al, am)        B: (bh, bm) (bh, bl) (bh, bm)        [low half, high half]
 // and lane half h takes the events 2 q + h; MFMA step t consumes registers 4 t .. 4 t + 3 of both.  B is split once per
 // workgroup into an LDS table (NST tiles x NSTEP steps x 64 lanes x 16 bytes, read with one ds_read_b128 per step; in
-// registers when the wave has one scale tile); A costs 9 VALU per element and tile of 32 rows and is shared by the
+// registers when the wave has one scale tile -- and then loaded READY-MADE when the caller had it built ahead of the launch:
+// normal_lse_table.h, template argument TBL); A costs 9 VALU per element and tile of 32 rows and is shared by the
 // wave's NST scale tiles.  Rows beyond NK and -inf small factors carry NL_BIG (finite: inf - inf would poison the split)
 // in the small-factor slot: 2^(min - NL_BIG log2e) = 0, and a column whose rows are ALL masked ends with a minimum
 // >= 1e29, which is reported as the NaN utils.py:219 gives.
 typedef short bf16x8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 constexpr float NL_BIG = 1e30f;
-
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-// (lo, hi) -> one register of two bf16, round-to-nearest-even: v_cvt_pk_bf16_f32.  A vector cast, not inline asm: the
-// compiler pads the wait states between a vector instruction's result and a matrix instruction that reads it as A or
-// B only when it knows what wrote the register -- behind an asm the MFMA read a stale operand (seen: the first tile
-// of a pipelined chain wrong, the later tiles, which reuse the same A registers, right).
-__device__ __forceinline__ unsigned nl_cvt_pk(float lo, float hi) {
-    const f32x2v v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));
-}
-__device__ __forceinline__ void nl_split_a(float x, unsigned &r1, unsigned &r2, unsigned &r3) {
-    r1 = nl_cvt_pk(x, x);                                         // (h, h)
-    const float hf = __uint_as_float(r1 & 0xffff0000u);
-    const float e1 = x - hf;
-    r2 = nl_cvt_pk(e1, hf);                                       // (m, h)
-    const float mf = __uint_as_float(r2 << 16);
-    const float e2 = e1 - mf;
-    r3 = nl_cvt_pk(e2, e1);                                       // (l, m)
-}
-__device__ __forceinline__ void nl_split_b(float x, unsigned &r1, unsigned &r2, unsigned &r3) {
-    const unsigned hh = nl_cvt_pk(x, x);
-    const float hf = __uint_as_float(hh & 0xffff0000u);
-    const float e1 = x - hf;
-    const unsigned mm = nl_cvt_pk(e1, e1);
-    const float mf = __uint_as_float(mm & 0xffff0000u);
-    const unsigned ll = nl_cvt_pk(e1 - mf, e1 - mf);
-    r1 = (hh & 0xffffu) | (mm & 0xffff0000u);                     // (h, m)
-    r2 = (hh & 0xffffu) | (ll & 0xffff0000u);                     // (h, l)
-    r3 = r1;                                                      // (h, m)
-}
 
 // Diagnostic build (make TIMELINE=1 -> tools/_build/libalan_timeline.so; tools/nlse_timeline.py): every wave stamps
 // s_memtime at the phases of its life and stores them, with s_memrealtime of its start and its hardware id, into a
@@ -80,12 +50,14 @@ __device__ unsigned long long nl_timeline[NL_TL_WAVES * NL_TL_SLOTS];
 // every offset fits 31 bits and no stride is negative.
 struct X3Desc {
     const float *val, *loc, *scl;
+    const u32x4v *tbl;                // the scale table built ahead of the launch (TBL kernels; normal_lse_table.h)
     float *part, *lse;
     const float *small[4];
     int32_t M, NK, NL, NS, E, n_sub, n_small, log_scale;   // n_sub: the plate in this many slices, four per workgroup
     int32_t v_sm, l_sl, l_se, s_ss, s_se;
     int32_t small_sm[4], small_sk[4];
     int32_t nkt, nlg;                 // k tiles per plate element; groups of NLW loc rows
+    int32_t m_q, m_r;                 // M = n_sub m_q + m_r: slice c = m_q (+ 1 where c < m_r) plate elements
     uint32_t rcp_e;                   // ceil(2^16 / E): floor(f / E) = (f * rcp_e) >> 16 for f < 2048
 };
 
@@ -94,7 +66,7 @@ struct X3Prep {
     X3Desc x;
     uint32_t gx, gy, gz;              // (scale-tile groups, loc-row groups, groups of four plate slices)
     int eq, nst, nlw, n_chunks;
-    bool flat;
+    bool flat, tbl;
     size_t lds;
 };
 int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o);
@@ -102,12 +74,13 @@ int nl_x3_prepare(const alan_normal_lse_desc_t &a, void *part, X3Prep &o);
 // EQ: events per lane half incl. the small-factor slot (2 EQ >= E + 1).  Grid: x = group of NST scale tiles, y = group
 // of NLW loc rows, z = group of four slices of the plate, one per wave: the waves of a workgroup share the B table and
 // the loc rows and add up their partial sums through LDS, so a launch leaves gridDim.z partial results per output (34
-// at K = 30 where the first build left 150) for the consumer to add.  Slice c = plate elements [c M / n_sub,
-// (c + 1) M / n_sub).  The value tile is staged as in the f32 kernel (STAGE): contiguous rows only.
-template <int EQ, int NST, int NLW, bool FLAT>
+// at K = 30 where the first build left 150) for the consumer to add.  Slice c: M / n_sub plate elements, one more
+// in the first M % n_sub slices.  The value tile is staged as in the f32 kernel (STAGE): contiguous rows only.
+template <int EQ, int NST, int NLW, bool FLAT, bool TBL = false>
 __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx, const int by, const int bz, const int gx,
                                                    const int gy) {
     static_assert(!FLAT || NLW == 1, "flat row tiling: one loc row per wave");
+    static_assert(!TBL || NST == 1, "a ready-made scale table: one scale tile per wave");
     constexpr int NSTEP = (3 * EQ + 3) / 4, NV = 4 * NSTEP;
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -136,7 +109,15 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
     // ... of its lane's (scale row, half) in every scale tile.
     constexpr int NQI = (EQ + 3) / 4;
     float xs[NST][NQI];
-    {
+    u32x4v breg[NSTEP];                               // B of the unit about to be multiplied (one scale tile: for good)
+    float lgn[NST];
+    auto load_table = [&]() {
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) breg[step] = d.tbl[step * 64 + lane];
+        lgn[0] = reinterpret_cast<const float *>(d.tbl + NSTEP * 64)[j];
+        asm volatile("" ::: "memory");
+    };
+    if constexpr (!TBL) {
         const int joff = j * d.s_ss, hoff = h ? d.s_se : 0, last_s = (NS - 1) * d.s_ss, last_e = (E - 1) * d.s_se;
 #pragma unroll
         for (int st = 0; st < NST; ++st)
@@ -153,7 +134,10 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
 #pragma unroll
     for (int lw = 0; lw < NLW; ++lw)
         lrow[lw] = d.loc[(uint32_t)(min(l + lw, d.NL - 1) * d.l_sl + min(lane, E - 1) * d.l_se)];
-    const int m0 = (int)((int64_t)min(sub, d.n_sub) * d.M / d.n_sub), m1 = (int)((int64_t)min(sub + 1, d.n_sub) * d.M / d.n_sub);
+    // (the longer slices first: a workgroup's four waves then have equally many, bar one workgroup, and the workgroups with the
+    // most work are dispatched first.  c M / n_sub as the boundary cost two 64-bit divisions -- ~200 dependent scalar
+    // instructions, 0.4 us -- in front of the first value-tile load)
+    const int m0 = sub * d.m_q + min(sub, d.m_r), m1 = m0 + d.m_q + (sub < d.m_r ? 1 : 0);
     const int rows_total = (m1 - m0) * NK;
     const int n_tiles = FLAT ? (rows_total + 31) >> 5 : (m1 - m0) * nkt;
     // the value tile: 32 rows of E floats are one contiguous run; lane i takes floats i, i + 64, ... of it (buffer loads:
@@ -207,13 +191,17 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         small_flat(hs);
     };
     float zc[NX], zn[NX], hc[4], hn[4];
-    if (n_tiles > 0) {
-        if (FLAT) {
-            load_flat(0, zc, hc);
-        } else {
-            load_tile(m0, 0, zc, hc);
-        }
+    if (FLAT) {
+        if (n_tiles > 0) load_flat(0, zc, hc);
+    } else {
+        // (unconditional -- an empty slice reads a valid tile nobody uses: behind a branch the compiler waits for the loads
+        // inside it, in front of ~100 instructions of set-up that should run while they are in flight)
+        load_tile(min(m0, d.M - 1), 0, zc, hc);
     }
+    // (ready-made: requested LAST -- it is needed last, behind the first unit's A operand, and its 8 KB per wave keep the
+    // CU's load path busy for hundreds of cycles that the loc rows and the value tile would otherwise queue behind: 7.84 us
+    // against 7.97 requested first)
+    if constexpr (TBL) load_table();
     // ---- the workgroup's B table: thread (wave w, lane) takes the event pairs w, w + 4, ... of its lane's (scale row,
     // half) in every scale tile; every load of a thread is issued before the first is used.  The log-normaliser
     // sum_e log(scale[s, e]) is collected on the way as per-(wave, lane) partial sums, added up in a fixed order behind
@@ -230,6 +218,7 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         for (int lw = 0; lw < NLW; ++lw)
             if (lane < 36) locl[lw * 36 + lane] = lane < E ? lrow[lw] : 0.f;
         // (the value tile's rows beyond the run are written every tile: the buffer loads read them as 0)
+        if constexpr (!TBL) {
         const bool lsc = d.log_scale != 0;
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
@@ -239,15 +228,8 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
             for (int qi = 0; qi < NQI; ++qi) {
                 const int q = wave + 4 * qi;                                                           // (scalar)
                 if (4 * qi + 3 < EQ || q < EQ) {
-                    const float x = xs[st][qi];
-                    const bool ev = s_ok && 2 * q + h < E;
-                    // log2(e) / (2 sigma^2); from log(sigma) = x: 2^(-2 log2(e) x) log2(e) / 2
-                    const float w = lsc ? __builtin_amdgcn_exp2f(-2.f * NL_LOG2E * x) * (0.5f * NL_LOG2E)
-                                        : (0.5f * NL_LOG2E) * __builtin_amdgcn_rcpf(x * x);
-                    const float bval = ev ? w : (s_ok && q == EQ - 1 && h == slot_h) ? NL_LOG2E : 0.f;
-                    lgp += ev ? (lsc ? x : __builtin_amdgcn_logf(x) * NL_LN2) : 0.f;
                     unsigned r[3];
-                    nl_split_b(bval, r[0], r[1], r[2]);
+                    nl_b_entry(xs[st][qi], lsc, s_ok && 2 * q + h < E, s_ok && q == EQ - 1 && h == slot_h, r, lgp);
                     // registers 3 q .. 3 q + 2 of the lane's operand: dword (3 q + i) & 3 of step (3 q + i) >> 2
                     const int v0 = 3 * q;
 #pragma unroll
@@ -264,21 +246,27 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
                 for (int v = 3 * EQ; v < NV; ++v)
                     if ((st * (NV - 3 * EQ) + v) % 4 == wave) bw[((st * NSTEP + (v >> 2)) * 64 + lane) * 4 + (v & 3)] = 0u;
         }
+        }
     }
     NL_STAMP(1);
-    __syncthreads();
-    NL_STAMP(2);
-    float lgn[NST];
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        float lg = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) lg += lgp_l[(st * 4 + w) * 64 + j] + lgp_l[(st * 4 + w) * 64 + 32 + j];
-        lgn[st] = lg + (float)E * 0.91893853320467274178f;
+    if constexpr (TBL) {                              // (the loc rows in LDS are the wave's own: no workgroup barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
     }
-    u32x4v breg[NSTEP];                               // B of the unit about to be multiplied (one scale tile: for good)
+    NL_STAMP(2);
+    if constexpr (!TBL) {
 #pragma unroll
-    for (int step = 0; step < NSTEP; ++step) breg[step] = bt[step * 64 + lane];
+        for (int st = 0; st < NST; ++st) {
+            float lg = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) lg += lgp_l[(st * 4 + w) * 64 + j] + lgp_l[(st * 4 + w) * 64 + 32 + j];
+            lgn[st] = lg + (float)E * NL_HALF_LOG_2PI;
+        }
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) breg[step] = bt[step * 64 + lane];
+    }
     float mreg[NLW][EQ];
 #pragma unroll
     for (int lw = 0; lw < NLW; ++lw)
@@ -334,12 +322,20 @@ __device__ __forceinline__ void normal_lse_x3_body(const X3Desc &d, const int bx
         // the LDS table behind them (one unit ahead: the reads land during a whole log-sum-exp).
         unsigned areg[NV];
         auto build_a = [&](int lw) {
+            // two events at a time on the packed f32 instructions (v_pk_add / v_pk_mul: two lanes' worth per issue slot; the
+            // loop is bound by vector issue): 7 instructions per element where one at a time takes 9
 #pragma unroll
-            for (int q = 0; q < EQ; ++q) {
-                const float df = zv[q] - mreg[lw][q];
-                float a = df * df;
-                if (q == EQ - 1) a = h == slot_h ? slot : a;
-                nl_split_a(a, areg[3 * q], areg[3 * q + 1], areg[3 * q + 2]);
+            for (int q = 0; q + 1 < EQ; q += 2) {
+                const f32x2v z2 = {zv[q], zv[q + 1]}, m2 = {mreg[lw][q], mreg[lw][q + 1]};
+                const f32x2v df = z2 - m2;
+                f32x2v a = df * df;
+                if (q + 1 == EQ - 1) a[1] = h == slot_h ? slot : a[1];
+                nl_split_a2(a, &areg[3 * q], &areg[3 * q + 3]);
+            }
+            if (EQ & 1) {
+                const float df = zv[EQ - 1] - mreg[lw][EQ - 1];
+                const float a = h == slot_h ? slot : df * df;
+                nl_split_a(a, areg[3 * EQ - 3], areg[3 * EQ - 2], areg[3 * EQ - 1]);
             }
 #pragma unroll
             for (int v = 3 * EQ; v < NV; ++v) areg[v] = 0u;

@@ -89,8 +89,12 @@ struct LinDesc {
 template <int NP>
 struct SmallMultiT {
     int32_t n;
-    int32_t mode[NP], logG[NP], block[NP];
-    uint32_t first_block[NP + 1];
+    uint32_t first_block[NP];    // of problem k; 0xffffffff beyond the last: a workgroup finds its problem from ONE fetch of these
+                                 // (a loop over them was a dependent scalar load per problem in front of everything else)
+    struct Head {
+        int32_t mode, logG, block;
+        uint32_t first_block;
+    } head[NP];                  // fetched with the problem's descriptor
     SmallDesc d[NP];
     LinDesc lin;                 // of the (at most one) ALAN_MODE_BERNOULLI_LINEAR problem
     NoiseLaunch noise;
@@ -194,14 +198,14 @@ inline uint32_t fill_small_multi(SmallMultiT<NP> &m, const SmallDesc *sd, const 
     uint32_t blocks = 0;
     for (int k = 0; k < n; ++k) {
         const int i = order[k];
-        m.mode[k] = mode[i];
-        m.logG[k] = gl[i].logG;
-        m.block[k] = gl[i].block ? 1 : 0;
-        m.first_block[k] = blocks;
+        m.head[k].mode = mode[i];
+        m.head[k].logG = gl[i].logG;
+        m.head[k].block = gl[i].block ? 1 : 0;
+        m.head[k].first_block = m.first_block[k] = blocks;
         blocks += gl[i].grid;
         m.d[k] = sd[i];
     }
-    m.first_block[n] = blocks;
+    for (int k = n; k < NP; ++k) m.first_block[k] = 0xffffffffu;
     return blocks;
 }
 int launch_lin(const LinDesc &ld, const GroupLaunch &gl, hipStream_t stream, const EvPair &ev);

@@ -595,7 +595,40 @@ static bool small_plate_prepare(const alan_reduce_desc_t &d, SmallPlateDesc &sd,
     return true;
 }
 
+// ALAN_MODE_NORMAL_TABLE: one workgroup of the small-problem launch (normal_lse_table.h).  Not a reduction: the descriptor
+// only names the scale rows (one KEEP dim) and the event (one REDUCE dim) of the single factor.
+static int table_prepare(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl) {
+    if (d.ndim < 0 || d.ndim > MAXD || d.n_factors != 1 || !d.factor[0].data || !d.out.data) return ALAN_ERR_BAD_DESC;
+    if (d.weight.data || d.lse_out.data || d.ring_n || d.noise.on || d.ev_start || d.ev_stop) return ALAN_ERR_BAD_DESC;
+    if (d.factor[0].dtype != ALAN_F32 || d.out.dtype != ALAN_F32) return ALAN_ERR_UNSUPPORTED;
+    if ((uintptr_t)d.out.data & 15) return ALAN_ERR_BAD_DESC;
+    int64_t ns = 1, e = 1, s_ss = 0, s_se = 0;
+    int nkd = 0, nrd = 0;
+    for (int i = 0; i < d.ndim; ++i) {
+        if (d.size[i] < 1) return ALAN_ERR_BAD_DESC;
+        if (d.size[i] == 1) continue;
+        if (d.role[i] == ALAN_KEEP) ns = d.size[i], s_ss = d.factor[0].stride[i], ++nkd;
+        else if (d.role[i] == ALAN_REDUCE) e = d.size[i], s_se = d.factor[0].stride[i], ++nrd;
+        else return ALAN_ERR_BAD_DESC;
+    }
+    if (nkd > 1 || nrd > 1) return ALAN_ERR_BAD_DESC;
+    if (ns > 32 || e > 32 || s_ss < 0 || s_se < 0 || ns * s_ss + e * s_se >= (1ll << 31)) return ALAN_ERR_UNSUPPORTED;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.f[0] = (const float *)d.factor[0].data;
+    sd.out = (float *)d.out.data;
+    sd.n_out = (uint32_t)ns, sd.n_red = (uint32_t)e, sd.nf = 1;
+    sd.fks[0][SMALL_NK - 1] = (int32_t)s_ss, sd.frs[0][SMALL_NR - 1] = (int32_t)s_se;
+    sd.fscale[0] = d.factor[0].scale;
+    gl = GroupLaunch();
+    gl.grid = 1;
+    return ALAN_OK;
+}
+
 static bool prepare_small(const alan_reduce_desc_t &d, SmallDesc &sd, GroupLaunch &gl, int &mode) {
+    if (d.mode == ALAN_MODE_NORMAL_TABLE) {
+        mode = d.mode;
+        return table_prepare(d, sd, gl) == ALAN_OK;
+    }
     uint32_t keep, red, plate;
     if (classify(d, keep, red, plate) != ALAN_OK || plate || d.ev_start || d.ev_stop) return false;
     if (peel_dim(d, keep, red, plate) >= 0) return false;
@@ -800,6 +833,11 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
         if (p == -2) return ALAN_ERR_BAD_DESC;
         if (p >= 0) return run_presum(d2, n, stride, nullptr, true);
     }
+    if (d->mode == ALAN_MODE_NORMAL_TABLE) {
+        SmallDesc sd;
+        GroupLaunch gl;
+        return table_prepare(*d, sd, gl);
+    }
     if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) {
         LinDesc ld;
         GroupLaunch gl;
@@ -819,7 +857,8 @@ extern "C" int alan_reduce_check(const alan_reduce_desc_t *d) {
 
 extern "C" size_t alan_reduce_workspace_bytes(const alan_reduce_desc_t *d) {
     if (!d) return 0;
-    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) return 0;
+    if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD || d->mode == ALAN_MODE_NORMAL_TABLE)
+        return 0;
     uint32_t keep, red, plate;
     if (classify(*d, keep, red, plate) != ALAN_OK) return 0;
     {
@@ -863,6 +902,14 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
         const int p = strip_presum(*d, d2, n, stride);
         if (p == -2) return ALAN_ERR_BAD_DESC;
         if (p >= 0) return run_presum(d2, n, stride, stream, false);
+    }
+    if (d->mode == ALAN_MODE_NORMAL_TABLE) {
+        SmallDesc sd;
+        GroupLaunch gl;
+        const int rc = table_prepare(*d, sd, gl);
+        if (rc != ALAN_OK) return rc;
+        const int mode = ALAN_MODE_NORMAL_TABLE;
+        return launch_small_multi(&sd, &gl, &mode, 1, stream, nullptr, nullptr, false);
     }
     if (d->mode == ALAN_MODE_BERNOULLI_LINEAR || d->mode == ALAN_MODE_BERNOULLI_LINEAR_GRAD) {
         LinDesc ld;
@@ -1012,5 +1059,5 @@ extern "C" int alan_reduce(const alan_reduce_desc_t *d, void *workspace, size_t 
     return run_single(s2, keep, plate, ALAN_MODE_SUM, d->out, d->add_const, stream);
 }
 
-extern "C" int alan_abi_version(void) { return 13; }
+extern "C" int alan_abi_version(void) { return 14; }
 extern "C" const char *alan_build_target(void) { return "gfx950"; }

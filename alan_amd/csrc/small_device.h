@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "plan.h"
+#include "normal_lse_table.h"
 
 namespace alan {
 
@@ -450,12 +451,15 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
     typedef __attribute__((address_space(4))) const char *kernarg_ptr;
     const char *base = (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + arg_off);
     const SmallMulti &m = *reinterpret_cast<const SmallMulti *>(base);
-    int p = 0;
-    while (p + 1 < m.n && vb >= m.first_block[p + 1]) ++p;                // workgroup-uniform
-    const uint32_t bid = vb - m.first_block[p];
+    int p = 0;                                                            // workgroup-uniform
+#pragma unroll
+    for (int i = 1; i < NP; ++i) p += vb >= m.first_block[i] ? 1 : 0;     // (constant offsets: one wide scalar load, no branch)
+    const typename SmallMulti::Head &hd =
+        *reinterpret_cast<const typename SmallMulti::Head *>(base + offsetof(SmallMulti, head) + (size_t)p * sizeof(typename SmallMulti::Head));
+    const uint32_t bid = vb - hd.first_block;
     const SmallDesc &d = *reinterpret_cast<const SmallDesc *>(base + offsetof(SmallMulti, d) + (size_t)p * sizeof(SmallDesc));
-    const bool block = m.block[p] != 0;
-    const int logG = m.logG[p];
+    const bool block = hd.block != 0;
+    const int logG = hd.logG;
     const NoiseLaunch &nz = *reinterpret_cast<const NoiseLaunch *>(base + offsetof(SmallMulti, noise));
     // (the cell: {counter, seed}, written by the previous launch that drew -- read past the scalar and vector L1 caches)
     uint64_t cellv = 0ull, nseed = nz.seed;
@@ -463,7 +467,7 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         cellv = __hip_atomic_load(nz.cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         nseed = __hip_atomic_load(nz.cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    switch (m.mode[p]) {
+    switch (hd.mode) {
         case ALAN_MODE_LSE: small_either<ALAN_MODE_LSE>(d, logG, block, bid); break;
         case ALAN_MODE_SUM: small_either<ALAN_MODE_SUM>(d, logG, block, bid); break;
         case ALAN_MODE_NORMAL: small_either<ALAN_MODE_NORMAL>(d, logG, block, bid); break;
@@ -481,6 +485,10 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
                 lin_body<false>(ld, logG, bid);
             break;
         }
+        case ALAN_MODE_NORMAL_TABLE:                  // (one workgroup: table_prepare, plan.hip)
+            nl_table_block(d.f[0], d.fks[0][SMALL_NK - 1], d.frs[0][SMALL_NR - 1], (int)d.n_out, (int)d.n_red, d.fscale[0] == 2.f,
+                           reinterpret_cast<unsigned *>(d.out));
+            break;
         default: break;
     }
     if (nz.receipt || nz.advance) noise_finish(nz, cellv, nseed);

@@ -564,6 +564,31 @@ def _normal_lse_desc(a, log_scale, d=None):
     return d
 
 
+SCALE_TABLE = True      # the plate step's scale table built by the producers' launch when there is one (ALAN_MODE_NORMAL_TABLE)
+
+
+def _ride_scale_table(a, d, log_scale, device):
+    """With producers queued for the launch in front of this plate step (a gradient-free evaluation), one more problem joins
+    them: the step's matrix operand built from ``scale`` (alan_normal_lse_desc_t.scale_table) -- its waves then load it instead
+    of building it behind a workgroup barrier.  Same bits either way.  -> the table (kept alive by the caller) or None."""
+    import ctypes as C
+    nbytes = int(N.lib().alan_normal_lse_table_bytes(C.byref(d)))
+    if nbytes == 0 or N.n_pending() == 0:
+        return None
+    xs = a["xs"]
+    table = t.empty(nbytes, dtype=t.uint8, device=device)
+    rd = N.ReduceDesc()
+    rd.mode, rd.ndim, rd.n_factors = N.MODE_NORMAL_TABLE, 2, 1
+    rd.size[0], rd.size[1] = xs.shape[0], xs.shape[1]
+    rd.role[0], rd.role[1] = N.KEEP, N.REDUCE
+    N.fill_tensor(rd.factor[0], xs, (xs.stride(0), xs.stride(1)), 2.0 if log_scale else 1.0)
+    rd.out.data, rd.out.dtype, rd.out.scale = table.data_ptr(), N.dtype_code(t.float32), 1.0
+    if not N.ride_along(rd, device, keepalive=(xs, table)):
+        return None
+    d.scale_table = table.data_ptr()
+    return table
+
+
 def _normal_lse_forward(a, log_scale, want_lse, partials=False):
     """One alan_normal_lse launch.  -> (out [NL, NS], lse [M, NL, NS] or None), or None when the library declines.
     ``partials``: out is [slices, NL, NS], the launch's partial sums left for the consumer to add (keep_partials)."""
@@ -582,7 +607,8 @@ def _normal_lse_forward(a, log_scale, want_lse, partials=False):
         d.out, d.o_sl, d.o_ss, d.add_const = out.data_ptr(), out.stride(0), out.stride(1), 0.0
     lse = _empty([d.M, d.NL, d.NS], t.float32, device) if want_lse else None
     d.lse_out = lse.data_ptr() if want_lse else None
-    if not N.run_normal_lse(d, device, keepalive=(a, out, lse)):
+    table = _ride_scale_table(a, d, log_scale, device) if SCALE_TABLE else None
+    if not N.run_normal_lse(d, device, keepalive=(a, out, lse, table)):
         return None
     if a["wide"]:
         N.flush()                                        # (the conversion below reads the launch's output)
@@ -668,9 +694,10 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False, partials=Fa
     partial sums, for a consumer that adds them on load (dims.PartialSumPT)."""
     tensors = [value[0], loc[0], scale[0], *[x for x, _ in smalls]]
     recording = t.is_grad_enabled() and any(x.requires_grad for x in tensors)
-    if recording or not partials or any(x.dtype != t.float32 for x in tensors):
-        N.flush()      # consumers read what queued producer launches write (native.deferring)
-    # (else the queued producers may ride in this launch's prelude, native.run_normal_lse: nothing below reads a tensor)
+    if recording or any(x.dtype != t.float32 for x in tensors):
+        N.flush()      # torch ops below (autograd's bookkeeping, a dtype conversion) read what queued producer launches write
+    # (else the queue stays as it is until native.run_normal_lse issues it in front of this launch -- nothing below reads a
+    # tensor -- and the step's scale table can still join it: _ride_scale_table)
     a = _normal_lse_args(value, loc, scale, smalls, plate, K)
     if a is None:
         N.flush()

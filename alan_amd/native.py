@@ -21,6 +21,7 @@ MODE_PRODUCER_GRAD = 6
 MODE_BERNOULLI_LINEAR = 7
 MODE_DOT = 8
 MODE_BERNOULLI_LINEAR_GRAD = 9
+MODE_NORMAL_TABLE = 11
 MODE_AFFINE = 10
 MODE_FUSED_FWD, MODE_FUSED_BWD = 100, 101      # (KernelTimer record tags of alan_normal_lse / _backward; not library modes)
 GRAD_VALUE, GRAD_LOC, GRAD_SCALE, GRAD_LOGITS = 1.0, 2.0, 3.0, 4.0      # factor[0].scale of a MODE_PRODUCER_GRAD call
@@ -99,7 +100,8 @@ class NormalLseDesc(C.Structure):
                 ("M", C.c_int64), ("NK", C.c_int64), ("NL", C.c_int64), ("NS", C.c_int64), ("E", C.c_int64),
                 ("out", C.c_void_p), ("o_sl", C.c_int64), ("o_ss", C.c_int64),
                 ("lse_out", C.c_void_p), ("add_const", C.c_double),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("keep_partials", C.c_int32)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("keep_partials", C.c_int32),
+                ("scale_table", C.c_void_p)]
 
 
 class NormalLseBackwardDesc(C.Structure):
@@ -150,6 +152,8 @@ def lib():
         L.alan_normal_lse.argtypes = [C.POINTER(NormalLseDesc), C.c_void_p, C.c_size_t, C.c_void_p]
         L.alan_normal_lse_workspace_bytes.restype = C.c_size_t
         L.alan_normal_lse_workspace_bytes.argtypes = [C.POINTER(NormalLseDesc)]
+        L.alan_normal_lse_table_bytes.restype = C.c_size_t
+        L.alan_normal_lse_table_bytes.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_normal_lse_n_partials.restype = C.c_int64
         L.alan_normal_lse_n_partials.argtypes = [C.POINTER(NormalLseDesc)]
         L.alan_normal_lse_backward.restype = C.c_int
@@ -222,7 +226,7 @@ def lib():
 
 EXPORTS = ("alan_reduce", "alan_reduce_check", "alan_reduce_workspace_bytes", "alan_reduce_batch", "alan_reduce_backward",
            "alan_reduce_backward_workspace_bytes", "alan_normal_lse", "alan_normal_lse_workspace_bytes",
-           "alan_normal_lse_n_partials", "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
+           "alan_normal_lse_n_partials", "alan_normal_lse_table_bytes", "alan_normal_lse_backward", "alan_normal_lse_backward_workspace_bytes",
            "alan_chain_batched_workspace_bytes", "alan_chain_logmmexp_batched", "alan_chain_logmmexp_terms_final",
            "alan_chain_backward_batched_workspace_bytes", "alan_chain_logmmexp_backward_batched",
            "alan_chain_messages", "alan_chain_sample", "alan_chain_filter",
@@ -276,7 +280,8 @@ _REC = [None]            # the CallList being recorded (sample._GraphedELBO sets
 _TRACE = [None]          # a list collecting what an evaluation did (Sample.explain): launches and model-lambda routes
 
 _MODE_NAMES = {0: "LSE", 1: "SUM", 2: "WEXPSUM", 3: "NORMAL", 4: "BERNOULLI", 5: "NORMAL_LOGSCALE", 6: "PRODUCER_GRAD",
-               7: "BERNOULLI_LINEAR", 8: "DOT", 9: "BERNOULLI_LINEAR_GRAD", 10: "AFFINE"}
+               7: "BERNOULLI_LINEAR", 8: "DOT", 9: "BERNOULLI_LINEAR_GRAD", 10: "AFFINE",
+               11: "NORMAL_TABLE (the scale table of the fused plate step that follows)"}
 
 
 def trace(kind, what, **info):
@@ -616,6 +621,17 @@ def may_defer():
         _Q.depth[1] -= 1
 
 
+def ride_along(desc, device, keepalive=()):
+    """A small problem nobody asked to wait for (the scale table of a fused plate step): it joins the queued launches if
+    there are any -- one more workgroup of a launch that goes out anyway -- and is NOT launched otherwise (False)."""
+    if not (_Q.depth[0] and _Q.pending and _Q.pending[0][1] == device and _TIMER[0] is None and not t.is_grad_enabled()):
+        return False
+    if desc.noise.on or lib().alan_reduce_check(C.byref(desc)) != 0:
+        return False
+    _Q.pending.append((desc, device, keepalive))
+    return True
+
+
 def flush():
     """Issue every queued launch now (in order)."""
     if _Q.chain is not None:
@@ -739,7 +755,8 @@ def run_normal_lse(desc, device, keepalive=()):
     check(rc, "alan_normal_lse")
     trace("launch", "alan_normal_lse (fused plate step: Normal producer + log-sum-exp + plate sum, the factor never written)",
           M=int(desc.M), K_child=int(desc.NK), loc_rows=int(desc.NL), scale_rows=int(desc.NS), event=int(desc.E),
-          small_factors=int(desc.n_small), partial_slices_kept=bool(desc.keep_partials))
+          small_factors=int(desc.n_small), partial_slices_kept=bool(desc.keep_partials),
+          scale_table_prebuilt=bool(desc.scale_table))
     if _REC[0] is not None:
         _REC[0].keep.append(ws)
         _REC[0].record(L.alan_normal_lse, C.byref(desc), ws.data_ptr() if ws is not None else None, nbytes, None)

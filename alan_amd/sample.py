@@ -465,8 +465,9 @@ class Sample:
         # (the captured launches depend on the routing switches: a graph captured under other settings is not reused)
         from . import logpq as LP
         from . import split as SP
+        from . import engine as E
         return (strategy_key(computation_strategy), D.FUSE_NORMAL, D.FUSE_PLATE_STEP, D.LAMBDA_BACKEND,
-                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, N.CHAIN_FINAL, SP.ONE_SHOT_EXCHANGE)
+                N.DEFER_SMALL_LAUNCHES, LP.PARTIAL_PLATE_SUMS, N.CHAIN_FINAL, SP.ONE_SHOT_EXCHANGE, E.SCALE_TABLE)
 
     def _graphed(self, computation_strategy):
         key = self._graph_key(computation_strategy)

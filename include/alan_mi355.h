@@ -110,6 +110,12 @@ typedef enum {
                               x = loc + eps * scale of a td.Normal (TorchDimDist.py:88-125 d.rsample; Param.py:18-25 the
                               exp transformation of an OptParam scale) written straight in the sample's layout; several
                               variables' draws join one alan_reduce_batch launch.  Exactly 3 factors. */
+    ALAN_MODE_NORMAL_TABLE = 11, /* not a reduction: builds the scale table of a fused plate step (alan_normal_lse_desc_t.
+                              scale_table) from its scale argument -- one KEEP dim (the scale rows, <= 32) and one REDUCE
+                              dim (the event, <= 32), ONE fp32 factor = scale, or log(scale) where factor_0.scale == 2
+                              (as g in ALAN_MODE_AFFINE); out.data = the table (alan_normal_lse_table_bytes bytes, 16-byte
+                              aligned, layout the library's own; out's strides are not read).  A problem like any other
+                              small one for alan_reduce_batch: it rides in the launch of the plate step's producers. */
     ALAN_MODE_BERNOULLI_LINEAR_GRAD = 9  /* backward of ALAN_MODE_BERNOULLI_LINEAR with respect to the FIRST operand `a`
                               of its FIRST dot term (movielens: z of `z @ x`) -- what autograd derives from the lambda's
                               batched matmul and TorchDimDist.py:127-162.  The forward's factors and roles unchanged;
@@ -252,8 +258,16 @@ typedef struct {
                                                           sums, [alan_normal_lse_n_partials(desc), NL, NS] fp32
                                                           contiguous (o_sl, o_ss, add_const not used), for a consumer
                                                           that adds them itself (alan_reduce, role ALAN_PRESUM) */
+    const void *scale_table;                           /* optional: what an ALAN_MODE_NORMAL_TABLE problem built from THIS
+                                                          scale / log_scale earlier on the stream (the waves then load
+                                                          their matrix operand instead of building it behind a barrier:
+                                                          about 1 us of a 9.5 us launch at K = 30); same bits either way;
+                                                          ignored where alan_normal_lse_table_bytes is 0, and by the
+                                                          backward */
 } alan_normal_lse_desc_t;
 size_t alan_normal_lse_workspace_bytes(const alan_normal_lse_desc_t *desc);
+/* Size of the scale table this call can use (0: it cannot -- more than 32 scale rows, or a shape the library declines). */
+size_t alan_normal_lse_table_bytes(const alan_normal_lse_desc_t *desc);
 /* How many partial results per output a keep_partials call leaves (0: the library declines the shape). */
 int64_t alan_normal_lse_n_partials(const alan_normal_lse_desc_t *desc);
 int alan_normal_lse(const alan_normal_lse_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);

@@ -334,3 +334,88 @@ def test_fp64_small_factor_exact_switch_routes_around_the_fp32_kernel(monkeypatc
     want = t.logsumexp(F.double() + small[0][:, None, None, :], -1).sum(0)
     t.testing.assert_close(exact, want, rtol=1e-12, atol=1e-10)
     t.testing.assert_close(fused, want, rtol=1e-6, atol=1e-5)
+
+
+def _table_launches(z, mu, sc, smalls, log_scale, with_table):
+    """alan_normal_lse through the C ABI, its scale table built by an ALAN_MODE_NORMAL_TABLE problem first (or not at all)."""
+    import ctypes as C
+    from alan_amd import native as N
+    L = N.lib()
+    M, NK, Ev = z.shape
+    a = dict(xv=z, xl=mu, xs=sc, ip=0, smalls=[(x, x.stride(0), x.stride(1)) for x in smalls])
+    d = E._normal_lse_desc(a, log_scale)
+    out = t.empty(mu.shape[0], sc.shape[0], device=DEV)
+    d.out, d.o_sl, d.o_ss = out.data_ptr(), out.stride(0), out.stride(1)
+    nb = L.alan_normal_lse_workspace_bytes(C.byref(d))
+    assert nb > 0
+    ws = t.empty(nb, dtype=t.uint8, device=DEV)
+    table = None
+    if with_table:
+        tb = L.alan_normal_lse_table_bytes(C.byref(d))
+        if tb == 0:
+            return None
+        table = t.full((tb,), 0xAB, dtype=t.uint8, device=DEV)
+        r = N.ReduceDesc()
+        r.mode, r.ndim, r.n_factors = N.MODE_NORMAL_TABLE, 2, 1
+        r.size[0], r.size[1], r.role[0], r.role[1] = sc.shape[0], sc.shape[1], N.KEEP, N.REDUCE
+        N.fill_tensor(r.factor[0], sc, (sc.stride(0), sc.stride(1)), 2.0 if log_scale else 1.0)
+        r.out.data, r.out.dtype, r.out.scale = table.data_ptr(), N.F32, 1.0
+        N.check(L.alan_reduce(C.byref(r), None, 0, N.current_stream(z.device)), "alan_reduce(NORMAL_TABLE)")
+        d.scale_table = table.data_ptr()
+    N.check(L.alan_normal_lse(C.byref(d), ws.data_ptr(), nb, N.current_stream(z.device)), "alan_normal_lse")
+    t.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("M,NK,NL,NS,Ev,n_small,log_scale", [
+    (300, 30, 30, 30, 18, 2, False), (37, 30, 30, 30, 18, 2, True), (7, 5, 4, 3, 3, 0, False), (9, 32, 31, 32, 19, 1, False),
+    (5, 7, 13, 20, 8, 0, True), (3, 30, 2, 9, 23, 1, True), (6, 25, 12, 31, 32, 2, False), (13, 31, 1, 1, 14, 1, True),
+    (5, 8, 40, 31, 1, 3, True), (2, 130, 2, 5, 31, 0, True), (3, 64, 2, 32, 32, 4, False), (4, 40, 3, 24, 18, 1, False),
+    (600, 30, 30, 30, 18, 2, False)])
+def test_a_prebuilt_scale_table_gives_the_same_bits(M, NK, NL, NS, Ev, n_small, log_scale):
+    """alan_normal_lse_desc_t.scale_table (ABI 14): the matrix operand built ahead of the launch by an
+    ALAN_MODE_NORMAL_TABLE problem -- every event bucket, one / two loc rows per wave, row-tiled and flat plates, scale rows
+    strided -- against the same launch building it itself: bit for bit."""
+    g = t.Generator().manual_seed(7 * M + NK + NS)
+    z = t.randn(M, NK, Ev, generator=g).to(DEV)
+    mu = t.randn(NL, Ev, generator=g).to(DEV)
+    raw = (0.3 * t.randn(NS, 2 * Ev, generator=g)).to(DEV)[:, ::2]                     # (event stride 2)
+    sc = raw if log_scale else raw.exp()
+    smalls = [t.randn(M, NK, generator=g).to(DEV) for _ in range(n_small)]
+    own = _table_launches(z, mu, sc, smalls, log_scale, False)
+    pre = _table_launches(z, mu, sc, smalls, log_scale, True)
+    assert pre is not None
+    assert t.equal(own, pre)
+    assert t.isfinite(own).all()
+
+
+def test_a_scale_table_is_declined_beyond_one_tile_of_scale_rows():
+    g = t.Generator().manual_seed(1)
+    z, mu, sc = t.randn(4, 16, 9, generator=g).to(DEV), t.randn(5, 9, generator=g).to(DEV), t.rand(33, 9, generator=g).to(DEV) + 0.5
+    assert _table_launches(z, mu, sc, [], False, True) is None
+
+
+def test_movielens_evaluation_builds_the_scale_table_in_the_producers_launch(monkeypatch):
+    """A gradient-free evaluation: the table problem rides in the producers' multi-problem launch (no launch of its own), the
+    plate step reports it, and the ELBO has the bits of an evaluation without it -- eagerly and replayed."""
+    fx = load_golden("e2e_movielens_K10.pt")
+    fx = dict(fx, data={k: (v[0].float(), v[1]) for k, v in fx["data"].items()})
+    prob = models.BUILDERS["movielens"](fx).to(DEV)
+    sample = prob.sample(10, reparam=False)         # (the library's own layout: the fixture's [K, plate, event] goes to the f32 kernel)
+    monkeypatch.setattr(E, "SCALE_TABLE", False)
+    rep0 = sample.explain(alan.no_checkpoint, as_text=False)
+    base = float(sample.elbo_nograd(alan.no_checkpoint))
+    monkeypatch.setattr(E, "SCALE_TABLE", True)
+    rep1 = sample.explain(alan.no_checkpoint, as_text=False)
+    with_table = float(sample.elbo_nograd(alan.no_checkpoint))
+    assert with_table == base
+    l0 = [x for x in rep0["launches"]]
+    l1 = [x for x in rep1["launches"]]
+    assert len(l0) == len(l1)                                                   # no launch more
+    step0 = [x for x in l0 if x["what"].startswith("alan_normal_lse")]
+    step1 = [x for x in l1 if x["what"].startswith("alan_normal_lse")]
+    assert len(step1) == 1 and step1[0]["scale_table_prebuilt"] and not step0[0]["scale_table_prebuilt"]
+    batch = [x for x in l1 if x["what"].startswith("alan_reduce_batch")][0]
+    assert any(p["mode"].startswith("NORMAL_TABLE") for p in batch["problems"])
+    replay = [float(sample.elbo_nograd(alan.no_checkpoint, graph=True)) for _ in range(3)]
+    assert replay[0] == replay[1] == replay[2] and abs(replay[0] - base) <= 1e-6 * abs(base)

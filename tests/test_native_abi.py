@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(N.EXPORTS)
     for s in syms:
         assert getattr(L, s) is not None
-    assert L.alan_abi_version() == 13
+    assert L.alan_abi_version() == 14
     assert L.alan_build_target() == b"gfx950"
 
 
@@ -71,7 +71,7 @@ def test_backward_rejects_bad_descriptors_and_declines_unsuitable_shapes():
 def test_fused_plate_step_struct_layout_and_rejections():
     """alan_normal_lse_desc_t / alan_normal_lse_backward_desc_t as the header lays them out (natural alignment), and
     malformed descriptors refused before any GPU work."""
-    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8   # (keep_partials + padding)
+    fwd = 8 + 3 * 8 + 8 + 2 * 8 + 8 + 2 * 8 + 4 + 4 + 4 * 8 + 4 * 8 + 4 * 8 + 5 * 8 + 8 + 2 * 8 + 8 + 8 + 2 * 8 + 8 + 8   # (keep_partials + padding, scale_table)
     assert ctypes.sizeof(N.NormalLseDesc) == fwd
     assert ctypes.sizeof(N.NormalLseBackwardDesc) == fwd + 8 + 8 + 2 * 8 + 4 * 8
     L = N.lib()
@@ -96,6 +96,29 @@ def test_fused_plate_step_struct_layout_and_rejections():
     assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 16, None) == -3         # workspace too small
     b.fwd.n_small = 5
     assert L.alan_normal_lse_backward(ctypes.byref(b), dummy, 1 << 20, None) == -1    # too many small factors
+    # the scale table (ABI 14): sized for one tile of scale rows, 0 beyond; a misaligned one is refused; the problem that
+    # builds it is checked like any other
+    assert L.alan_normal_lse_table_bytes(None) == 0
+    d.v_sm, d.v_sk, d.v_se, d.l_sl, d.l_se, d.s_ss, d.s_se = 5 * 18, 18, 1, 18, 1, 18, 1
+    assert L.alan_normal_lse_table_bytes(ctypes.byref(d)) == 8 * 64 * 16 + 32 * 4    # E = 18: ten event pairs, eight MFMA steps
+    d.NS = 33
+    assert L.alan_normal_lse_table_bytes(ctypes.byref(d)) == 0
+    d.NS = 3
+    d.scale_table = ctypes.c_void_p(0x1004)
+    assert L.alan_normal_lse(ctypes.byref(d), dummy, 1 << 20, None) == -1
+    r = N.ReduceDesc()
+    r.mode, r.ndim, r.n_factors = N.MODE_NORMAL_TABLE, 2, 1
+    r.size[0], r.size[1], r.role[0], r.role[1] = 3, 18, N.KEEP, N.REDUCE
+    r.factor[0].data, r.factor[0].dtype, r.factor[0].scale = dummy, N.F32, 1.0
+    r.factor[0].stride[0], r.factor[0].stride[1] = 18, 1
+    assert L.alan_reduce_check(ctypes.byref(r)) == -1                                 # no table to write
+    r.out.data, r.out.dtype = dummy, N.F32
+    assert L.alan_reduce_check(ctypes.byref(r)) == 0
+    assert L.alan_reduce_workspace_bytes(ctypes.byref(r)) == 0
+    r.size[0] = 33
+    assert L.alan_reduce_check(ctypes.byref(r)) == N.ERR_UNSUPPORTED
+    r.size[0], r.role[1] = 3, N.PLATE
+    assert L.alan_reduce_check(ctypes.byref(r)) == -1
 
 
 def test_bad_descriptors_are_rejected_without_touching_the_gpu():
