@@ -1437,6 +1437,294 @@ __global__ __launch_bounds__(NT) void chain_pair_backward_mfma_kernel(
     }
 }
 
+// The whole backward in ONE launch (round 4; T = 1000: ten launches of 12 us at K = 30, of 53 us at K = 100 -- a launch per
+// round of the tree, every node of a round waiting for the slowest of the round above).  A workgroup per node of the tree,
+// the root first: a node needs its parent's result only for the second half of its work, so it stages its pair, takes the
+// maxima and the exponentials and multiplies Pe @ Ce at once -- every node of the tree does that side by side -- and then
+// waits for the gradient its parent leaves in memory.  No flags: a launch in front of this one fills the workspace with a
+// NaN of a payload no arithmetic produces (BWD_UNSET); the parent stores its result element by element with agent-scope
+// relaxed atomics (past the non-coherent caches; release / acquire FENCES write back and invalidate a whole L2 per
+// workgroup here: 181 us for the T = 1000, K = 30 tree against 123 with a launch per round) and the child reads until an
+// element is no longer BWD_UNSET -- one thread watches the first element, then every thread checks its own.  What is
+// left on the path from the root to the leaves is, per round: one store-to-load hand-over, a division, two products.
+// Progress: workgroups start in the order of their index on each XCD (round-robin over the XCDs) and a node's parent has a
+// lower index, so the lowest-indexed unfinished node always holds a slot and never waits for anyone behind it; should that
+// ever fail, a wait gives up after `timeout` ticks of the 100 MHz clock and the element counts as NaN (nothing hangs;
+// every gradient below it is NaN).
+constexpr uint32_t BWD_UNSET = 0x7fedcba9u;
+constexpr int BWD_MAX_LEVELS = 32;
+struct BwdLevel {
+    const float *src;                 // the round's inputs: [B][n_src] matrices with strides (cB, cT, cR, cC)
+    const float *G;                   // upstream gradients [B][n_nodes][K][K]; nullptr at the root
+    float *dsrc;                      // [B][n_src][K][K]
+    int64_t cB, cT, cR, cC;
+    int32_t n_src, n_nodes, leaf, pad_;   // leaf: dsrc is the caller's grad_ms (nobody in this launch reads it)
+};
+struct BwdTree {
+    uint32_t first[BWD_MAX_LEVELS];   // first workgroup of level l (0 = the root's round); 0xffffffff beyond the last
+    BwdLevel lv[BWD_MAX_LEVELS];
+    uint32_t total, timeout;
+    int32_t K, pad_;
+    const float *root;
+    int64_t rB, rRow, rCol;
+    const float *vec, *grad_vec, *grad_chain;
+};
+
+__global__ __launch_bounds__(256) void chain_unset_kernel(uint4 *ws, uint32_t n16) {
+    const uint4 u = {BWD_UNSET, BWD_UNSET, BWD_UNSET, BWD_UNSET};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) ws[i] = u;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void chain_tree_backward_kernel(const BwdTree a) {
+    typedef float T;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int K = a.K, KS = K | 1;
+    T *Pe = reinterpret_cast<T *>(smem_raw);
+    T *Ce = Pe + (size_t)K * KS;
+    T *Gp = Ce + (size_t)K * KS;
+    T *pm = Gp + (size_t)K * KS, *cm = pm + K, *pw = cm + K, *cw = pw + K, *pn = cw + K, *cn = pn + K;    // (pn, cn: ties)
+    const int tid = threadIdx.x, KK = K * K, lane = tid & 63, wave = tid >> 6;
+    const uint32_t vb = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    int li = 0;                                           // (workgroup-uniform; constant offsets: wide scalar loads, no branch)
+#pragma unroll
+    for (int i = 1; i < BWD_MAX_LEVELS; ++i) li += vb >= a.first[i] ? 1 : 0;
+    typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+    const char *base = (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr());
+    const BwdLevel &lv = *reinterpret_cast<const BwdLevel *>(base + offsetof(BwdTree, lv) + (size_t)li * sizeof(BwdLevel));
+    const uint32_t first_here = *reinterpret_cast<const uint32_t *>(base + offsetof(BwdTree, first) + (size_t)li * 4);
+    const int node = (int)(vb - first_here), n_src = lv.n_src;
+    const int t0 = 2 * node, t1 = t0 + 1;
+    const T NINF = Num<T>::ninf();
+    const T *Gn = lv.G ? lv.G + (b * lv.n_nodes + node) * (int64_t)KK : nullptr;
+    T *dP = lv.dsrc + (b * n_src + t0) * (int64_t)KK;
+    T *dC = dP + KK;
+    const bool pair = t1 < n_src;
+    auto upstream_root = [&](int i, int j) -> T {
+        T g = a.grad_chain ? a.grad_chain[(b * K + i) * K + j] : T(0);
+        if (a.grad_vec) {
+            const T v = a.vec[b * K + i];
+            if (v != NINF) g += a.grad_vec[b * K + i] * Num<T>::exp_acc(a.root[b * a.rB + i * a.rRow + j * a.rCol] - v);
+        }
+        return g;
+    };
+    // what a node hands to its children: agent-scope relaxed atomics, element by element (the leaves' output: plain stores)
+    const bool leaf_out = lv.leaf != 0;
+    auto put = [&](T *p, T v) {
+        if (leaf_out)
+            *p = v;
+        else
+            __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // the parent's gradient: one thread watches its first element (a node's elements arrive within a microsecond of each other;
+    // hundreds of waiting workgroups polling all of theirs would flood the fabric) ...
+    auto wait_parent = [&]() {
+        if (Gn && tid == 0) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            while (__float_as_uint(__hip_atomic_load(Gn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == BWD_UNSET) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t_start > a.timeout) break;
+            }
+        }
+        __syncthreads();
+    };
+    // ... then every thread reads its own until they are there
+    auto get = [&](const T *p) {
+        T v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__float_as_uint(v) == BWD_UNSET) {
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            do {
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while (__float_as_uint(v) == BWD_UNSET && __builtin_amdgcn_s_memrealtime() - t_start <= a.timeout);
+            if (__float_as_uint(v) == BWD_UNSET) v = __builtin_nanf("");
+        }
+        return v;
+    };
+    const float invK = 1.f / (float)K;
+    auto row_of = [&](int e) {
+        int i = (int)((float)e * invK);
+        i -= (i * K > e) ? 1 : 0;
+        i += ((i + 1) * K <= e) ? 1 : 0;
+        return i;
+    };
+    if (!pair) {                                          // leftover of this round (utils.py:488-495): the gradient passes through
+        wait_parent();
+        for (int e = tid; e < KK; e += NT) put(dP + e, Gn ? get(Gn + e) : upstream_root(row_of(e), e - row_of(e) * K));
+        return;
+    }
+    const T *Pg = lv.src + b * lv.cB + (int64_t)t0 * lv.cT, *Cg = lv.src + b * lv.cB + (int64_t)t1 * lv.cT;
+    const int64_t sRow = lv.cR, sCol = lv.cC;
+    // ---- before the parent is needed: the pair staged, maxima, exponentials, Pe @ Ce + eps (left in Gp)
+    constexpr int CH = 8;
+    for (int e0 = tid; e0 < KK; e0 += NT * CH) {
+        T pv[CH], cv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (e0 - tid + NT * u >= KK) {     // (uniform: a whole round beyond the matrices)
+                pv[u] = cv[u] = T(0);
+                continue;
+            }
+            const int e = min(e0 + NT * u, KK - 1), i = row_of(e), j = e - i * K;
+            pv[u] = Pg[i * sRow + j * sCol];
+            cv[u] = Cg[i * sRow + j * sCol];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int e = e0 + NT * u;
+            if (e < KK) {
+                const int i = row_of(e), j = e - i * K;
+                Pe[i * KS + j] = pv[u], Ce[i * KS + j] = cv[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int rc = tid; rc < 2 * K; rc += NT) {
+        const bool is_row = rc < K;
+        const int idx = is_row ? rc : rc - K;
+        const T *p0 = is_row ? Pe + idx * KS : Ce + idx;
+        const int st = is_row ? 1 : KS;
+        T m0 = NINF, m1 = NINF, m2 = NINF, m3 = NINF;
+        int x = 0;
+        for (; x + 4 <= K; x += 4) {
+            m0 = fmaxf(m0, p0[x * st]), m1 = fmaxf(m1, p0[(x + 1) * st]);
+            m2 = fmaxf(m2, p0[(x + 2) * st]), m3 = fmaxf(m3, p0[(x + 3) * st]);
+        }
+        for (; x < K; ++x) m0 = fmaxf(m0, p0[x * st]);
+        (is_row ? pm : cm)[idx] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    }
+    __syncthreads();
+    for (int e = tid; e < KK; e += NT) {
+        const int i = row_of(e), j = e - i * K;
+        Pe[i * KS + j] = Num<T>::exp_acc(Pe[i * KS + j] - pm[i]);
+        Ce[i * KS + j] = Num<T>::exp_acc(Ce[i * KS + j] - cm[j]);
+    }
+    __syncthreads();
+    // rows of P / columns of C in four segments, a thread each (lanes 4 q .. 4 q + 3 of a wave: two shuffles add them up)
+    auto walk4 = [&](auto f) {
+        for (int q0 = 0; q0 < 2 * K; q0 += NT / 4) {      // (uniform trip count: the shuffles below need whole groups)
+            const int rc = q0 + (tid >> 2), seg = tid & 3;
+            const bool on = rc < 2 * K;
+            const bool is_row = rc < K;
+            const int idx = on ? (is_row ? rc : rc - K) : 0;
+            const int per = (K + 3) >> 2, x0 = seg * per, x1 = min(K, x0 + per);
+            float v = f(is_row, idx, x0, x1);
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (on && seg == 0) f(is_row, idx, v);
+        }
+    };
+    struct Ties {
+        const T *Pe, *Ce;
+        T *pn, *cn;
+        int KS;
+        __device__ float operator()(bool is_row, int idx, int x0, int x1) const {
+            const T *e0 = is_row ? Pe + idx * KS : Ce + idx;
+            const int st = is_row ? 1 : KS;
+            float n = 0.f;
+            for (int x = x0; x < x1; ++x) n += e0[x * st] == T(1) ? 1.f : 0.f;
+            return n;
+        }
+        __device__ void operator()(bool is_row, int idx, float v) const { (is_row ? pn : cn)[idx] = v; }
+    };
+    walk4(Ties{Pe, Ce, pn, cn, KS});
+    const int c = lane & 31, h = lane >> 5, nt = (K + 31) >> 5;
+    auto tile = [&](auto a_at, auto b_at, int i0, int j0) {
+        chain_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ra = min(i0 + c, K - 1), cb = min(j0 + c, K - 1);
+        const bool oka = i0 + c < K, okb = j0 + c < K;
+        constexpr int SU = 8;
+        for (int k0 = 0; k0 < K; k0 += 2 * SU) {
+            float av[SU], bv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int kk = k0 + 2 * u + h, k = min(kk, K - 1);
+                const bool okk = kk < K;                  // (selects, not products with 0: 0 x inf would be NaN)
+                av[u] = oka && okk ? a_at(ra, k) : 0.f;
+                bv[u] = okb && okk ? b_at(k, cb) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    for (int tk = wave; tk < nt * nt; tk += NT / 64) {
+        const int i0 = 32 * (tk / nt), j0 = 32 * (tk % nt);
+        const chain_f32x16 acc = tile([&](int i, int k) { return Pe[i * KS + k]; }, [&](int k, int j) { return Ce[k * KS + j]; }, i0, j0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = j0 + c;
+            if (i < K && j < K) Gp[i * KS + j] = acc[r] + Num<T>::eps;
+        }
+    }
+    // ---- the parent's gradient: G' = G / (Pe @ Ce + eps)
+    wait_parent();                                        // (its barrier also closes the products' writes to Gp)
+    for (int e0 = tid; e0 < KK; e0 += NT * CH) {
+        T gv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int e = min(e0 + NT * u, KK - 1);
+            gv[u] = Gn ? get(Gn + e) : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int e = e0 + NT * u;
+            if (e < KK) {
+                const int i = row_of(e), j = e - i * K;
+                Gp[i * KS + j] = (Gn ? gv[u] : upstream_root(i, j)) / Gp[i * KS + j];
+            }
+        }
+    }
+    __syncthreads();
+    if (a.pad_ == 1) {                                    // (diagnostic, ALAN_CHAIN_BWD_DEBUG=1: the hand-over alone, no products)
+        for (int e = tid; e < KK; e += NT) put(dP + e, Gp[row_of(e) * KS + e - row_of(e) * K]), put(dC + e, 1.f);
+        return;
+    }
+    // ---- the amax paths: eps * sum(G') shared among the maxima of a row of P / a column of C (their number: counted above)
+    struct Sums {
+        const T *Gp;
+        T *pw, *cw;
+        const T *pn, *cn;
+        int KS;
+        __device__ float operator()(bool is_row, int idx, int x0, int x1) const {
+            const T *g0 = is_row ? Gp + idx * KS : Gp + idx;
+            const int st = is_row ? 1 : KS;
+            float s = 0.f;
+            for (int x = x0; x < x1; ++x) s += g0[x * st];
+            return s;
+        }
+        __device__ void operator()(bool is_row, int idx, float v) const {
+            (is_row ? pw : cw)[idx] = Num<T>::eps * v / (is_row ? pn : cn)[idx];
+        }
+    };
+    walk4(Sums{Gp, pw, cw, pn, cn, KS});
+    __syncthreads();
+    // ---- dP = Pe * (G' @ Ce^T) and dC = Ce * (Pe^T @ G'): 2 nt^2 tiles dealt to the waves
+    for (int tk = wave; tk < 2 * nt * nt; tk += NT / 64) {
+        const bool second = tk >= nt * nt;
+        const int t2 = second ? tk - nt * nt : tk, i0 = 32 * (t2 / nt), j0 = 32 * (t2 % nt);
+        chain_f32x16 acc;
+        if (!second)        // dP[i, k] : A[i][j] = G'[i][j], B[j][k] = Ce[k][j]
+            acc = tile([&](int i, int j) { return Gp[i * KS + j]; }, [&](int j, int k) { return Ce[k * KS + j]; }, i0, j0);
+        else                // dC[k, j] : A[k][r] = Pe[r][k], B[r][j] = G'[r][j]
+            acc = tile([&](int k, int r) { return Pe[r * KS + k]; }, [&](int r, int j) { return Gp[r * KS + j]; }, i0, j0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h, j = j0 + c;
+            if (i < K && j < K) {
+                if (!second) {
+                    const T pe = Pe[i * KS + j];
+                    put(dP + i * K + j, pe * acc[r] + (pe == T(1) ? pw[i] : T(0)));
+                } else {
+                    const T ce = Ce[i * KS + j];
+                    put(dC + i * K + j, ce * acc[r] + (ce == T(1) ? cw[j] : T(0)));
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, int64_t sB, int64_t sT, int64_t sRow,
                               int64_t sCol, const void *tree, const void *out_vec, const void *grad_vec,
@@ -1451,7 +1739,7 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
     bool mfma = false;
     size_t smem_m = 0;
     if constexpr (sizeof(T) == 4) {
-        smem_m = (3 * (size_t)K * (size_t)(K | 1) + 4 * (size_t)K) * sizeof(float);
+        smem_m = (3 * (size_t)K * (size_t)(K | 1) + 6 * (size_t)K) * sizeof(float);
         mfma = bwd_mfma_knob != 0 && K >= 2 && smem_m <= 160 * 1024;
         if (mfma && smem_m > 64 * 1024 &&
             hipFuncSetAttribute((const void *)chain_pair_backward_mfma_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1462,6 +1750,49 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return ALAN_ERR_LAUNCH;
     const T *root = (const T *)((const char *)tree + tl.off[tl.L]);
+    if constexpr (sizeof(T) == 4) {
+        static const int tree_knob = env_knob("ALAN_CHAIN_BWD_TREE");                 // ablation knob: 0 = a launch per round
+        if (mfma && tree_knob != 0 && tl.L >= 2 && tl.L <= BWD_MAX_LEVELS) {
+            // one launch for the whole tree (chain_tree_backward_kernel) behind one that marks the workspace as not yet written
+            BwdTree a;
+            std::memset(&a, 0, sizeof(a));
+            uint32_t total = 0;
+            for (int li = 0; li < BWD_MAX_LEVELS; ++li) a.first[li] = 0xffffffffu;
+            for (int li = 0; li < tl.L; ++li) {
+                const int r = tl.L - li;
+                const bool top = r == tl.L, bottom = r == 1;
+                BwdLevel &lv = a.lv[li];
+                lv.src = bottom ? (const float *)ms : (const float *)((const char *)tree + tl.off[r - 1]);
+                lv.cB = bottom ? sB : tl.n[r - 1] * K * K, lv.cT = bottom ? sT : K * K, lv.cR = bottom ? sRow : K,
+                lv.cC = bottom ? sCol : 1;
+                lv.G = top ? nullptr : (const float *)((const char *)ws + tl.off[r]);
+                lv.dsrc = bottom ? (float *)grad_ms : (float *)((char *)ws + tl.off[r - 1]);
+                lv.n_src = (int32_t)tl.n[r - 1], lv.n_nodes = (int32_t)tl.n[r], lv.leaf = bottom ? 1 : 0;
+                a.first[li] = total;
+                total += (uint32_t)tl.n[r];
+            }
+            if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
+            a.total = total, a.timeout = 20000000u;                                    // 0.2 s of the 100 MHz clock
+            a.K = (int32_t)K;
+            static const int dbg_knob = env_knob("ALAN_CHAIN_BWD_DEBUG");
+            a.pad_ = dbg_knob == 1 ? 1 : 0;
+            a.root = (const float *)root, a.rB = K * K, a.rRow = K, a.rCol = 1;
+            a.vec = (const float *)out_vec, a.grad_vec = (const float *)grad_vec, a.grad_chain = (const float *)grad_chain;
+            const uint32_t n16 = (uint32_t)(tl.bytes / 16);                             // (rounds are 256-byte aligned)
+            ALAN_LAUNCH(chain_unset_kernel, dim3(std::min<uint32_t>((n16 + 255) / 256, 2048u)), dim3(256), 0, stream, (uint4 *)ws, n16);
+            if (hipGetLastError() != hipSuccess) return ALAN_ERR_LAUNCH;
+            if (K > 48) {
+                if (smem_m > 64 * 1024 &&
+                    hipFuncSetAttribute((const void *)chain_tree_backward_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)smem_m) != hipSuccess)
+                    return ALAN_ERR_LAUNCH;
+                ALAN_LAUNCH(chain_tree_backward_kernel<1024>, dim3(total, (uint32_t)B), dim3(1024), smem_m, stream, a);
+            } else {
+                ALAN_LAUNCH(chain_tree_backward_kernel<256>, dim3(total, (uint32_t)B), dim3(256), smem_m, stream, a);
+            }
+            return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
+        }
+    }
     for (int r = tl.L; r >= 1; --r) {
         const bool top = r == tl.L, bottom = r == 1;
         const T *src = bottom ? (const T *)ms : (const T *)((const char *)tree + tl.off[r - 1]);

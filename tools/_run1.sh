@@ -1,6 +1,6 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r4_tbl; rm -rf $O; mkdir -p $O
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/ml30 --output-format csv -- python3 tools/prof_case.py ml 30 200 > $O/ml30.log 2>&1 && f=$(find $O/ml30 -name '*kernel_stats.csv' | head -n 1) && if [ -n "$f" ]; then head -n 4 "$f" | cut -c1-160; fi
-timeout -k 10 200 python3 tools/pipeline_probe_short.py > $O/pipeline_short.txt 2>&1; echo "pp rc=$?"; tail -n 1 $O/pipeline_short.txt
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 5 $O/pytest.log
+O=gpurun_out/r4_chain; rm -rf $O; mkdir -p $O
+timeout -k 10 120 python3 tools/chain_bwd_probe.py 37 30 > $O/probe_small.txt 2>&1; echo "small rc=$?"; grep "T=" $O/probe_small.txt
+timeout -k 10 300 python3 tools/chain_bwd_probe.py 1000 30 100 > $O/probe.txt 2>&1; echo "probe rc=$?"; grep "T=" $O/probe.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_chain_batched.py tests/test_gpu_reduce.py tests/test_timeseries.py -m gpu -x -q -k "chain or timeseries" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 $O/pytest.log
