@@ -218,14 +218,17 @@ class EvalPipeline:
         from . import native as N
         if n > self.n_lanes * self.capacity - (self.total - self.first):
             raise ValueError(f"at most {self.n_lanes * self.capacity} evaluations between two results() calls")
-        if self.problem.memory_fingerprint() != self.fingerprint:
-            raise N.NativeError("alan_amd: the problem's tensors moved since this pipeline was built: build a new one")
         L = N.lib()
         self._sync_noise(int(n))
         stream = t.cuda.current_stream(self.problem.device).cuda_stream
         N.check(L.alan_pipeline_fence(self._h, stream), "alan_pipeline_fence")
         N.check(L.alan_pipeline_submit(self._h, int(n)), "alan_pipeline_submit")
         self.total += int(n)
+        # (checked while the library's threads are already launching: 10 us of host time off the front of every batch.  The
+        # recorded launches keep every tensor they were recorded over alive, so a batch submitted over moved tensors reads
+        # valid -- stale -- memory, and this raises before anyone can read its results)
+        if self.problem.memory_fingerprint() != self.fingerprint:
+            raise N.NativeError("alan_amd: the problem's tensors moved since this pipeline was built: build a new one")
 
     def _sync_noise(self, n):
         """Lanes that draw their own particles (GraphedEval captures): each lane's generator state lives on the device and

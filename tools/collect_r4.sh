@@ -25,7 +25,14 @@ bash tools/pipeline_trace.sh 30 300 4 4 600 > $O/pipeline_trace_30.txt 2>&1 || e
 timeout -k 10 300 python3 tools/pipeline_probe.py 30 300 3000 2>&1 | grep "K=" > $O/pipeline_30.txt || echo "pipeline probe failed"
 timeout -k 10 300 python3 tools/pipeline_configs_probe.py 2>&1 | grep "lane" > $O/pipeline_configs.txt || echo "pipeline configs probe failed"
 # the per-wave timeline of the fused plate step (diagnostic build: make -C alan_amd/csrc TIMELINE=1)
-if [ -f tools/_build/timeline/libalan_mi355.so ]; then timeout -k 10 100 python3 tools/nlse_timeline.py 300 30 18 > $O/timeline_k30.txt 2>&1 || echo "timeline K=30 failed"; fi
+if [ -f tools/_build/timeline/libalan_mi355.so ]; then
+  timeout -k 10 100 python3 tools/nlse_timeline.py 300 30 18 table > $O/timeline_k30.txt 2>&1 || echo "timeline K=30 failed"
+  timeout -k 10 100 python3 tools/nlse_timeline.py 300 30 18 > $O/timeline_k30_own_table.txt 2>&1 || echo "timeline K=30 (own table) failed"
+fi
+timeout -k 10 300 python3 tools/chain_bwd_probe.py 1000 30 100 2>&1 | grep "T=" > $O/chain_bwd.txt || echo "chain backward probe failed"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/producer_parts --output-format csv -- python3 tools/producer_parts_probe.py > $O/producer_parts.log 2>&1 || echo "producer parts probe failed"
+f=$(find $O/producer_parts -name '*kernel_stats.csv' | head -n 1); if [ -n "$f" ]; then cp "$f" $O/producer_parts_kernel_stats.csv; fi
+find $O/producer_parts -name "*kernel_trace.csv" -delete
 timeout -k 10 300 python3 tools/nlse_bwd_precision.py > $O/bwd_prec_x2.md 2>/dev/null || echo "backward precision probe failed"
 ALAN_NLB_X2=0 timeout -k 10 300 python3 tools/nlse_bwd_precision.py > $O/bwd_prec_f32.md 2>/dev/null || echo "backward precision probe (fp32) failed"
 find $O -name "*agent_info.csv" -delete; find $O -name "*domain_stats.csv" -delete

@@ -20,19 +20,9 @@ M, K, Ev = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (300, 30, 1
 TABLE = "table" in sys.argv[4:]           # the scale table built ahead of the launch (a launch of its own here; in an evaluation it
                                           # rides in the producers' launch): the kernel's TBL variant
 if TABLE:
-    def _table_now(a, d, log_scale, device):
-        nb = int(N.lib().alan_normal_lse_table_bytes(C.byref(d)))
-        xs = a["xs"]
-        table = t.empty(nb, dtype=t.uint8, device=device)
-        r = N.ReduceDesc()
-        r.mode, r.ndim, r.n_factors = N.MODE_NORMAL_TABLE, 2, 1
-        r.size[0], r.size[1], r.role[0], r.role[1] = xs.shape[0], xs.shape[1], N.KEEP, N.REDUCE
-        N.fill_tensor(r.factor[0], xs, (xs.stride(0), xs.stride(1)), 2.0 if log_scale else 1.0)
-        r.out.data, r.out.dtype, r.out.scale = table.data_ptr(), N.F32, 1.0
-        N.check(N.lib().alan_reduce(C.byref(r), None, 0, N.current_stream(device)), "alan_reduce(NORMAL_TABLE)")
-        d.scale_table = table.data_ptr()
-        return table
-    E._ride_scale_table = _table_now
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from _scale_table import force_scale_table
+    force_scale_table()
 g = t.Generator(device="cuda").manual_seed(0)
 pl, Kz, dl, ds = Dim("plate", M), Dim("K", K), Dim("Kl", K), Dim("Ks", K)
 z = t.randn(M, K, Ev, device="cuda", generator=g)

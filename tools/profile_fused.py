@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch as t
 from alan_amd import engine as E
 from alan_amd.dims import Dim
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _scale_table import force_scale_table
+force_scale_table()             # (the gradient-free launches: the kernel an evaluation runs, its scale table built ahead)
 
 for M, K, Ev, iters in ((300, 30, 18, 20), (300, 100, 18, 6)):
     g = t.Generator(device="cuda").manual_seed(0)

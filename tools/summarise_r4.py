@@ -91,7 +91,10 @@ for k in sorted(fetch, key=lambda k: (k[0], k[1])):
 json.dump(res, open(os.path.join(OUT, "r4_fused_kernel_pmc.json"), "w"), indent=1)
 open(os.path.join(OUT, "r4_fused_kernel_pmc.md"), "w").write("\n".join(md) + "\n")
 
-for src, dst, head in (("timeline_k30.txt", "r4_timeline_K30.txt", "# python3 tools/nlse_timeline.py 300 30 18 (diagnostic build, make TIMELINE=1): where a wave of the K=30 launch spends its life (round 4: the scale rows requested first)\n"),
+for src, dst, head in (("timeline_k30.txt", "r4_timeline_K30.txt", "# python3 tools/nlse_timeline.py 300 30 18 table (diagnostic build, make TIMELINE=1): where a wave of the K=30 launch spends its life -- the kernel an evaluation runs since ABI 14: its scale table built ahead of the launch, slices without 64-bit divisions, longer slices first\n"),
+                       ("timeline_k30_own_table.txt", "r4_timeline_K30_own_table.txt", "# python3 tools/nlse_timeline.py 300 30 18: the same launch building its scale table itself (what a training forward runs)\n"),
+                       ("chain_bwd.txt", "r4_chain_backward.txt", "# python3 tools/chain_bwd_probe.py 1000 30 100: the timeseries chain's backward, one launch for the tree (tree=1, default) against a launch per round (tree=0), HIP events around 50 back-to-back calls\n"),
+                       ("producer_parts_kernel_stats.csv", "r4_producer_parts_kernel_stats.csv", ""),
                        ("pipeline_trace_30.txt", "r4_pipeline_timeline_K30.txt", "# bash tools/pipeline_trace.sh 30 300 4 4 600: the GPU's timeline of pipelined movielens K=30 evaluations (rocprofv3 kernel trace; the profiler slows the host's launches, so the period is longer than unprofiled)\n"),
                        ("pipeline_30.txt", "r4_pipeline_probe_K30.txt", "# python3 tools/pipeline_probe.py 30 300 3000: throughput of sample.EvalPipeline by lanes and issuing threads\n"),
                        ("pipeline_configs.txt", "r4_pipeline_other_configs.txt", "# python3 tools/pipeline_configs_probe.py: sample() + elbo with fresh particles (SamplingPipeline), bus_breakdown and timeseries evaluations, pipelined\n")):
