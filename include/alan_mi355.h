@@ -315,7 +315,11 @@ int alan_normal_lse_backward(const alan_normal_lse_backward_desc_t *desc, void *
  * alan_chain_logmmexp_backward_batched: the gradient with respect to ms -- what autograd derives from utils.py:478-510
  * (+ logpq.py:139), INCLUDING the paths through the eps floor and through amax.  `tree` is the forward's workspace,
  * untouched since.  The upstream gradient is grad_vec [B, K] (of out_vec; then out_vec must be given) and / or grad_chain
- * [B, K, K] (of out_chain); both given = their sum.  grad_ms receives [B, T, K, K] contiguous. */
+ * [B, K, K] (of out_chain); both given = their sum.  grad_ms receives [B, T, K, K] contiguous.
+ * fp32, 2 <= rounds: TWO launches whatever T is -- one that marks the workspace as not yet written, one with a workgroup per
+ * node of the tree (ABI 14; a launch per round before: 122 -> 72 us at T = 1000, K = 30).  A node waits for its parent's
+ * gradient in memory for a BOUNDED time (0.2 s: it then yields NaN, as does everything below it -- never a hang); the
+ * launch relies on workgroups starting in index order, not on all of them being resident. */
 size_t alan_chain_batched_workspace_bytes(int64_t B, int64_t T, int64_t K, int32_t dtype);
 int alan_chain_logmmexp_batched(const void *ms, int32_t dtype, int64_t B, int64_t T, int64_t K,
                                 int64_t sB, int64_t sT, int64_t sRow, int64_t sCol,
