@@ -1664,14 +1664,15 @@ __global__ __launch_bounds__(NT) void chain_tree_backward_kernel(const BwdTree a
         T gv[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int e = min(e0 + NT * u, KK - 1);
-            gv[u] = Gn ? get(Gn + e) : T(0);
+            const int e = min(e0 + NT * u, KK - 1);       // (every load requested before the first is looked at)
+            gv[u] = Gn ? __hip_atomic_load(Gn + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : T(0);
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int e = e0 + NT * u;
             if (e < KK) {
                 const int i = row_of(e), j = e - i * K;
+                if (Gn && __float_as_uint(gv[u]) == BWD_UNSET) gv[u] = get(Gn + e);
                 Gp[i * KS + j] = (Gn ? gv[u] : upstream_root(i, j)) / Gp[i * KS + j];
             }
         }
