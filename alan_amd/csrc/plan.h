@@ -188,21 +188,53 @@ inline uint32_t fill_small_multi(SmallMultiT<NP> &m, const SmallDesc *sd, const 
     std::memset(&m, 0, sizeof(m));
     m.n = n;
     if (lin) m.lin = *lin;
-    // Problems of ONE workgroup first: they are chains of dependent latencies (4 us alone) that should start with the
-    // launch, not behind the hundreds of workgroups of the big problems (heaviest FIRST was measured: 9.3 us against 8.0).
-    int order[SMALL_MULTI];
+    // What the launch's own timeline showed (tools/small_timeline.py, movielens K = 30: 1,416 workgroups, 8.95 us): every problem
+    // had been given the lanes that suit it ALONE on an idle chip -- 32 lanes per output for a sum of 18 -- so the batch did not
+    // fit the chip at once (5-6 workgroups of 256 threads per CU), and the workgroups dealt last, the linear-logits
+    // producer's with the longest life of all (5.5 us), started 4-5 us late.  So (1) the biggest problems give up lanes until the
+    // launch is about one chipful, and (2) behind the problems of a few workgroups (chains of dependent latencies that should
+    // start with the launch) the problems go out by the work of one of their lanes, most first.
+    GroupLaunch g2[NP];
+    for (int i = 0; i < n; ++i) g2[i] = gl[i];
+    auto n_out_of = [&](int i) { return mode[i] == ALAN_MODE_BERNOULLI_LINEAR && lin ? lin->n_out : sd[i].n_out; };
+    auto n_red_of = [&](int i) { return mode[i] == ALAN_MODE_BERNOULLI_LINEAR && lin ? lin->n_red : sd[i].n_red; };
+    constexpr uint32_t CHIPFUL = 1024;
+    // (lanes that cost nothing to give up: a lane of the small kernel has four elements' loads in flight at once, so down to
+    // four elements per lane the walk is still one round of loads)
+    for (int i = 0; i < n; ++i) {
+        if (g2[i].block || mode[i] == ALAN_MODE_BERNOULLI_LINEAR || mode[i] == ALAN_MODE_NORMAL_TABLE || g2[i].grid <= 4) continue;
+        const uint64_t nr = n_red_of(i);
+        while (g2[i].logG > 0 && ((nr + (1ull << (g2[i].logG - 1)) - 1) >> (g2[i].logG - 1)) <= 4) g2[i].logG -= 1;
+        g2[i].grid = (uint32_t)((((uint64_t)n_out_of(i) << g2[i].logG) + 255) / 256);
+    }
+    for (;;) {
+        uint32_t total = 0;
+        int big = -1;
+        for (int i = 0; i < n; ++i) {
+            total += g2[i].grid;
+            if (!g2[i].block && g2[i].logG > 2 && g2[i].grid > 64 && (big < 0 || g2[i].grid > g2[big].grid)) big = i;
+        }
+        if (total <= CHIPFUL || big < 0) break;
+        g2[big].logG -= 1;
+        g2[big].grid = (uint32_t)((((uint64_t)n_out_of(big) << g2[big].logG) + 255) / 256);
+    }
+    int order[NP];
     for (int i = 0; i < n; ++i) order[i] = i;
-    auto weight = [&](int i) { return gl[i].grid <= 2 ? 0 : 1; };
+    auto weight = [&](int i) -> int64_t {
+        if (g2[i].grid <= 4) return (int64_t)1 << 40;
+        const int64_t per_lane = g2[i].block ? (int64_t)n_red_of(i) / 256 + 1 : ((int64_t)n_red_of(i) >> g2[i].logG) + 1;
+        return per_lane * (mode[i] == ALAN_MODE_BERNOULLI_LINEAR ? 8 : 1);       // (an element of it: a dot product)
+    };
     for (int i = 1; i < n; ++i)
-        for (int j = i; j > 0 && weight(order[j]) < weight(order[j - 1]); --j) std::swap(order[j], order[j - 1]);
+        for (int j = i; j > 0 && weight(order[j]) > weight(order[j - 1]); --j) std::swap(order[j], order[j - 1]);
     uint32_t blocks = 0;
     for (int k = 0; k < n; ++k) {
         const int i = order[k];
         m.head[k].mode = mode[i];
-        m.head[k].logG = gl[i].logG;
-        m.head[k].block = gl[i].block ? 1 : 0;
+        m.head[k].logG = g2[i].logG;
+        m.head[k].block = g2[i].block ? 1 : 0;
         m.head[k].first_block = m.first_block[k] = blocks;
-        blocks += gl[i].grid;
+        blocks += g2[i].grid;
         m.d[k] = sd[i];
     }
     for (int k = n; k < NP; ++k) m.first_block[k] = 0xffffffffu;

@@ -326,6 +326,18 @@ __global__ __launch_bounds__(256) void reduce_small_multi_kernel(const SmallMult
     small_multi_block<>(0, blockIdx.x);
 }
 
+#ifdef ALAN_TIMELINE
+}  // namespace alan
+extern "C" int alan_small_timeline_read(unsigned long long *host_out, int n_wgs) {
+    if (n_wgs > alan::SM_TL_WGS) n_wgs = alan::SM_TL_WGS;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(alan::sm_timeline), sizeof(unsigned long long) * n_wgs * alan::SM_TL_SLOTS) ==
+                   hipSuccess
+               ? alan::SM_TL_SLOTS : -1;
+}
+namespace alan {
+#endif
+
 int launch_small_multi(const SmallDesc *sd, const GroupLaunch *gl, const int *mode, int n, hipStream_t stream,
                        const LinDesc *lin, const alan_noise_t *noise, bool advance) {
     if (n < 1 || n > SMALL_MULTI) return ALAN_ERR_BAD_DESC;

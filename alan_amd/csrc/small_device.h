@@ -10,6 +10,22 @@ namespace alan {
 
 __device__ __forceinline__ void small_store(float *p, float v) { *p = v; }
 
+// Diagnostic build (make TIMELINE=1; tools/small_timeline.py): every workgroup of a multi-problem launch stamps s_memtime at
+// the phases of its life -- 0 entry, 1 its problem found and the descriptor's head read, 2 the first round of loads landed,
+// 3 the walk over the reduced dim done, 4 lanes combined and the result stored, 5 exit -- and leaves them, with
+// s_memrealtime of entry and exit, its problem and where it ran, in a buffer of the library's own ("show
+// where a 10 us kernel with < 1 MB of input spends its life").  In the default build no stamp executes.
+#ifdef ALAN_TIMELINE
+constexpr int SM_TL_SLOTS = 12, SM_TL_WGS = 4096;
+__device__ unsigned long long sm_timeline[SM_TL_WGS * SM_TL_SLOTS];
+__shared__ unsigned long long sm_tl[SM_TL_SLOTS];
+#define SM_STAMP(i) do { if (threadIdx.x == 0) sm_tl[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SM_STAMP_LANDED(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SM_STAMP(i); } while (0)
+#else
+#define SM_STAMP(i) ((void)0)
+#define SM_STAMP_LANDED(i) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Generated noise (alan_noise_t): Philox4x32-10 (Salmon et al., SC'11: the counter-based generator torch's own CUDA /
 // HIP sampling kernels use) keyed by the seed, counter = the element's index / 4; its four 32-bit words make four
@@ -226,15 +242,19 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
                 for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
                 if (MODE == ALAN_MODE_WEXPSUM) woff += idx * d.wrs[k];
             }
-            // unused factor slots alias factor 0 with zero strides: the load is harmless and never used
+            // (unused factor slots alias factor 0 with zero strides -- harmless to load, but a Normal producer's three factors
+            // were six loads per element, 24 per lane and round: the slots beyond nf are skipped, a scalar branch each)
 #pragma unroll
-            for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];
+            for (int f = 0; f < MAXF; ++f) val[u][f] = f < 2 || f < d.nf ? d.f[f][off[f]] : T(0);
             if (NOISY) {
                 if (noise) val[u][1] = noise_at(noise_seed, noise_base + (uint64_t)(int64_t)off[1]);
             }
             wv[u] = MODE == ALAN_MODE_WEXPSUM ? d.w[woff] : 0.f;
             off0[u] = off[0];
         }
+#ifdef ALAN_TIMELINE
+        if (r0 == gl) SM_STAMP_LANDED(2);
+#endif
         if ((MODE == ALAN_MODE_LSE || MODE == ALAN_MODE_SUM) && d.presum_n > 1) {
             // factor 0 is the sum of presum_n slices (role ALAN_PRESUM): the other slices, eight loads per element in
             // flight, added in slice order
@@ -258,6 +278,7 @@ __device__ __forceinline__ void small_body(const SmallDesc &d, const int logG, c
         for (int u = 0; u < UNR; ++u)
             accumulate<T, MODE>(m, s, val[u], wv[u], sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
     }
+    SM_STAMP(3);
     combine_lanes<T, MODE, BLOCK, NW>(m, s, G);
     if (active && gl == 0) {
         T v = (MODE == ALAN_MODE_LSE) ? lse_finish(m, s) : s;
@@ -408,6 +429,9 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             }
         }
         const float y = d.val[voff];
+#ifdef ALAN_TIMELINE
+        if (r == gl) SM_STAMP_LANDED(2);
+#endif
         float xl = 0.f;
 #pragma unroll
         for (int tm = 0; tm < LIN_T; ++tm) {
@@ -421,7 +445,8 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
             // (every load of a chunk issued before the first product: the kernel is a chain of load latencies -- four
             // products in flight made movielens' 18-event dot five round trips.  16 at a time (groups of four beyond the
             // length skipped): a chunk of 32 cost the kernel half its waves per SIMD in registers)
-            xl += lin_dot<16>(pa, pb, len, as, bs);
+            // (17-20 events -- movielens' 18 -- in ONE round trip: 20 loads per operand in flight; the sums' order is the same)
+            xl += len > 16 && len <= 20 ? lin_dot<20>(pa, pb, len, as, bs) : lin_dot<16>(pa, pb, len, as, bs);
         }
         // logsigmoid(x) = min(x, 0) - log(1 + exp(-|x|)) on the fast transcendental instructions (1 ulp each; 1 + e in
         // (1, 2] is rounded as the reference's log1p argument is): the accurate expf / log1pf were two thirds of an element
@@ -429,6 +454,7 @@ __device__ __forceinline__ void lin_body(const LinDesc &d, const int logG, const
         const float ls = fminf(xl, 0.f) - __builtin_amdgcn_logf(1.f + e) * 0.69314718055994530942f;
         s += ls - (1.f - y) * xl;
     }
+    SM_STAMP(3);
     combine_lanes<float, ALAN_MODE_SUM, BLOCK>(m, s, G);
     if (active && gl == 0) small_store(d.out + obase, s * d.out_scale + d.add_const);
 }
@@ -451,15 +477,32 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
     typedef __attribute__((address_space(4))) const char *kernarg_ptr;
     const char *base = (const char *)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + arg_off);
     const SmallMulti &m = *reinterpret_cast<const SmallMulti *>(base);
+#ifdef ALAN_TIMELINE
+    const unsigned long long sm_real0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0)
+        for (int i = 0; i < SM_TL_SLOTS; ++i) sm_tl[i] = 0;
+    SM_STAMP(0);
+#endif
     int p = 0;                                                            // workgroup-uniform
 #pragma unroll
     for (int i = 1; i < NP; ++i) p += vb >= m.first_block[i] ? 1 : 0;     // (constant offsets: one wide scalar load, no branch)
-    const typename SmallMulti::Head &hd =
-        *reinterpret_cast<const typename SmallMulti::Head *>(base + offsetof(SmallMulti, head) + (size_t)p * sizeof(typename SmallMulti::Head));
+    // (every problem's head fetched beside first_block[] -- constant offsets, the same round of scalar loads -- and picked by
+    // p afterwards: a fetch at an offset that depends on p was a third dependent round trip in front of the descriptor's)
+    typename SmallMulti::Head hd = m.head[0];
+#pragma unroll
+    for (int i = 1; i < NP; ++i) {
+        const typename SmallMulti::Head hi = m.head[i];
+        hd.mode = p == i ? hi.mode : hd.mode, hd.logG = p == i ? hi.logG : hd.logG;
+        hd.block = p == i ? hi.block : hd.block, hd.first_block = p == i ? hi.first_block : hd.first_block;
+    }
     const uint32_t bid = vb - hd.first_block;
     const SmallDesc &d = *reinterpret_cast<const SmallDesc *>(base + offsetof(SmallMulti, d) + (size_t)p * sizeof(SmallDesc));
     const bool block = hd.block != 0;
     const int logG = hd.logG;
+#ifdef ALAN_TIMELINE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(logG), "s"(bid) : "memory");
+    SM_STAMP(1);
+#endif
     const NoiseLaunch &nz = *reinterpret_cast<const NoiseLaunch *>(base + offsetof(SmallMulti, noise));
     // (the cell: {counter, seed}, written by the previous launch that drew -- read past the scalar and vector L1 caches)
     uint64_t cellv = 0ull, nseed = nz.seed;
@@ -492,6 +535,21 @@ __device__ __forceinline__ void small_multi_block(const size_t arg_off, const ui
         default: break;
     }
     if (nz.receipt || nz.advance) noise_finish(nz, cellv, nseed);
+#ifdef ALAN_TIMELINE
+    SM_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SM_STAMP(5);
+    if (threadIdx.x == 0 && vb < SM_TL_WGS) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sm_tl[6] = sm_real0, sm_tl[7] = __builtin_amdgcn_s_memrealtime();
+        sm_tl[8] = ((unsigned long long)xcc << 32) | hwid;
+        sm_tl[9] = ((unsigned long long)(unsigned)hd.mode << 32) | (unsigned)p;
+        sm_tl[10] = gridDim.x;
+        for (int i = 0; i < SM_TL_SLOTS; ++i) sm_timeline[vb * SM_TL_SLOTS + i] = sm_tl[i];
+    }
+#endif
 }
 
 }  // namespace alan

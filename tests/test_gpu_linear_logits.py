@@ -153,8 +153,10 @@ def test_in_a_multi_problem_launch_the_values_are_those_of_a_lone_launch():
             got = [c() for c in calls]
             assert N.n_pending() == len(calls)
         N.flush()
+    # (the same values -- not the same bits since round 4: a multi-problem launch takes lanes from its biggest problems until
+    # it is about one chipful, plan.h fill_small_multi, and a sum over fewer lanes is added up in another order)
     for a, b in zip(got, want):
-        assert t.equal(a, b)
+        t.testing.assert_close(a, b, rtol=2e-6, atol=2e-6 * float(b.abs().max()))
 
 
 @pytest.mark.parametrize("fixture,model", [("e2e_movielens_K10.pt", "movielens"), ("e2e_bus_breakdown_K3.pt", "bus_breakdown"),

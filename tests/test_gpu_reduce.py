@@ -545,10 +545,12 @@ def test_deferred_producers_go_out_as_one_launch_and_match_immediate_ones():
         # a consumer flushes the queue before it reads
         total, _ = E.reduce_factors([(got[3], (dm, dz)), (got[4], (dm, dz))], reduce=(dz,), plate=(dm,))
         assert N.n_pending() == 0
+    # (the same values, not the same bits: a multi-problem launch may give its biggest problems fewer lanes per output than
+    # they take alone -- plan.h fill_small_multi, round 4 -- and a sum over fewer lanes is added up in another order)
     for a, b in zip(got, want):
-        assert t.equal(a, b)
+        t.testing.assert_close(a, b, rtol=2e-6, atol=2e-6 * float(b.abs().max()))
     ref, _ = E.reduce_factors([(want[3], (dm, dz)), (want[4], (dm, dz))], reduce=(dz,), plate=(dm,))
-    assert t.equal(total, ref)
+    t.testing.assert_close(total, ref, rtol=2e-6, atol=2e-6 * float(ref.abs().max()))
     # outside deferring(), or with gradients enabled, may_defer() is inert
     with N.may_defer():
         calls[0]()
