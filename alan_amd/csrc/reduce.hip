@@ -133,7 +133,23 @@ __global__ __launch_bounds__(256) void reduce_small_kernel(const SmallDesc d, co
 // = 40 loads each, all of a thread's share in two rounds, and the 16 waves' (max, sum) pairs meet through LDS.
 template <int MODE, int UNR, int PF>
 __global__ __launch_bounds__(1024) void reduce_wide_kernel(const SmallDesc d) {
+#ifdef ALAN_TIMELINE
+    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0)
+        for (int i = 0; i < SM_TL_SLOTS; ++i) sm_tl[i] = 0;
+    SM_STAMP(0);
+#endif
     small_body<MODE, true, 16, UNR, PF>(d, 10, 0);
+#ifdef ALAN_TIMELINE
+    SM_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SM_STAMP(5);
+    if (threadIdx.x == 0) {                               // (the last row of the buffer: tools/small_timeline.py)
+        sm_tl[6] = real0, sm_tl[7] = __builtin_amdgcn_s_memrealtime();
+        sm_tl[9] = (100ull << 32), sm_tl[10] = 1;
+        for (int i = 0; i < SM_TL_SLOTS; ++i) sm_timeline[(SM_TL_WGS - 1) * SM_TL_SLOTS + i] = sm_tl[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -147,36 +147,50 @@ __device__ __forceinline__ void accumulate(T &m, T &s, const T (&val)[MAXF], T w
     }
 }
 
-// Lanes of a group (or the NW waves of a block) -> one value.
+// Lanes of a group (or the NW waves of a block) -> one value.  Log-sum-exp in two passes -- the maximum over the lanes first
+// (compares only), every lane's sum rescaled to it ONCE, then a plain sum -- where merging (max, sum) pairs step by step took
+// two exponentials per step and lane: the 1024-thread launch that ends an evaluation spent 3.5 of its 6.1 us there (six
+// shuffle steps, then fifteen dependent merges by one thread; tools/small_timeline.py).
+template <typename T>
+__device__ __forceinline__ void lse_rescale(T &m, T &s, T M) {
+    s = s * ((m == Num<T>::ninf()) ? T(0) : Num<T>::exp(m - M));      // (a NaN sum survives the multiply by 0, as it must)
+    m = M;
+}
 template <typename T, int MODE, bool BLOCK, int NW = 4>
 __device__ __forceinline__ void combine_lanes(T &m, T &s, uint32_t G) {
     const uint32_t WG = BLOCK ? 64u : G;  // lanes combined by shuffles
     if (MODE == ALAN_MODE_LSE) {
+        T M = m;
         for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) {
-            const T m2 = __shfl_xor(m, (int)ofs);
-            const T s2 = __shfl_xor(s, (int)ofs);
-            lse_merge(m, s, m2, s2);
+            const T m2 = __shfl_xor(M, (int)ofs);
+            M = M > m2 ? M : m2;
         }
-    } else {
-        for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
+        lse_rescale(m, s, M);
     }
+    for (uint32_t ofs = WG >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, (int)ofs);
     if (BLOCK) {
         __shared__ T sm[NW], ss[NW];
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        if (ln == 0) {
             sm[wv] = m;
             ss[wv] = s;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            m = sm[0];
-            s = ss[0];
-            for (int i = 1; i < NW; ++i) {
-                if (MODE == ALAN_MODE_LSE)
-                    lse_merge(m, s, sm[i], ss[i]);
-                else
-                    s += ss[i];
+        if (wv == 0) {                                   // the waves' values on the first wave's lanes, the same two passes
+            static_assert(NW <= 64 && (NW & (NW - 1)) == 0, "waves of a block: a power of two");
+            m = ln < NW ? sm[ln] : Num<T>::ninf();
+            s = ln < NW ? ss[ln] : T(0);
+            if (MODE == ALAN_MODE_LSE) {
+                T M = m;
+#pragma unroll
+                for (int ofs = NW >> 1; ofs > 0; ofs >>= 1) {
+                    const T m2 = __shfl_xor(M, ofs);
+                    M = M > m2 ? M : m2;
+                }
+                lse_rescale(m, s, M);
             }
+#pragma unroll
+            for (int ofs = NW >> 1; ofs > 0; ofs >>= 1) s += __shfl_xor(s, ofs);
         }
     }
 }

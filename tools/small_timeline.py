@@ -35,8 +35,9 @@ buf = (C.c_ulonglong * (SLOTS * NW))()
 L.alan_small_timeline_read.restype = C.c_int
 assert L.alan_small_timeline_read(buf, NW) == SLOTS
 tl = np.frombuffer(buf, dtype=np.uint64).reshape(NW, SLOTS).astype(np.int64)
+wide = tl[NW - 1].copy()                    # the evaluation's last launch (reduce_wide_kernel: one workgroup of 1024 threads)
 grid = int(tl[0, 10])
-tl = tl[:min(grid, NW)]
+tl = tl[:min(grid, NW - 1)]
 clock = np.median((tl[:, 5] - tl[:, 0]) / np.maximum(1, (tl[:, 7] - tl[:, 6]) * 10.0))      # cycles per ns
 first = tl[:, 6].min()
 entry, exit_ = (tl[:, 6] - first) * 10.0, (tl[:, 7] - first) * 10.0
@@ -65,3 +66,8 @@ per_cu = np.unique(cu, return_counts=True)[1]
 print(f"CUs used: {len(per_cu)}; workgroups per CU: min {per_cu.min()}, median {int(np.median(per_cu))}, max {per_cu.max()}")
 hist, edges = np.histogram(entry, bins=10)
 print("entry histogram (ns):", ", ".join(f"{int(edges[i])}-{int(edges[i + 1])}: {hist[i]}" for i in range(len(hist))))
+if wide[5] > 0:
+    w = (wide[1:6] - wide[0]) / clock
+    print(f"the evaluation's last launch (reduce_wide_kernel, 1 workgroup x 1024 threads; ns after its entry): descriptor + addresses + "
+          f"first loads landed {w[1]:.0f}, the slices' loads + walk done {w[2]:.0f}, 16 waves combined + result stored {w[3]:.0f}, "
+          f"drained {w[4]:.0f}; entry -> exit by the 100 MHz clock {(wide[7] - wide[6]) * 10} ns")
