@@ -50,8 +50,10 @@ prob_id = tl[:, 9] & 0xffffffff
 for p in sorted(set(prob_id.tolist())):
     sel = prob_id == p
     mode = int(tl[sel][0, 9] >> 32)
-    ph = (tl[sel][:, 1:6] - tl[sel][:, 0:5]) / clock
-    # (a phase a problem's body does not stamp reads as the previous stamp: its slot stays 0)
+    st = tl[sel][:, 0:6].astype(np.float64)
+    for i in range(1, 6):                       # (a phase a problem's body does not stamp: its slot stays 0 -> the previous stamp)
+        st[:, i] = np.where(st[:, i] > 0, st[:, i], st[:, i - 1])
+    ph = (st[:, 1:6] - st[:, 0:5]) / clock
     ph = np.where(tl[sel][:, 1:6] > 0, ph, np.nan)
     med = [np.nanmedian(ph[:, i]) if np.isfinite(ph[:, i]).any() else float("nan") for i in range(5)]
     e, x = entry[sel], exit_[sel]
