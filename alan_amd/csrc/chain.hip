@@ -1678,10 +1678,6 @@ __global__ __launch_bounds__(NT) void chain_tree_backward_kernel(const BwdTree a
         }
     }
     __syncthreads();
-    if (a.pad_ == 1) {                                    // (diagnostic, ALAN_CHAIN_BWD_DEBUG=1: the hand-over alone, no products)
-        for (int e = tid; e < KK; e += NT) put(dP + e, Gp[row_of(e) * KS + e - row_of(e) * K]), put(dC + e, 1.f);
-        return;
-    }
     // ---- the amax paths: eps * sum(G') shared among the maxima of a row of P / a column of C (their number: counted above)
     struct Sums {
         const T *Gp;
@@ -1775,8 +1771,6 @@ static int chain_backward_run(const void *ms, int64_t B, int64_t Tn, int64_t K, 
             if (!ws || ws_bytes < tl.bytes) return ALAN_ERR_WORKSPACE;
             a.total = total, a.timeout = 20000000u;                                    // 0.2 s of the 100 MHz clock
             a.K = (int32_t)K;
-            static const int dbg_knob = env_knob("ALAN_CHAIN_BWD_DEBUG");
-            a.pad_ = dbg_knob == 1 ? 1 : 0;
             a.root = (const float *)root, a.rB = K * K, a.rRow = K, a.rCol = 1;
             a.vec = (const float *)out_vec, a.grad_vec = (const float *)grad_vec, a.grad_chain = (const float *)grad_chain;
             const uint32_t n16 = (uint32_t)(tl.bytes / 16);                             // (rounds are 256-byte aligned)
