@@ -699,8 +699,10 @@ def normal_lse(value, loc, scale, smalls, plate, K, log_scale=False, partials=Fa
     partial sums, for a consumer that adds them on load (dims.PartialSumPT)."""
     tensors = [value[0], loc[0], scale[0], *[x for x, _ in smalls]]
     recording = t.is_grad_enabled() and any(x.requires_grad for x in tensors)
-    if recording or any(x.dtype != t.float32 for x in tensors):
-        N.flush()      # torch ops below (autograd's bookkeeping, a dtype conversion) read what queued producer launches write
+    if any(x.dtype != t.float32 for x in tensors):
+        N.flush()      # a dtype conversion below reads what queued producer launches write
+    # (with gradients recorded the step runs inside _NormalLse.forward -- grad mode off in there, like the producers' own
+    # forwards that queued the launches -- and autograd's bookkeeping reads no tensor data)
     # (else the queue stays as it is until native.run_normal_lse issues it in front of this launch -- nothing below reads a
     # tensor -- and the step's scale table can still join it: _ride_scale_table)
     a = _normal_lse_args(value, loc, scale, smalls, plate, K)
