@@ -240,10 +240,16 @@ __global__ __launch_bounds__(256) void bernoulli_linear_kernel(const LinDesc d, 
 
 // ALAN_MODE_BERNOULLI_LINEAR_GRAD: d out / d a for term 0's first operand,
 //   da[keep, e] = out_scale * sum_R G[keep] * (y - sigmoid(l)) * b[..., e],        l as in the forward.
-// A thread per output row: its row of `a` stays in registers (<= 32 events), for every element of the summed dims it
-// recomputes the logit, and accumulates the weighted rows of b.  (movielens: 9,000 rows x 5 films x 18 events.)
+// FOUR lanes per output row, eight events each (round 4; a thread per row was 36 workgroups at movielens -- 9,000 rows x 5 films
+// x 18 events -- each thread walking the summed dims one element at a time with 32 dependent-on-nothing loads it waited for
+// before the next element's: 10 us).  A lane keeps its eight events of the row of `a`; the summed dims go by in rounds of up to
+// four elements (eight at a time: no faster) whose loads -- 8 of b each, the values, the plain terms -- are all requested
+// before the first is used; the logit is
+// the four lanes' partial dots added by two shuffles.
 __global__ __launch_bounds__(256) void bernoulli_linear_grad_kernel(const LinDesc d) {
-    const uint32_t o0 = blockIdx.x * 256u + threadIdx.x;
+    constexpr int EW = 8, RU = 4;
+    const uint32_t t0 = blockIdx.x * 256u + threadIdx.x, o0 = t0 >> 2;
+    const int e0 = (int)(t0 & 3u) * EW;
     const bool active = o0 < d.n_out;
     uint32_t o = active ? o0 : d.n_out - 1u;
     int32_t abase[LIN_T], bbase[LIN_T], vbase = 0, obase = 0, gbase = 0;
@@ -264,66 +270,85 @@ __global__ __launch_bounds__(256) void bernoulli_linear_grad_kernel(const LinDes
         gbase += idx * d.gks[k];
     }
     const int len = d.len[0], as0 = d.ads[0], bs0 = d.bds[0];
-    float arow[32], acc[32];
+    float arow[EW], acc[EW];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        arow[e] = d.a[0][abase[0] + min(e, len - 1) * as0];
+    for (int e = 0; e < EW; ++e) {
+        arow[e] = e0 + e < len ? d.a[0][abase[0] + min(e0 + e, len - 1) * as0] : 0.f;
         acc[e] = 0.f;
     }
     const float gw = d.g[gbase] * d.out_scale;
-    for (uint32_t r = 0; r < d.n_red; ++r) {
-        int32_t aoff[LIN_T], boff[LIN_T], voff = vbase;
+    for (uint32_t r0 = 0; r0 < d.n_red; r0 += RU) {
+        float brow[RU][EW], y[RU], extra[RU];
+        int32_t aoff[RU][LIN_T], boff[RU][LIN_T];
 #pragma unroll
-        for (int tm = 0; tm < LIN_T; ++tm) {
-            aoff[tm] = abase[tm];
-            boff[tm] = bbase[tm];
-        }
-        uint32_t rr = r;
+        for (int u = 0; u < RU; ++u) {
+            if (u > 0 && r0 + (uint32_t)u >= d.n_red) {                          // (uniform: nothing to load)
 #pragma unroll
-        for (int k = LIN_NR - 1; k >= 0; --k) {
-            const uint32_t q = fd_div(rr, d.rdiv[k]);
-            const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
-            rr = q;
+                for (int e = 0; e < EW; ++e) brow[u][e] = 0.f;
+                y[u] = extra[u] = 0.f;
 #pragma unroll
-            for (int tm = 0; tm < LIN_T; ++tm) {
-                aoff[tm] += idx * d.ars[tm][k];
-                boff[tm] += idx * d.brs[tm][k];
-            }
-            voff += idx * d.vrs[k];
-        }
-        float brow[32];
-#pragma unroll
-        for (int e = 0; e < 32; ++e) brow[e] = d.b[0][boff[0] + min(e, len - 1) * bs0];
-        const float y = d.val[voff];
-        float xl = 0.f;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) xl = fmaf(e < len ? arow[e] : 0.f, brow[e], xl);
-#pragma unroll
-        for (int tm = 1; tm < LIN_T; ++tm) {
-            if (tm >= d.nt) continue;
-            if (d.b[tm] == nullptr) {
-                xl += d.a[tm][aoff[tm]];
+                for (int tm = 0; tm < LIN_T; ++tm) aoff[u][tm] = abase[tm], boff[u][tm] = bbase[tm];
                 continue;
             }
-            const float *pa = d.a[tm] + aoff[tm], *pb = d.b[tm] + boff[tm];
-            xl += lin_dot<16>(pa, pb, d.len[tm], d.ads[tm], d.bds[tm]);
-        }
-        // y - sigmoid(x), sigmoid on the fast transcendental instructions (rcp of 1 + 2^(-x log2 e))
-        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-xl * 1.44269504088896340736f));
-        const float c = gw * (y - sg);
+            const uint32_t r = r0 + (uint32_t)u;
+            int32_t voff = vbase;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) acc[e] = fmaf(c, brow[e], acc[e]);
+            for (int tm = 0; tm < LIN_T; ++tm) aoff[u][tm] = abase[tm], boff[u][tm] = bbase[tm];
+            uint32_t rr = r;
+#pragma unroll
+            for (int k = LIN_NR - 1; k >= 0; --k) {
+                const uint32_t q = fd_div(rr, d.rdiv[k]);
+                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+                rr = q;
+#pragma unroll
+                for (int tm = 0; tm < LIN_T; ++tm) {
+                    aoff[u][tm] += idx * d.ars[tm][k];
+                    boff[u][tm] += idx * d.brs[tm][k];
+                }
+                voff += idx * d.vrs[k];
+            }
+#pragma unroll
+            for (int e = 0; e < EW; ++e) brow[u][e] = d.b[0][boff[u][0] + min(e0 + e, len - 1) * bs0];
+            y[u] = d.val[voff];
+            extra[u] = 0.f;
+#pragma unroll
+            for (int tm = 1; tm < LIN_T; ++tm)
+                if (tm < d.nt && d.b[tm] == nullptr) extra[u] += d.a[tm][aoff[u][tm]];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (u > 0 && r0 + (uint32_t)u >= d.n_red) break;                   // (uniform)
+            float xl = 0.f;
+#pragma unroll
+            for (int e = 0; e < EW; ++e) xl = fmaf(arow[e], brow[u][e], xl);   // (arow is 0 beyond len)
+            xl += __shfl_xor(xl, 1);
+            xl += __shfl_xor(xl, 2);
+            xl += extra[u];
+#pragma unroll
+            for (int tm = 1; tm < LIN_T; ++tm) {
+                if (tm >= d.nt || d.b[tm] == nullptr) continue;
+                const float *pa = d.a[tm] + aoff[u][tm], *pb = d.b[tm] + boff[u][tm];
+                xl += lin_dot<16>(pa, pb, d.len[tm], d.ads[tm], d.bds[tm]);
+            }
+            // y - sigmoid(x), sigmoid on the fast transcendental instructions (rcp of 1 + 2^(-x log2 e))
+            const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-xl * 1.44269504088896340736f));
+            const float c = gw * (y[u] - sg);
+#pragma unroll
+            for (int e = 0; e < EW; ++e) acc[e] = fmaf(c, brow[u][e], acc[e]);
+        }
     }
     if (active) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e)
-            if (e < len) d.out[obase + e * d.ods] = acc[e];
+        for (int e = 0; e < EW; ++e)
+            if (e0 + e < len) d.out[obase + (e0 + e) * d.ods] = acc[e];
     }
 }
 
 int launch_lin_grad(const LinDesc &ld, hipStream_t stream, const EvPair &ev) {
     if (ld.n_out == 0) return ALAN_OK;
-    ALAN_LAUNCH_EXT(bernoulli_linear_grad_kernel, dim3((ld.n_out + 255) / 256), dim3(256), 0, stream, ev.start, ev.stop, 0, ld);
+    if (4ull * ld.n_out >= (1ull << 32)) return ALAN_ERR_UNSUPPORTED;             // (four lanes per row on a 32-bit thread index)
+    ALAN_LAUNCH_EXT(bernoulli_linear_grad_kernel, dim3((uint32_t)((4ull * ld.n_out + 255) / 256)), dim3(256), 0, stream, ev.start,
+                    ev.stop, 0, ld);
     return hipGetLastError() == hipSuccess ? ALAN_OK : ALAN_ERR_LAUNCH;
 }
 
