@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256) void reduce_small_plate_kernel(const SmallPlat
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) sc[f] = d.fscale[f];
     float total = 0.f;
-    for (uint32_t p = 0; p < d.n_plate; ++p) {
-        int32_t pb[MAXF], lp = lbase;
+    constexpr int UNR = 4;
+    // the offsets of plate element p: every factor's, and the lse output's
+    auto plate_offsets = [&](uint32_t p, int32_t (&pb)[MAXF], int32_t &lp) {
+        lp = lbase;
 #pragma unroll
         for (int f = 0; f < MAXF; ++f) pb[f] = base[f];
         uint32_t pp = p;
@@ -192,36 +194,71 @@ __global__ __launch_bounds__(256) void reduce_small_plate_kernel(const SmallPlat
             for (int f = 0; f < MAXF; ++f) pb[f] += idx * d.fps[f][k];
             lp += idx * d.lps[k];
         }
-        float m = Num<float>::ninf(), s = 0.f;
-        constexpr int UNR = 4;
-        for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
-            float val[UNR][MAXF];
+    };
+    // one round of a lane's loads: UNR elements of the reduced dims from r0 on
+    auto load_round = [&](const int32_t (&pb)[MAXF], uint32_t r0, float (&val)[UNR][MAXF]) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const uint32_t ru = r0 + (uint32_t)u * G;
-                uint32_t rr = ru < d.n_red ? ru : r0;     // clamped: the slot is masked in accumulate()
-                int32_t off[MAXF];
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t ru = r0 + (uint32_t)u * G;
+            uint32_t rr = ru < d.n_red ? ru : r0;         // clamped: the slot is masked in accumulate()
+            int32_t off[MAXF];
 #pragma unroll
-                for (int f = 0; f < MAXF; ++f) off[f] = pb[f];
+            for (int f = 0; f < MAXF; ++f) off[f] = pb[f];
 #pragma unroll
-                for (int k = SP_NR - 1; k >= 0; --k) {
-                    const uint32_t q = fd_div(rr, d.rdiv[k]);
-                    const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
-                    rr = q;
+            for (int k = SP_NR - 1; k >= 0; --k) {
+                const uint32_t q = fd_div(rr, d.rdiv[k]);
+                const int32_t idx = (int32_t)(rr - q * d.rdiv[k].d);
+                rr = q;
 #pragma unroll
-                    for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
-                }
-#pragma unroll
-                for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];    // (unused slots alias factor 0, stride 0)
+                for (int f = 0; f < MAXF; ++f) off[f] += idx * d.frs[f][k];
             }
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
-                accumulate<float, ALAN_MODE_LSE>(m, s, val[u], 0.f, sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
+            for (int f = 0; f < MAXF; ++f) val[u][f] = d.f[f][off[f]];        // (unused slots alias factor 0, stride 0)
         }
-        combine_lanes<float, ALAN_MODE_LSE, false>(m, s, G);
-        const float v = lse_finish(m, s);
-        if (active && gl == 0 && d.lse) d.lse[lp] = v;
-        total += v;
+    };
+    if (d.n_red <= UNR * G) {
+        // (the usual case: a plate element is ONE round of loads per lane -- the next element's are requested before this
+        // one's lanes are combined: the plate walk was a chain of load latencies, one per element)
+        float cur[UNR][MAXF], nxt[UNR][MAXF];
+        int32_t pb[MAXF], lp, lp_n = 0;
+        plate_offsets(0, pb, lp);
+        load_round(pb, gl < d.n_red ? gl : 0u, cur);
+        for (uint32_t p = 0; p < d.n_plate; ++p) {
+            if (p + 1 < d.n_plate) {
+                plate_offsets(p + 1, pb, lp_n);
+                load_round(pb, gl < d.n_red ? gl : 0u, nxt);
+            }
+            float m = Num<float>::ninf(), s = 0.f;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                accumulate<float, ALAN_MODE_LSE>(m, s, cur[u], 0.f, sc, d.nf, gl + (uint32_t)u * G < d.n_red);
+            combine_lanes<float, ALAN_MODE_LSE, false>(m, s, G);
+            const float v = lse_finish(m, s);
+            if (active && gl == 0 && d.lse) d.lse[lp] = v;
+            total += v;
+            lp = lp_n;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) cur[u][f] = nxt[u][f];
+        }
+    } else {
+        for (uint32_t p = 0; p < d.n_plate; ++p) {
+            int32_t pb[MAXF], lp;
+            plate_offsets(p, pb, lp);
+            float m = Num<float>::ninf(), s = 0.f;
+            for (uint32_t r0 = gl; r0 < d.n_red; r0 += UNR * G) {
+                float val[UNR][MAXF];
+                load_round(pb, r0, val);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    accumulate<float, ALAN_MODE_LSE>(m, s, val[u], 0.f, sc, d.nf, r0 + (uint32_t)u * G < d.n_red);
+            }
+            combine_lanes<float, ALAN_MODE_LSE, false>(m, s, G);
+            const float v = lse_finish(m, s);
+            if (active && gl == 0 && d.lse) d.lse[lp] = v;
+            total += v;
+        }
     }
     if (active && gl == 0) d.out[obase] = total + d.add_const;
 }
